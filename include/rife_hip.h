@@ -1,0 +1,87 @@
+/* librife_hip — C-ABI of the MI355X-native RIFE engine.
+ *
+ * This is the drop-in boundary for the reference's hot path `RIFE::load()` / `RIFE::process()`
+ * (nihui/rife-ncnn-vulkan src/rife.h:11-52, src/rife.cpp:127-379, 381-1212, 2462-3202): every entry point
+ * below replaces one member of that class.  Plain pointers and sizes only; no C++/torch types cross it.
+ * The C++ class `RIFE` in rife-ncnn-vulkan_amd/csrc/rife.h (same name, same signatures as the reference)
+ * is a thin shim over these calls, and INTEGRATION.md shows the binding a maintainer of the reference adds.
+ *
+ * Error convention (reference: `int` return, 0 = ok, src/rife.cpp:378,1211,3201): 0 on success, negative
+ * on failure; rife_hip_last_error() returns a thread-local message.  Nothing throws across this boundary.
+ * There is NO CPU fallback: every compute entry point fails (-RIFE_HIP_ENODEV) when no HIP device exists.
+ */
+#ifndef RIFE_HIP_H
+#define RIFE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RIFE_HIP_EINVAL   1   /* bad argument */
+#define RIFE_HIP_ENODEV   2   /* no such HIP device / no GPU */
+#define RIFE_HIP_EIO      3   /* model file missing or malformed */
+#define RIFE_HIP_EMODEL   4   /* graph is not a supported RIFE family */
+#define RIFE_HIP_EHIP     5   /* HIP runtime error */
+#define RIFE_HIP_ENOSYS   6   /* mode not implemented */
+
+typedef struct rife_hip rife_hip_t;
+
+/* ncnn::get_gpu_count() as used by the reference CLI (src/main.cpp:792-802). */
+int rife_hip_device_count(void);
+
+/* RIFE::RIFE(gpuid, tta_mode, tta_temporal_mode, uhd_mode, num_threads, rife_v2, rife_v4)  src/rife.cpp:27-47.
+ * gpuid = HIP device ordinal (the reference's -1 = CPU device is not served by this library). */
+rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int uhd_mode, int num_threads,
+                            int rife_v2, int rife_v4);
+
+/* RIFE::~RIFE()  src/rife.cpp:49-78 */
+void rife_hip_destroy(rife_hip_t* r);
+
+/* RIFE::load(modeldir)  src/rife.cpp:127-379 — reads <modeldir>/flownet.{param,bin} (+ contextnet, fusionnet
+ * unless rife_v4), validates the topology against the compiled-in schedules, packs and uploads the weights. */
+int rife_hip_load(rife_hip_t* r, const char* modeldir);
+
+/* RIFE::process(in0image, in1image, timestep, outimage)  src/rife.cpp:381-1212 / 2462-3202.
+ * Host buffers: tightly packed u8 HWC RGB, w*h*3 bytes each (the ncnn::Mat the CLI builds, src/main.cpp:187,332).
+ * Re-entrant on a const object from several host threads (src/main.cpp:860-863). */
+int rife_hip_process(const rife_hip_t* r, const uint8_t* in0_rgb, const uint8_t* in1_rgb, int w, int h,
+                     float timestep, uint8_t* out_rgb);
+
+/* Same, with all three frames already resident in device memory (what ncnn's VkMat path does internally between
+ * record_clone and submit, src/rife.cpp:2522-2530,3176-3186).  Work is enqueued on `hip_stream` (a hipStream_t;
+ * NULL = the engine's own stream) and the call returns without synchronising when a stream is given. */
+int rife_hip_process_device(const rife_hip_t* r, const void* d_in0_rgb, const void* d_in1_rgb, int w, int h,
+                            float timestep, void* d_out_rgb, void* hip_stream);
+
+const char* rife_hip_last_error(void);
+
+/* ---- measurement hooks (bench.py / profiles) ---------------------------------------------------------------
+ * When enabled, every launch of the engine's kernels is bracketed by HIP events on the launch stream; read-out
+ * synchronises and returns per-kernel-class totals.  `names` receives '\n'-separated class names. */
+int rife_hip_profile_enable(rife_hip_t* r, int on);
+int rife_hip_profile_read(rife_hip_t* r, char* names, size_t names_cap, double* total_ms, long long* launches,
+                          double* flops, int max_classes);   /* returns number of classes */
+
+/* ---- stage taps for parity tests (the reference's Extractor can extract / inject `flow0..flow3`,
+ * src/rife.cpp:2653-2669; these do the same for the v4 schedule).  Planar CHW fp32 host arrays. ------------- */
+int rife_hip_v4_extract_flow(const rife_hip_t* r, const uint8_t* in0_rgb, const uint8_t* in1_rgb, int w, int h,
+                             float timestep, int fi, const float* const* inject, int n_inject, float* out6chw);
+
+/* ---- single-kernel entry points for per-kernel parity tests (host arrays, planar CHW fp32 like ncnn::Mat) --- */
+/* 3x3 conv, pad 1, stride 1|2, + bias, optional residual add (same shape as output), per-channel negative slope
+ * (1.0 = none, 0.2 = LeakyReLU(0.2), PReLU slopes otherwise): ncnn Convolution (+BinaryOp add +ReLU/PReLU). */
+int rife_hip_op_conv3x3(int gpuid, const float* x_chw, int c, int h, int w, const float* weight_oihw, const float* bias,
+                        int outc, int stride, const float* residual_chw, const float* slope, float* out_chw);
+/* 4x4 stride-2 pad-1 transposed conv (ncnn Deconvolution, weights [oc][ic][4][4]) + per-channel slope. */
+int rife_hip_op_deconv4x4(int gpuid, const float* x_chw, int c, int h, int w, const float* weight_oihw, const float* bias,
+                          int outc, const float* slope, float* out_chw);
+/* rife.Warp (src/warp.cpp:96-168): image c x h x w, flow 2 x h x w. */
+int rife_hip_op_warp(int gpuid, const float* image_chw, const float* flow_chw, int c, int h, int w, float* out_chw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIFE_HIP_H */

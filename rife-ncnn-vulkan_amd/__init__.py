@@ -1,0 +1,174 @@
+"""rife-ncnn-vulkan_amd — MI355X-native RIFE frame interpolation behind the reference's `RIFE` surface.
+
+Python host-side mirror of the reference's C++ class (nihui/rife-ncnn-vulkan src/rife.h:11-52):
+
+    r = RIFE(gpuid, tta_mode=False, tta_temporal_mode=False, uhd_mode=False, num_threads=1, rife_v2=False, rife_v4=False)
+    r.load(modeldir)                       # RIFE::load,    src/rife.cpp:127-379
+    out = r.process(in0, in1, timestep)    # RIFE::process, src/rife.cpp:381-1212 / 2462-3202
+
+Everything is computed by the hand-written HIP kernels in csrc/ through the C-ABI of include/rife_hip.h
+(librife_hip.so).  There is no CPU or PyTorch fallback: importing works without a GPU, computing does not.
+The package name contains '-' and '.', so import it with importlib.import_module("rife-ncnn-vulkan_amd").
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librife_hip.so")
+_lib = None
+
+# every symbol include/rife_hip.h declares
+C_ABI_SYMBOLS = [
+    "rife_hip_device_count", "rife_hip_create", "rife_hip_destroy", "rife_hip_load", "rife_hip_process",
+    "rife_hip_process_device", "rife_hip_last_error", "rife_hip_profile_enable", "rife_hip_profile_read",
+    "rife_hip_v4_extract_flow", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
+]
+
+
+def build(force=False):
+    """Compile librife_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(_HERE, "..", "include", "rife_hip.h")]
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", csrc] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def lib():
+    """Load the C-ABI library.  If PyTorch-ROCm is importable it is imported first so that both share one
+    libamdhip64 (same SONAME); the library itself only needs the HIP runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("librife_hip.so is not built (run __graft_entry__.build() or make -C rife-ncnn-vulkan_amd/csrc); "
+                           "there is no fallback path")
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    L.rife_hip_device_count.restype = ci
+    L.rife_hip_create.restype = vp
+    L.rife_hip_create.argtypes = [ci] * 7
+    L.rife_hip_destroy.argtypes = [vp]
+    L.rife_hip_load.argtypes = [vp, ctypes.c_char_p]
+    L.rife_hip_process.argtypes = [vp, vp, vp, ci, ci, cf, vp]
+    L.rife_hip_process_device.argtypes = [vp, vp, vp, ci, ci, cf, vp, vp]
+    L.rife_hip_last_error.restype = ctypes.c_char_p
+    L.rife_hip_profile_enable.argtypes = [vp, ci]
+    L.rife_hip_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, vp, vp, vp, ci]
+    L.rife_hip_v4_extract_flow.argtypes = [vp, vp, vp, ci, ci, cf, ci, vp, ci, vp]
+    L.rife_hip_op_conv3x3.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, ci, vp, vp, vp]
+    L.rife_hip_op_deconv4x4.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, vp, vp]
+    L.rife_hip_op_warp.argtypes = [ci, vp, vp, ci, ci, ci, vp]
+    _lib = L
+    return L
+
+
+class RifeError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RifeError("%s failed (%d): %s" % (what, rc, lib().rife_hip_last_error().decode()))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def device_count():
+    return lib().rife_hip_device_count()
+
+
+class RIFE:
+    """Same constructor arguments, in the same order, as the reference's `RIFE` (src/rife.h:14)."""
+
+    def __init__(self, gpuid, tta_mode=False, tta_temporal_mode=False, uhd_mode=False, num_threads=1, rife_v2=False, rife_v4=False):
+        self._h = lib().rife_hip_create(int(gpuid), int(tta_mode), int(tta_temporal_mode), int(uhd_mode), int(num_threads),
+                                        int(rife_v2), int(rife_v4))
+        if not self._h:
+            raise RifeError("rife_hip_create: " + lib().rife_hip_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rife_hip_destroy(self._h)
+            self._h = None
+
+    def load(self, modeldir):
+        _check(lib().rife_hip_load(self._h, os.fspath(modeldir).encode()), "load")
+        return 0
+
+    def process(self, in0image, in1image, timestep, outimage=None):
+        """in0image / in1image: (h, w, 3) uint8 RGB arrays (the ncnn::Mat the CLI builds, src/main.cpp:187)."""
+        a = np.ascontiguousarray(in0image, dtype=np.uint8)
+        b = np.ascontiguousarray(in1image, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 3 or a.shape != b.shape:
+            raise ValueError("frames must be (h, w, 3) uint8 arrays of equal size")
+        h, w, _ = a.shape
+        out = outimage if outimage is not None else np.empty_like(a)
+        _check(lib().rife_hip_process(self._h, _p(a), _p(b), w, h, float(timestep), _p(out)), "process")
+        return out
+
+    def process_device(self, d_in0, d_in1, w, h, timestep, d_out, stream=None):
+        """Device pointers (ints) to tightly packed u8 HWC RGB frames; enqueues on `stream` (hipStream_t as int)."""
+        _check(lib().rife_hip_process_device(self._h, d_in0, d_in1, w, h, float(timestep), d_out, stream), "process_device")
+
+    # ---- measurement / parity taps ----
+    def profile_enable(self, on=True):
+        _check(lib().rife_hip_profile_enable(self._h, int(on)), "profile_enable")
+
+    def profile_read(self):
+        names = ctypes.create_string_buffer(4096)
+        ms = np.zeros(64, np.float64); n = np.zeros(64, np.int64); fl = np.zeros(64, np.float64)
+        k = lib().rife_hip_profile_read(self._h, names, 4096, _p(ms), _p(n), _p(fl), 64)
+        nm = names.value.decode().split("\n")
+        return {nm[i]: dict(ms=float(ms[i]), launches=int(n[i]), flops=float(fl[i])) for i in range(k)}
+
+    def v4_extract_flow(self, in0image, in1image, timestep, fi, inject=()):
+        a = np.ascontiguousarray(in0image, dtype=np.uint8); b = np.ascontiguousarray(in1image, dtype=np.uint8)
+        h, w, _ = a.shape
+        wp, hp = (w + 31) // 32 * 32, (h + 31) // 32 * 32
+        s = (8, 4, 2, 1)[fi]
+        out = np.empty((6, hp // s, wp // s), np.float32)
+        inj = [np.ascontiguousarray(f, dtype=np.float32) for f in inject]
+        arr = (ctypes.c_void_p * max(1, len(inj)))(*[f.ctypes.data for f in inj])
+        _check(lib().rife_hip_v4_extract_flow(self._h, _p(a), _p(b), w, h, float(timestep), fi, arr, len(inj), _p(out)), "v4_extract_flow")
+        return out
+
+
+# ---- single-kernel entry points (planar CHW float32 numpy arrays) ----
+def op_conv3x3(x, weight, bias, stride=1, residual=None, slope=None, gpuid=0):
+    x = np.ascontiguousarray(x, np.float32); weight = np.ascontiguousarray(weight, np.float32); bias = np.ascontiguousarray(bias, np.float32)
+    c, h, w = x.shape
+    oc = weight.shape[0]
+    out = np.empty((oc, (h - 1) // stride + 1, (w - 1) // stride + 1), np.float32)
+    res = None if residual is None else np.ascontiguousarray(residual, np.float32)
+    sl = None if slope is None else np.ascontiguousarray(slope, np.float32)
+    _check(lib().rife_hip_op_conv3x3(gpuid, _p(x), c, h, w, _p(weight), _p(bias), oc, stride, _p(res), _p(sl), _p(out)), "op_conv3x3")
+    return out
+
+
+def op_deconv4x4(x, weight, bias, slope=None, gpuid=0):
+    x = np.ascontiguousarray(x, np.float32); weight = np.ascontiguousarray(weight, np.float32); bias = np.ascontiguousarray(bias, np.float32)
+    c, h, w = x.shape
+    oc = weight.shape[0]
+    out = np.empty((oc, 2 * h, 2 * w), np.float32)
+    sl = None if slope is None else np.ascontiguousarray(slope, np.float32)
+    _check(lib().rife_hip_op_deconv4x4(gpuid, _p(x), c, h, w, _p(weight), _p(bias), oc, _p(sl), _p(out)), "op_deconv4x4")
+    return out
+
+
+def op_warp(image, flow, gpuid=0):
+    image = np.ascontiguousarray(image, np.float32); flow = np.ascontiguousarray(flow, np.float32)
+    c, h, w = image.shape
+    out = np.empty_like(image)
+    _check(lib().rife_hip_op_warp(gpuid, _p(image), _p(flow), c, h, w, _p(out)), "op_warp")
+    return out

@@ -1,0 +1,235 @@
+// Bandwidth-bound kernels of the RIFE v4 schedule: pre/post-processing, the backward bilinear warp,
+// bilinear resampling, flow/mask update and the final blend.  Each restates the arithmetic of one
+// reference shader / CPU loop literally (same operation order, two roundings per a*b+c: this TU is
+// compiled with -ffp-contract=off), so that given identical inputs the outputs are bit-identical to the
+// CPU path they are tested against:
+//   rife_preproc.comp:33-66 / rife.cpp:4152-4211      -> k_preproc (stores the u8 image, /255 applied at use)
+//   warp.comp:24-69 / warp.cpp:96-168                  -> warp_sample(), k_warp_chw
+//   ncnn Interp bilinear (flownet.param:10,47,52,...)  -> fused into k_assemble* / k_flow_update
+//   flownet.param:49-62,99-115,152-165,202-217         -> k_assemble<S>, k_flow_update<S>, k_final
+//   rife_postproc.comp:33-63 / rife.cpp:4373-4397      -> k_final
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rife {
+
+// ---- images are kept as padded RGBX u8 (4 B / pixel): x * (1/255.f) is recomputed at every use, which is
+// bit-identical to storing the fp32 plane (rife.cpp:4167: `*outptr++ = *ptr++ * (1 / 255.f)`) and makes the
+// 4-tap warp gather a single dword per tap for all three channels. ----
+__global__ void k_preproc(const uint8_t* __restrict__ rgb, int w, int h, uint32_t* __restrict__ out, int wp, int hp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wp) return;
+    uint32_t v = 0;
+    if (x < w && y < h) {
+        const uint8_t* p = rgb + ((size_t)y * w + x) * 3;
+        v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    }
+    out[(size_t)y * wp + x] = v;
+}
+
+__device__ __forceinline__ float3 unpack_rgb(uint32_t v) {
+    const float k = 1 / 255.f;
+    return make_float3((float)(v & 0xff) * k, (float)((v >> 8) & 0xff) * k, (float)((v >> 16) & 0xff) * k);
+}
+
+// rife.Warp for a 3-channel RGBX image: out = bilerp(img, x + fx, y + fy) with the reference's
+// clamp-then-alpha rule (warp.cpp:126-146).
+struct WarpTaps { int i00, i01, i10, i11; float alpha, beta; };
+
+__device__ __forceinline__ WarpTaps warp_taps(int x, int y, float flow_x, float flow_y, int w, int h) {
+    const float sample_x = (float)x + flow_x;
+    const float sample_y = (float)y + flow_y;
+    int x0 = (int)floorf(sample_x);
+    int y0 = (int)floorf(sample_y);
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = min(max(x0, 0), w - 1);
+    y0 = min(max(y0, 0), h - 1);
+    x1 = min(max(x1, 0), w - 1);
+    y1 = min(max(y1, 0), h - 1);
+    WarpTaps t;
+    t.alpha = sample_x - (float)x0;
+    t.beta = sample_y - (float)y0;
+    t.i00 = y0 * w + x0; t.i01 = y0 * w + x1; t.i10 = y1 * w + x0; t.i11 = y1 * w + x1;
+    return t;
+}
+
+__device__ __forceinline__ float warp_lerp(float v0, float v1, float v2, float v3, float alpha, float beta) {
+    const float v4 = v0 * (1 - alpha) + v1 * alpha;
+    const float v5 = v2 * (1 - alpha) + v3 * alpha;
+    return v4 * (1 - beta) + v5 * beta;
+}
+
+__device__ __forceinline__ float3 warp_rgbx(const uint32_t* __restrict__ img, int x, int y, float fx, float fy, int w, int h) {
+    const WarpTaps t = warp_taps(x, y, fx, fy, w, h);
+    const float3 a = unpack_rgb(img[t.i00]), b = unpack_rgb(img[t.i01]), c = unpack_rgb(img[t.i10]), d = unpack_rgb(img[t.i11]);
+    return make_float3(warp_lerp(a.x, b.x, c.x, d.x, t.alpha, t.beta), warp_lerp(a.y, b.y, c.y, d.y, t.alpha, t.beta),
+                       warp_lerp(a.z, b.z, c.z, d.z, t.alpha, t.beta));
+}
+
+// generic rife.Warp on planar CHW fp32 (per-kernel parity test entry point; v2.3 context features)
+__global__ void k_warp_chw(const float* __restrict__ image, const float* __restrict__ flow, float* __restrict__ out, int c, int h, int w) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const size_t plane = (size_t)w * h;
+    const WarpTaps t = warp_taps(x, y, flow[(size_t)y * w + x], flow[plane + (size_t)y * w + x], w, h);
+    for (int q = 0; q < c; q++) {
+        const float* im = image + q * plane;
+        out[q * plane + (size_t)y * w + x] = warp_lerp(im[t.i00], im[t.i01], im[t.i10], im[t.i11], t.alpha, t.beta);
+    }
+}
+
+// ncnn bilinear downscale by 2^k (align_corner=0): source centre falls exactly between two pixels, so both
+// weights are 0.5: rows = S[sx]*a0 + S[sx+1]*a1 (horizontal), D = rows0*b0 + rows1*b1 (vertical).
+__device__ __forceinline__ float down4(float v00, float v01, float v10, float v11) {
+    const float r0 = v00 * 0.5f + v01 * 0.5f;
+    const float r1 = v10 * 0.5f + v11 * 0.5f;
+    return r0 * 0.5f + r1 * 0.5f;
+}
+
+// Block-0 input: x = Interp(1/8)(Concat(in0, in1, in2)) -> NHWC8 {in0.rgb, in1.rgb, t, 0}   (flownet.param:9-10)
+__global__ void k_assemble0(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float timestep,
+                            float* __restrict__ X, int wp, int hp) {
+    const int Wb = wp / 8, Hb = hp / 8;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= Wb || y >= Hb) return;
+    const int sx = 8 * x + 3, sy = 8 * y + 3;
+    const size_t i00 = (size_t)sy * wp + sx, i10 = i00 + wp;
+    const float3 a0 = unpack_rgb(img0[i00]), a1 = unpack_rgb(img0[i00 + 1]), a2 = unpack_rgb(img0[i10]), a3 = unpack_rgb(img0[i10 + 1]);
+    const float3 b0 = unpack_rgb(img1[i00]), b1 = unpack_rgb(img1[i00 + 1]), b2 = unpack_rgb(img1[i10]), b3 = unpack_rgb(img1[i10 + 1]);
+    float4 o0, o1;
+    o0.x = down4(a0.x, a1.x, a2.x, a3.x); o0.y = down4(a0.y, a1.y, a2.y, a3.y); o0.z = down4(a0.z, a1.z, a2.z, a3.z);
+    o0.w = down4(b0.x, b1.x, b2.x, b3.x); o1.x = down4(b0.y, b1.y, b2.y, b3.y); o1.y = down4(b0.z, b1.z, b2.z, b3.z);
+    o1.z = down4(timestep, timestep, timestep, timestep);
+    o1.w = 0.f;
+    float4* dst = reinterpret_cast<float4*>(X + ((size_t)y * Wb + x) * 8);
+    dst[0] = o0; dst[1] = o1;
+}
+
+// Blocks 1..3 input (flownet.param:52-62, 107-115, 160-165):
+//   x = Concat(Interp(1/S)(Concat(warp(in0,F.xy), warp(in1,F.zw), in2, M)), Interp(1/S)(F)/S)  -> NHWC16 (12 + 4 zero)
+template <int S>
+__global__ void k_assemble(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float timestep,
+                           const float4* __restrict__ F, const float* __restrict__ M, float* __restrict__ X, int wp, int hp) {
+    const int Wb = wp / S, Hb = hp / S;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= Wb || y >= Hb) return;
+    float o[12];
+    if (S == 1) {
+        const size_t i = (size_t)y * wp + x;
+        const float4 f = F[i];
+        const float3 w0 = warp_rgbx(img0, x, y, f.x, f.y, wp, hp);
+        const float3 w1 = warp_rgbx(img1, x, y, f.z, f.w, wp, hp);
+        o[0] = w0.x; o[1] = w0.y; o[2] = w0.z; o[3] = w1.x; o[4] = w1.y; o[5] = w1.z; o[6] = timestep; o[7] = M[i];
+        o[8] = f.x; o[9] = f.y; o[10] = f.z; o[11] = f.w;
+    } else {
+        const int sx = S * x + S / 2 - 1, sy = S * y + S / 2 - 1;
+        float v[4][12];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int px = sx + (k & 1), py = sy + (k >> 1);
+            const size_t i = (size_t)py * wp + px;
+            const float4 f = F[i];
+            const float3 w0 = warp_rgbx(img0, px, py, f.x, f.y, wp, hp);
+            const float3 w1 = warp_rgbx(img1, px, py, f.z, f.w, wp, hp);
+            v[k][0] = w0.x; v[k][1] = w0.y; v[k][2] = w0.z; v[k][3] = w1.x; v[k][4] = w1.y; v[k][5] = w1.z;
+            v[k][6] = timestep; v[k][7] = M[i];
+            v[k][8] = f.x; v[k][9] = f.y; v[k][10] = f.z; v[k][11] = f.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 12; c++) o[c] = down4(v[0][c], v[1][c], v[2][c], v[3][c]);
+#pragma unroll
+        for (int c = 8; c < 12; c++) o[c] = o[c] / (float)S;        // BinaryOp div by scalar (flownet.param:53,108)
+    }
+    float4* dst = reinterpret_cast<float4*>(X + ((size_t)y * Wb + x) * 16);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    dst[2] = make_float4(o[8], o[9], o[10], o[11]);
+    dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ncnn linear_coeffs for an upscale by S (power of two): fx = (dx + 0.5) / S - 0.5 is exact in fp32 here
+// (the reference computes it in double and rounds to float; all intermediates are dyadic and short).
+__device__ __forceinline__ void up_coeff(int d, int S, int in, int& s0, float& a0, float& a1) {
+    float f = ((float)d + 0.5f) * (1.0f / (float)S) - 0.5f;
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= in - 1) { s = in - 2; f = 1.f; }
+    s0 = s; a0 = 1.f - f; a1 = f;
+}
+
+// flow_b is kept as [Hb][Wb][8] fp32 {x, y, z, w, mask, unused, 0, 0}.
+// After block b < 3 (flownet.param:47-58, 99-105, 152-158):
+//   u = Interp(S)(flow_b);  b == 0: F = u[0:4] * S, M = u[4];   b > 0: F = F*1 + u[0:4]*S (Eltwise), M = M + u[4]
+template <int S, bool FIRST>
+__global__ void k_flow_update(const float* __restrict__ flow, float4* __restrict__ F, float* __restrict__ M, int wp, int hp) {
+    const int Wb = wp / S, Hb = hp / S;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wp) return;
+    int sx, sy; float a0, a1, b0, b1;
+    up_coeff(x, S, Wb, sx, a0, a1);
+    up_coeff(y, S, Hb, sy, b0, b1);
+    const float* p00 = flow + ((size_t)sy * Wb + sx) * 8;
+    const float* p10 = p00 + (size_t)Wb * 8;
+    const float4 q00 = *reinterpret_cast<const float4*>(p00), q01 = *reinterpret_cast<const float4*>(p00 + 8);
+    const float4 q10 = *reinterpret_cast<const float4*>(p10), q11 = *reinterpret_cast<const float4*>(p10 + 8);
+    const float m00 = p00[4], m01 = p00[12], m10 = p10[4], m11 = p10[12];
+#define RIFE_UP(c00, c01, c10, c11) (((c00) * a0 + (c01) * a1) * b0 + ((c10) * a0 + (c11) * a1) * b1)
+    float4 u;
+    u.x = RIFE_UP(q00.x, q01.x, q10.x, q11.x);
+    u.y = RIFE_UP(q00.y, q01.y, q10.y, q11.y);
+    u.z = RIFE_UP(q00.z, q01.z, q10.z, q11.z);
+    u.w = RIFE_UP(q00.w, q01.w, q10.w, q11.w);
+    const float um = RIFE_UP(m00, m01, m10, m11);
+#undef RIFE_UP
+    const size_t i = (size_t)y * wp + x;
+    const float s = (float)S;
+    if (FIRST) {
+        F[i] = make_float4(u.x * s, u.y * s, u.z * s, u.w * s);
+        M[i] = um;
+    } else {
+        const float4 f = F[i];
+        F[i] = make_float4(f.x * 1.0f + u.x * s, f.y * 1.0f + u.y * s, f.z * 1.0f + u.z * s, f.w * 1.0f + u.w * s);
+        M[i] = M[i] + um;
+    }
+}
+
+// Tail of the graph + postproc (flownet.param:202-217, rife.cpp:4373-4397 / rife_postproc.comp:39-62):
+//   F += flow3[0:4]; M += flow3[4]; m = sigmoid(M); out = warp(in0,F.xy)*m + warp(in1,F.zw)*(1-m);
+//   u8 = clamp((int)(out*255 + 0.5), 0, 255), cropped to w x h, HWC RGB.
+__global__ void k_final(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, const float4* __restrict__ F,
+                        const float* __restrict__ M, const float* __restrict__ flow3, uint8_t* __restrict__ out, int w, int h, int wp, int hp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t i = (size_t)y * wp + x;
+    const float* fl = flow3 + i * 8;
+    const float4 d = *reinterpret_cast<const float4*>(fl);
+    float4 f = F[i];
+    f.x = f.x + d.x; f.y = f.y + d.y; f.z = f.z + d.z; f.w = f.w + d.w;
+    const float mm = M[i] + fl[4];
+    const float m = 1.f / (1.f + expf(-mm));
+    const float rm = 1.0f - m;
+    const float3 w1 = warp_rgbx(img1, x, y, f.z, f.w, wp, hp);
+    const float3 w0 = warp_rgbx(img0, x, y, f.x, f.y, wp, hp);
+    const float r = w0.x * m + w1.x * rm, g = w0.y * m + w1.y * rm, b = w0.z * m + w1.z * rm;
+    uint8_t* o = out + ((size_t)y * w + x) * 3;
+    o[0] = (uint8_t)min(max((int)(r * 255.f + 0.5f), 0), 255);
+    o[1] = (uint8_t)min(max((int)(g * 255.f + 0.5f), 0), 255);
+    o[2] = (uint8_t)min(max((int)(b * 255.f + 0.5f), 0), 255);
+}
+
+// layout converters for the parity taps (planar CHW fp32 <-> NHWC with a channel stride)
+__global__ void k_chw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int c, int h, int w, int ld) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    for (int q = 0; q < ld; q++) dst[((size_t)y * w + x) * ld + q] = q < c ? src[((size_t)q * h + y) * w + x] : 0.f;
+}
+
+__global__ void k_nhwc_to_chw(const float* __restrict__ src, float* __restrict__ dst, int c, int h, int w, int ld) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    for (int q = 0; q < c; q++) dst[((size_t)q * h + y) * w + x] = src[((size_t)y * w + x) * ld + q];
+}
+
+}  // namespace rife

@@ -1,0 +1,693 @@
+// librife_hip: host side of the MI355X-native RIFE engine + the C-ABI declared in include/rife_hip.h.
+//
+// What of the reference this file replaces (all under /root/reference/src):
+//   RIFE::RIFE / ~RIFE        rife.cpp:27-78     -> rife_hip_create / rife_hip_destroy
+//   RIFE::load                rife.cpp:127-379   -> rife_hip_load  (ncnn::Net::load_param/load_model -> NcnnModel,
+//                                                  pipeline creation -> kernels are compiled ahead of time)
+//   RIFE::process_v4          rife.cpp:2462-3202 -> Engine::run_v4 (one fixed schedule instead of ncnn's graph walk)
+//   ncnn VkCompute record/submit/wait (rife.cpp:2522-2530, 3176-3186) -> one HIP stream per in-flight pair
+// There is deliberately no CPU path in this library: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rife_hip.h"
+#include "conv_mfma.h"
+#include "elementwise.h"
+#include "model_hashes.h"
+#include "ncnn_model.h"
+
+namespace rife {
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return -code; }
+
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail(RIFE_HIP_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// conv layer: host-side description + packed device weights
+// ------------------------------------------------------------------------------------------------
+struct ConvLayer {
+    int cin = 0, cin_p = 0, cout = 0, stride = 1;
+    bool deconv = false;
+    int epi = EPI_STORE;
+    int MS = 2, NS = 2, CC = 16;          // kernel configuration
+    int ntiles = 1, nchunks = 1, ntaps = 9, npar = 1;
+    float *d_w = nullptr, *d_bias = nullptr, *d_slope = nullptr;
+    double flops_per_pixel = 0;           // algorithmic: 2 * MAC per GEMM-M pixel
+    std::string cls;                      // profile class
+    int8_t tdy[4][9], tdx[4][9];
+};
+
+static void free_layer(ConvLayer& L) {
+    if (L.d_w) (void)hipFree(L.d_w);
+    if (L.d_bias) (void)hipFree(L.d_bias);
+    if (L.d_slope) (void)hipFree(L.d_slope);
+    L.d_w = L.d_bias = L.d_slope = nullptr;
+}
+
+// Choose the kernel configuration for a layer (see conv_mfma.h for the meaning of MS / NS / CC).
+static void configure(ConvLayer& L) {
+    const int NT = L.cout <= 32 ? 32 : (L.cout % 64 == 0 ? 64 : (L.cout % 96 == 0 ? 96 : 64));
+    L.NS = NT / 32;
+    L.ntiles = (L.cout + NT - 1) / NT;
+    if (L.stride == 2) { L.MS = 1; L.CC = 8; }
+    else if (L.NS == 3) { L.MS = 2; L.CC = 8; }
+    else { L.MS = 2; L.CC = 16; }
+    L.cin_p = (L.cin + L.CC - 1) / L.CC * L.CC;
+    L.nchunks = L.cin_p / L.CC;
+    L.ntaps = L.deconv ? 4 : 9;
+    L.npar = L.deconv ? 4 : 1;
+    std::memset(L.tdy, 0, sizeof L.tdy); std::memset(L.tdx, 0, sizeof L.tdx);
+    if (!L.deconv) {
+        for (int t = 0; t < 9; t++) { L.tdy[0][t] = (int8_t)(t / 3 - 1); L.tdx[0][t] = (int8_t)(t % 3 - 1); }
+    } else {
+        // out(2y+p) gathers input y+d through kernel row k with 2(y+d) + k - 1 = 2y + p  ->  p=0: (d=0,k=1),(d=-1,k=3); p=1: (d=0,k=2),(d=+1,k=0)
+        static const int D[2][2] = {{0, -1}, {0, 1}};
+        for (int par = 0; par < 4; par++)
+            for (int t = 0; t < 4; t++) { L.tdy[par][t] = (int8_t)D[par >> 1][t >> 1]; L.tdx[par][t] = (int8_t)D[par & 1][t & 1]; }
+    }
+}
+
+// ncnn weight order [oc][ic][kh][kw] (also for Deconvolution) -> MFMA B-fragment order
+// [ntile][par][chunk][tap][g][half][n][4], channel = chunk*CC + g*8 + half*4 + s.
+static std::vector<float> pack_weights(const ConvLayer& L, const float* w) {
+    const int NT = L.NS * 32, NG = L.CC / 8, K = L.deconv ? 4 : 3;
+    static const int KD[2][2] = {{1, 3}, {2, 0}};   // deconv kernel row per (parity, tap), matching D[][] in configure()
+    std::vector<float> out((size_t)L.ntiles * L.npar * L.nchunks * L.ntaps * L.CC * NT, 0.f);
+    size_t o = 0;
+    for (int nt = 0; nt < L.ntiles; nt++)
+        for (int par = 0; par < L.npar; par++)
+            for (int ch = 0; ch < L.nchunks; ch++)
+                for (int t = 0; t < L.ntaps; t++) {
+                    int ky, kx;
+                    if (L.deconv) { ky = KD[par >> 1][t >> 1]; kx = KD[par & 1][t & 1]; }
+                    else { ky = t / 3; kx = t % 3; }
+                    for (int g = 0; g < NG; g++)
+                        for (int half = 0; half < 2; half++)
+                            for (int n = 0; n < NT; n++)
+                                for (int s = 0; s < 4; s++, o++) {
+                                    const int c = ch * L.CC + g * 8 + half * 4 + s, oc = nt * NT + n;
+                                    if (c < L.cin && oc < L.cout) out[o] = w[(((size_t)oc * L.cin + c) * K + ky) * K + kx];
+                                }
+                }
+    return out;
+}
+
+static int upload_layer(ConvLayer& L, const float* w, const float* bias, const float* slope /*per-channel or null*/, float uniform_slope) {
+    configure(L);
+    std::vector<float> pk = pack_weights(L, w);
+    const int cp = L.ntiles * L.NS * 32;
+    std::vector<float> b(cp, 0.f), s(cp, 1.f);
+    for (int i = 0; i < L.cout; i++) { b[i] = bias ? bias[i] : 0.f; s[i] = slope ? slope[i] : uniform_slope; }
+    HIPCHK(hipMalloc(&L.d_w, pk.size() * 4));
+    HIPCHK(hipMalloc(&L.d_bias, cp * 4));
+    HIPCHK(hipMalloc(&L.d_slope, cp * 4));
+    HIPCHK(hipMemcpy(L.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(L.d_bias, b.data(), cp * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(L.d_slope, s.data(), cp * 4, hipMemcpyHostToDevice));
+    const int K = L.deconv ? 16 : 9;
+    L.flops_per_pixel = 2.0 * L.cin * L.cout * K;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel dispatch
+// ------------------------------------------------------------------------------------------------
+template <int STRIDE, int MS, int NS, int CC, int EPI>
+static hipError_t launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    auto kfn = conv_mfma_kernel<STRIDE, MS, NS, CC, EPI>;
+    constexpr int lds = conv_lds_bytes<STRIDE, MS, NS, CC>();
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+struct TensorView { float* p; int ld, coff; };
+
+// x: NHWC input (H x W), y: output; for deconv layers y has 2H x 2W pixels (or the 4H x 4W flow tensor with EPI_DECONV_PS).
+static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorView y, const TensorView* res, hipStream_t st) {
+    ConvArgs a;
+    a.in = x.p; a.in_ld = x.ld; a.in_coff = x.coff; a.H = H; a.W = W;
+    a.out = y.p; a.out_ld = y.ld; a.out_coff = y.coff;
+    a.wpk = L.d_w; a.bias = L.d_bias; a.slope = L.d_slope;
+    a.res = res ? res->p : nullptr; a.res_ld = res ? res->ld : 0; a.res_coff = res ? res->coff : 0;
+    a.Ho = L.deconv ? H : (H + 2 - 3) / L.stride + 1;
+    a.Wo = L.deconv ? W : (W + 2 - 3) / L.stride + 1;
+    a.Cout = L.cout; a.nchunks = L.nchunks; a.ntaps = L.ntaps; a.npar = L.npar;
+    std::memcpy(a.tdy, L.tdy, sizeof a.tdy); std::memcpy(a.tdx, L.tdx, sizeof a.tdx);
+    if (x.ld % 4 || x.coff % 4 || x.ld - x.coff < L.cin_p) return fail(RIFE_HIP_EINVAL, "conv input view is not padded to the channel chunk");
+    const int TH = 4 * L.MS;
+    a.tiles_x = (a.Wo + 31) / 32;
+    const int tiles_y = (a.Ho + TH - 1) / TH;
+    dim3 grid(a.tiles_x * tiles_y, 1, L.ntiles * L.npar);
+    hipError_t e = hipErrorInvalidValue;
+#define RIFE_CFG(S_, MS_, NS_, CC_, E_) \
+    if (L.stride == S_ && L.MS == MS_ && L.NS == NS_ && L.CC == CC_ && L.epi == E_) e = launch_cfg<S_, MS_, NS_, CC_, E_>(a, grid, st); else
+    RIFE_CFG(2, 1, 1, 8, EPI_STORE)
+    RIFE_CFG(2, 1, 2, 8, EPI_STORE)
+    RIFE_CFG(2, 1, 3, 8, EPI_STORE)
+    RIFE_CFG(1, 2, 1, 16, EPI_STORE)
+    RIFE_CFG(1, 2, 2, 16, EPI_STORE)
+    RIFE_CFG(1, 2, 3, 8, EPI_STORE)
+    RIFE_CFG(1, 2, 1, 16, EPI_DECONV_PS)
+    RIFE_CFG(1, 2, 1, 16, EPI_DECONV)
+    RIFE_CFG(1, 2, 2, 16, EPI_DECONV)
+    RIFE_CFG(1, 2, 3, 8, EPI_DECONV)
+    RIFE_CFG(1, 2, 1, 16, EPI_DECONV_SIG)
+    { return fail(RIFE_HIP_ENOSYS, "no conv kernel instantiation for this layer shape"); }
+#undef RIFE_CFG
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiler (rife_hip_profile_*): HIP events on the launch stream around every kernel
+// ------------------------------------------------------------------------------------------------
+struct Profiler {
+    bool on = false;
+    std::mutex mu;
+    struct Rec { int cls; hipEvent_t e0, e1; double flops; };
+    std::vector<Rec> recs;
+    std::vector<std::string> names;
+    std::map<std::string, int> ids;
+    std::vector<double> ms, flops;
+    std::vector<long long> launches;
+    int cls_id(const std::string& n) {
+        auto it = ids.find(n);
+        if (it != ids.end()) return it->second;
+        int id = (int)names.size();
+        names.push_back(n); ids[n] = id; ms.push_back(0); flops.push_back(0); launches.push_back(0);
+        return id;
+    }
+    void begin(const std::string& cls, double fl, hipStream_t st, size_t& token) {
+        token = (size_t)-1;
+        if (!on) return;
+        std::lock_guard<std::mutex> g(mu);
+        Rec r; r.cls = cls_id(cls); r.flops = fl;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        (void)hipEventRecord(r.e0, st);
+        recs.push_back(r); token = recs.size() - 1;
+    }
+    void end(size_t token, hipStream_t st) {
+        if (token == (size_t)-1) return;
+        std::lock_guard<std::mutex> g(mu);
+        (void)hipEventRecord(recs[token].e1, st);
+    }
+    void collect() {
+        std::lock_guard<std::mutex> g(mu);
+        for (Rec& r : recs) {
+            (void)hipEventSynchronize(r.e1);
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms[r.cls] += t; flops[r.cls] += r.flops; launches[r.cls]++; }
+            (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+        }
+        recs.clear();
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// per-pair workspace ("context"): everything one in-flight frame pair needs, sized for one padded resolution
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int w = 0, h = 0, wp = 0, hp = 0;
+    uint8_t *d_in0 = nullptr, *d_in1 = nullptr, *d_out = nullptr;   // staging for the host-buffer entry point
+    uint32_t *img0 = nullptr, *img1 = nullptr;                       // padded RGBX u8
+    float *X = nullptr, *S1 = nullptr, *T0 = nullptr, *T1 = nullptr; // block input, stem-1 output, trunk ping/pong
+    float* flow[4] = {nullptr, nullptr, nullptr, nullptr};           // [hp/s][wp/s][8]
+    float4* F = nullptr; float* M = nullptr;                         // full-resolution flow (4ch) and mask logit
+    std::vector<void*> allocs;
+    ~Ctx() {
+        for (void* p : allocs) (void)hipFree(p);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+template <typename T>
+static int dalloc(Ctx& c, T*& p, size_t n) {
+    void* v = nullptr;
+    HIPCHK(hipMalloc(&v, n * sizeof(T)));
+    c.allocs.push_back(v);
+    p = (T*)v;
+    return 0;
+}
+
+}  // namespace rife
+
+using namespace rife;
+
+// ------------------------------------------------------------------------------------------------
+// the engine object behind rife_hip_t
+// ------------------------------------------------------------------------------------------------
+struct rife_hip {
+    int gpuid = 0;
+    bool tta = false, tta_temporal = false, uhd = false, v2 = false, v4 = false;
+    int num_threads = 1;
+    bool loaded = false;
+    // v4.6 schedule: per block {stem0, stem1, res x8, head}
+    struct Block { ConvLayer stem0, stem1, res[8], head; int c = 0, scale = 1; } blk[4];
+    mutable Profiler prof;
+    mutable std::mutex mu;
+    mutable std::vector<std::unique_ptr<Ctx>> free_ctx;                  // pool for the host-buffer entry point
+    mutable std::map<void*, std::unique_ptr<Ctx>> stream_ctx;            // one workspace per caller stream
+
+    ~rife_hip() {
+        (void)hipSetDevice(gpuid);
+        free_ctx.clear(); stream_ctx.clear();
+        for (auto& b : blk) { free_layer(b.stem0); free_layer(b.stem1); for (auto& r : b.res) free_layer(r); free_layer(b.head); }
+    }
+};
+
+namespace rife {
+
+// structural hashes of the graphs the schedules below were written for (= the reference's
+// models/rife-v4.6/flownet.param; tests/test_models.py proves the equivalence whenever /root/reference exists)
+static const uint64_t V46_HASH_OUT0 = RIFE_V46_HASH_OUT0;
+
+static int ensure_ctx(Ctx& c, int w, int h) {
+    const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;    // rife.cpp:2499-2500
+    if (c.wp == wp && c.hp == hp && c.w == w && c.h == h) return 0;
+    for (void* p : c.allocs) (void)hipFree(p);
+    c.allocs.clear();
+    c.w = w; c.h = h; c.wp = wp; c.hp = hp;
+    const size_t P = (size_t)wp * hp;
+    int rc;
+    if ((rc = dalloc(c, c.d_in0, (size_t)w * h * 3))) return rc;
+    if ((rc = dalloc(c, c.d_in1, (size_t)w * h * 3))) return rc;
+    if ((rc = dalloc(c, c.d_out, (size_t)w * h * 3))) return rc;
+    if ((rc = dalloc(c, c.img0, P))) return rc;
+    if ((rc = dalloc(c, c.img1, P))) return rc;
+    if ((rc = dalloc(c, c.X, P * 16))) return rc;                  // block 3: full res x 16 ch
+    if ((rc = dalloc(c, c.S1, P / 4 * 32))) return rc;             // block 3 stem-0 output: (hp/2 x wp/2) x 32; block 0: (hp/16 x wp/16) x 96
+    if ((rc = dalloc(c, c.T0, P / 16 * 64))) return rc;            // block 3 trunk: (hp/4 x wp/4) x 64 (the largest trunk)
+    if ((rc = dalloc(c, c.T1, P / 16 * 64))) return rc;
+    static const int sc[4] = {8, 4, 2, 1};
+    for (int b = 0; b < 4; b++) {
+        const size_t n = P / (sc[b] * sc[b]) * 8;
+        if ((rc = dalloc(c, c.flow[b], n))) return rc;
+        HIPCHK(hipMemset(c.flow[b], 0, n * 4));
+    }
+    if ((rc = dalloc(c, c.F, P))) return rc;
+    if ((rc = dalloc(c, c.M, P))) return rc;
+    return 0;
+}
+
+struct Timed {
+    Profiler& p; hipStream_t st; size_t tok;
+    Timed(Profiler& p_, const std::string& cls, double fl, hipStream_t s) : p(p_), st(s) { p.begin(cls, fl, st, tok); }
+    ~Timed() { p.end(tok, st); }
+};
+
+static inline dim3 grid2d(int w, int h) { return dim3((w + 255) / 256, h); }
+
+// One IFBlock: stems, 8 residual convs, head -> flow[b]   (flownet.param:11-46, 63-98, 116-151, 166-201)
+static int run_block_convs(const rife_hip& E, Ctx& c, int b) {
+    const rife_hip::Block& B = E.blk[b];
+    hipStream_t st = c.stream;
+    const int s = B.scale, Hb = c.hp / s, Wb = c.wp / s;
+    const int xin_ld = b == 0 ? 8 : 16;
+    int rc;
+    {
+        Timed t(E.prof, B.stem0.cls, B.stem0.flops_per_pixel * (Hb / 2) * (Wb / 2), st);
+        if ((rc = launch_conv(B.stem0, {c.X, xin_ld, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, nullptr, st))) return rc;
+    }
+    {
+        Timed t(E.prof, B.stem1.cls, B.stem1.flops_per_pixel * (Hb / 4) * (Wb / 4), st);
+        if ((rc = launch_conv(B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {c.T0, B.c, 0}, nullptr, st))) return rc;
+    }
+    float* cur = c.T0; float* nxt = c.T1;
+    const int Ht = Hb / 4, Wt = Wb / 4;
+    for (int i = 0; i < 8; i++) {
+        Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
+        TensorView res{cur, B.c, 0};
+        if ((rc = launch_conv(B.res[i], {cur, B.c, 0}, Ht, Wt, {nxt, B.c, 0}, &res, st))) return rc;
+        std::swap(cur, nxt);
+    }
+    {
+        Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);
+        if ((rc = launch_conv(B.head, {cur, B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st))) return rc;
+    }
+    return 0;
+}
+
+static int run_assemble(const rife_hip& E, Ctx& c, int b, float timestep) {
+    hipStream_t st = c.stream;
+    Timed t(E.prof, "assemble", 0, st);
+    const int s = E.blk[b].scale;
+    dim3 g = grid2d(c.wp / s, c.hp / s);
+    if (b == 0) hipLaunchKernelGGL(k_assemble0, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.X, c.wp, c.hp);
+    else if (s == 4) hipLaunchKernelGGL(k_assemble<4>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
+    else if (s == 2) hipLaunchKernelGGL(k_assemble<2>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
+    else hipLaunchKernelGGL(k_assemble<1>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int run_flow_update(const rife_hip& E, Ctx& c, int b) {
+    hipStream_t st = c.stream;
+    Timed t(E.prof, "flow_update", 0, st);
+    dim3 g = grid2d(c.wp, c.hp);
+    if (b == 0) hipLaunchKernelGGL((k_flow_update<8, true>), g, dim3(256), 0, st, c.flow[0], c.F, c.M, c.wp, c.hp);
+    else if (b == 1) hipLaunchKernelGGL((k_flow_update<4, false>), g, dim3(256), 0, st, c.flow[1], c.F, c.M, c.wp, c.hp);
+    else hipLaunchKernelGGL((k_flow_update<2, false>), g, dim3(256), 0, st, c.flow[2], c.F, c.M, c.wp, c.hp);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// RIFE::process_v4, non-TTA branch (rife.cpp:2931-3173) on device-resident frames.
+static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t* d_in1, float timestep, uint8_t* d_out) {
+    hipStream_t st = c.stream;
+    int rc;
+    {
+        Timed t(E.prof, "preproc", 0, st);
+        dim3 g = grid2d(c.wp, c.hp);
+        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.img0, c.wp, c.hp);
+        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.img1, c.wp, c.hp);
+        HIPCHK(hipGetLastError());
+    }
+    for (int b = 0; b < 4; b++) {
+        if ((rc = run_assemble(E, c, b, timestep))) return rc;
+        if ((rc = run_block_convs(E, c, b))) return rc;
+        if (b < 3 && (rc = run_flow_update(E, c, b))) return rc;
+    }
+    {
+        Timed t(E.prof, "final", 0, st);
+        hipLaunchKernelGGL(k_final, grid2d(c.w, c.h), dim3(256), 0, st, c.img0, c.img1, c.F, c.M, c.flow[3], d_out, c.w, c.h, c.wp, c.hp);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+static int check_device(int gpuid) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RIFE_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    if (gpuid < 0 || gpuid >= n) return fail(RIFE_HIP_ENODEV, "invalid gpu device");
+    HIPCHK(hipSetDevice(gpuid));
+    return 0;
+}
+
+}  // namespace rife
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+extern "C" {
+
+const char* rife_hip_last_error(void) { return g_err.c_str(); }
+
+int rife_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int uhd_mode, int num_threads, int rife_v2, int rife_v4) {
+    if (check_device(gpuid)) return nullptr;
+    rife_hip* E = new rife_hip;
+    E->gpuid = gpuid; E->tta = tta_mode; E->tta_temporal = tta_temporal_mode; E->uhd = uhd_mode;
+    E->num_threads = num_threads; E->v2 = rife_v2; E->v4 = rife_v4;
+    return E;
+}
+
+void rife_hip_destroy(rife_hip_t* r) { delete r; }
+
+int rife_hip_load(rife_hip_t* E, const char* modeldir) {
+    if (!E || !modeldir) return fail(RIFE_HIP_EINVAL, "null argument");
+    int rc;
+    if ((rc = check_device(E->gpuid))) return rc;
+    if (!E->v4) return fail(RIFE_HIP_ENOSYS, "only the rife-v4.x family is implemented on the HIP path so far");
+    NcnnModel m;
+    const std::string base = std::string(modeldir) + "/flownet";
+    if (!m.load_param(base + ".param")) return fail(RIFE_HIP_EIO, m.error);
+    if (m.structural_hash("out0") != V46_HASH_OUT0)
+        return fail(RIFE_HIP_EMODEL, base + ".param is not the rife-v4.6 IFNet graph this engine schedules");
+    if (!m.load_bin(base + ".bin")) return fail(RIFE_HIP_EIO, m.error);
+    std::vector<const NcnnLayer*> wl = m.weighted();
+    if (wl.size() != 44) return fail(RIFE_HIP_EMODEL, "unexpected number of weighted layers");
+    static const int C[4] = {192, 128, 96, 64}, SC[4] = {8, 4, 2, 1};
+    size_t k = 0;
+    for (int b = 0; b < 4; b++) {
+        rife_hip::Block& B = E->blk[b];
+        B.c = C[b]; B.scale = SC[b];
+        char name[64];
+        auto setup = [&](ConvLayer& L, int cin, int cout, int stride, bool deconv, int epi, float slope, const char* cls) -> int {
+            const NcnnLayer* nl = wl[k++];
+            const int kk = deconv ? 16 : 9;
+            if (nl->type != (deconv ? "Deconvolution" : "Convolution") || nl->geti(0, 0) != cout || (int)nl->weight.size() != cin * cout * kk ||
+                nl->geti(3, 1) != stride)
+                return fail(RIFE_HIP_EMODEL, "weighted layer " + nl->name + " does not match the rife-v4.6 schedule");
+            free_layer(L);
+            L.cin = cin; L.cout = cout; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi; L.cls = cls;
+            return upload_layer(L, nl->weight.data(), nl->bias.data(), nullptr, slope);
+        };
+        std::snprintf(name, sizeof name, "stem0_b%d", b);
+        if ((rc = setup(B.stem0, b == 0 ? 7 : 12, C[b] / 2, 2, false, EPI_STORE, 0.2f, name))) return rc;
+        std::snprintf(name, sizeof name, "stem1_b%d", b);
+        if ((rc = setup(B.stem1, C[b] / 2, C[b], 2, false, EPI_STORE, 0.2f, name))) return rc;
+        std::snprintf(name, sizeof name, "trunk_b%d", b);
+        for (int i = 0; i < 8; i++)
+            if ((rc = setup(B.res[i], C[b], C[b], 1, false, EPI_STORE, 0.2f, name))) return rc;
+        std::snprintf(name, sizeof name, "head_b%d", b);
+        if ((rc = setup(B.head, C[b], 24, 2, true, EPI_DECONV_PS, 1.0f, name))) return rc;
+    }
+    E->loaded = true;
+    return 0;
+}
+
+static int process_common(const rife_hip* E, int w, int h, float timestep) {
+    if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
+    if (!E->loaded) return fail(RIFE_HIP_EINVAL, "process() before load()");
+    if (w <= 0 || h <= 0) return fail(RIFE_HIP_EINVAL, "bad frame size");
+    if (E->tta || E->tta_temporal) return fail(RIFE_HIP_ENOSYS, "TTA modes are not implemented on the HIP path yet");
+    (void)timestep;
+    return 0;
+}
+
+int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, uint8_t* out) {
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (!in0 || !in1 || !out) return fail(RIFE_HIP_EINVAL, "null frame pointer");
+    const size_t nbytes = (size_t)w * h * 3;
+    // rife.cpp:2470-2480: timestep 0 / 1 return an input frame unchanged (the reference rebinds the Mat; a copy is pixel-identical)
+    if (timestep == 0.f) { std::memmove(out, in0, nbytes); return 0; }
+    if (timestep == 1.f) { std::memmove(out, in1, nbytes); return 0; }
+    if ((rc = check_device(E->gpuid))) return rc;
+    std::unique_ptr<Ctx> c;
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        if (!E->free_ctx.empty()) { c = std::move(E->free_ctx.back()); E->free_ctx.pop_back(); }
+    }
+    if (!c) {
+        c.reset(new Ctx);
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
+        c->own_stream = true;
+    }
+    rc = ensure_ctx(*c, w, h);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(c->d_in0, in0, nbytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->d_in1, in1, nbytes, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) rc = fail(RIFE_HIP_EHIP, std::string("H2D: ") + hipGetErrorString(e));
+    }
+    if (!rc) rc = run_v4(*E, *c, c->d_in0, c->d_in1, timestep, c->d_out);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(out, c->d_out, nbytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(RIFE_HIP_EHIP, std::string("D2H/sync: ") + hipGetErrorString(e));
+    }
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        E->free_ctx.push_back(std::move(c));
+    }
+    return rc;
+}
+
+int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* d_in1, int w, int h, float timestep, void* d_out, void* hip_stream) {
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (!d_in0 || !d_in1 || !d_out) return fail(RIFE_HIP_EINVAL, "null frame pointer");
+    if ((rc = check_device(E->gpuid))) return rc;
+    const size_t nbytes = (size_t)w * h * 3;
+    Ctx* c;
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        auto& slot = E->stream_ctx[hip_stream];
+        if (!slot) {
+            slot.reset(new Ctx);
+            if (hip_stream) slot->stream = (hipStream_t)hip_stream;
+            else {
+                if (hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
+                slot->own_stream = true;
+            }
+        }
+        c = slot.get();
+    }
+    if (timestep == 0.f || timestep == 1.f) {
+        HIPCHK(hipMemcpyAsync(d_out, timestep == 0.f ? d_in0 : d_in1, nbytes, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        if ((rc = ensure_ctx(*c, w, h))) return rc;
+        if ((rc = run_v4(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, timestep, (uint8_t*)d_out))) return rc;
+    }
+    if (!hip_stream) HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rife_hip_profile_enable(rife_hip_t* E, int on) {
+    if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
+    E->prof.collect();
+    E->prof.on = on != 0;
+    if (on) {
+        std::lock_guard<std::mutex> g(E->prof.mu);
+        std::fill(E->prof.ms.begin(), E->prof.ms.end(), 0.0);
+        std::fill(E->prof.flops.begin(), E->prof.flops.end(), 0.0);
+        std::fill(E->prof.launches.begin(), E->prof.launches.end(), 0LL);
+    }
+    return 0;
+}
+
+int rife_hip_profile_read(rife_hip_t* E, char* names, size_t names_cap, double* total_ms, long long* launches, double* flops, int max_classes) {
+    if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
+    E->prof.collect();
+    std::lock_guard<std::mutex> g(E->prof.mu);
+    std::string all;
+    int n = std::min<int>(max_classes, (int)E->prof.names.size());
+    for (int i = 0; i < n; i++) {
+        all += E->prof.names[i]; all += '\n';
+        total_ms[i] = E->prof.ms[i]; launches[i] = E->prof.launches[i]; flops[i] = E->prof.flops[i];
+    }
+    if (names && names_cap) { std::strncpy(names, all.c_str(), names_cap - 1); names[names_cap - 1] = 0; }
+    return n;
+}
+
+// ---- stage tap: flow{fi} with optional injection of flow0..flow{n_inject-1} (rife.cpp:2653-2669) -------------
+int rife_hip_v4_extract_flow(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, int fi,
+                             const float* const* inject, int n_inject, float* out6chw) {
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (fi < 0 || fi > 3 || n_inject < 0 || n_inject > fi) return fail(RIFE_HIP_EINVAL, "bad stage index");
+    if ((rc = check_device(E->gpuid))) return rc;
+    Ctx c;
+    if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
+    c.own_stream = true;
+    if ((rc = ensure_ctx(c, w, h))) return rc;
+    const size_t nbytes = (size_t)w * h * 3;
+    HIPCHK(hipMemcpyAsync(c.d_in0, in0, nbytes, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(c.d_in1, in1, nbytes, hipMemcpyHostToDevice, c.stream));
+    dim3 g = grid2d(c.wp, c.hp);
+    hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, c.stream, c.d_in0, c.w, c.h, c.img0, c.wp, c.hp);
+    hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, c.stream, c.d_in1, c.w, c.h, c.img1, c.wp, c.hp);
+    float* tmp = nullptr;
+    if ((rc = dalloc(c, tmp, (size_t)c.wp * c.hp * 6))) return rc;
+    for (int b = 0; b <= fi; b++) {
+        const int s = E->blk[b].scale, Hb = c.hp / s, Wb = c.wp / s;
+        if (b < n_inject) {
+            HIPCHK(hipMemcpyAsync(tmp, inject[b], (size_t)Hb * Wb * 6 * 4, hipMemcpyHostToDevice, c.stream));
+            hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(Wb, Hb), dim3(256), 0, c.stream, tmp, c.flow[b], 6, Hb, Wb, 8);
+        } else {
+            if ((rc = run_assemble(*E, c, b, timestep))) return rc;
+            if ((rc = run_block_convs(*E, c, b))) return rc;
+        }
+        if (b < fi && (rc = run_flow_update(*E, c, b))) return rc;
+    }
+    const int s = E->blk[fi].scale, Hb = c.hp / s, Wb = c.wp / s;
+    hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(Wb, Hb), dim3(256), 0, c.stream, c.flow[fi], tmp, 6, Hb, Wb, 8);
+    HIPCHK(hipMemcpyAsync(out6chw, tmp, (size_t)Hb * Wb * 6 * 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+// ---- single-kernel entry points ------------------------------------------------------------------------------
+static int op_conv_common(int gpuid, const float* x, int c, int h, int w, const float* weight, const float* bias, int outc, int stride,
+                          bool deconv, int epi, const float* residual, const float* slope, float* out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    ConvLayer L;
+    L.cin = c; L.cout = outc; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi;
+    if ((rc = upload_layer(L, weight, bias, slope, 1.0f))) { free_layer(L); return rc; }
+    const int ho = deconv ? 2 * h : (h + 2 - 3) / stride + 1, wo = deconv ? 2 * w : (w + 2 - 3) / stride + 1;
+    const int ldi = L.cin_p;
+    float *d_chw = nullptr, *d_x = nullptr, *d_y = nullptr, *d_r = nullptr, *d_o = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_chw); (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_r); (void)hipFree(d_o); free_layer(L); };
+    const size_t nin = (size_t)c * h * w, nout = (size_t)outc * ho * wo;
+    hipError_t e = hipMalloc(&d_chw, std::max(nin, nout) * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_x, (size_t)h * w * ldi * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_y, (size_t)ho * wo * outc * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_o, nout * 4);
+    if (e == hipSuccess && residual) e = hipMalloc(&d_r, (size_t)ho * wo * outc * 4);
+    if (e != hipSuccess) { cleanup(); return fail(RIFE_HIP_EHIP, "hipMalloc failed"); }
+    (void)hipMemcpy(d_chw, x, nin * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(w, h), dim3(256), 0, 0, d_chw, d_x, c, h, w, ldi);
+    TensorView rv{d_r, outc, 0};
+    if (residual) {
+        (void)hipMemcpy(d_chw, residual, nout * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(wo, ho), dim3(256), 0, 0, d_chw, d_r, outc, ho, wo, outc);
+    }
+    rc = launch_conv(L, {d_x, ldi, 0}, h, w, {d_y, outc, 0}, residual ? &rv : nullptr, 0);
+    if (!rc) {
+        hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(wo, ho), dim3(256), 0, 0, d_y, d_o, outc, ho, wo, outc);
+        e = hipMemcpy(out, d_o, nout * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RIFE_HIP_EHIP, std::string("op: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    return rc;
+}
+
+int rife_hip_op_conv3x3(int gpuid, const float* x, int c, int h, int w, const float* weight, const float* bias, int outc, int stride,
+                        const float* residual, const float* slope, float* out) {
+    if (stride != 1 && stride != 2) return fail(RIFE_HIP_EINVAL, "stride must be 1 or 2");
+    return op_conv_common(gpuid, x, c, h, w, weight, bias, outc, stride, false, EPI_STORE, residual, slope, out);
+}
+
+int rife_hip_op_deconv4x4(int gpuid, const float* x, int c, int h, int w, const float* weight, const float* bias, int outc, const float* slope, float* out) {
+    return op_conv_common(gpuid, x, c, h, w, weight, bias, outc, 2, true, EPI_DECONV, nullptr, slope, out);
+}
+
+int rife_hip_op_warp(int gpuid, const float* image, const float* flow, int c, int h, int w, float* out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    float *d_i = nullptr, *d_f = nullptr, *d_o = nullptr;
+    const size_t n = (size_t)c * h * w;
+    hipError_t e = hipMalloc(&d_i, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_f, (size_t)2 * h * w * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_o, n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_i, image, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_f, flow, (size_t)2 * h * w * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_warp_chw, grid2d(w, h), dim3(256), 0, 0, d_i, d_f, d_o, c, h, w);
+        e = hipMemcpy(out, d_o, n * 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_i); (void)hipFree(d_f); (void)hipFree(d_o);
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("op_warp: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// tooling: structural hash of a named blob of a .param file (used to derive / test the compiled-in constants)
+int rife_hip_param_hash(const char* param_path, const char* blob, uint64_t* out) {
+    NcnnModel m;
+    if (!m.load_param(param_path)) return fail(RIFE_HIP_EIO, m.error);
+    *out = m.structural_hash(blob);
+    return *out ? 0 : fail(RIFE_HIP_EMODEL, "no such blob");
+}
+
+}  // extern "C"

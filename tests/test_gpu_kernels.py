@@ -1,0 +1,85 @@
+"""Per-kernel parity through the C-ABI: HIP kernels vs the CPU oracle on seeded inputs (GPU box only).
+
+Tolerance for the fp32 MFMA convolutions: the kernel accumulates the same fp32 products as the oracle in a
+different order (v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain), so |diff| <= 1e-5 * (1 + sum|a*b|) is the
+rounding-noise bound used.  Warp is restated operation-for-operation: required bit-exact."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+amd = importlib.import_module("rife-ncnn-vulkan_amd")
+
+
+def conv_tol(x, w):
+    return 2e-5 * (1.0 + np.abs(w).sum(axis=(1, 2, 3)).max() * np.abs(x).max())
+
+
+@pytest.mark.parametrize("cin,cout,stride,h,w,res", [
+    (7, 96, 2, 34, 60, False),      # v4.6 block-0 stem (K = 63, Cout not a multiple of 64)
+    (12, 48, 2, 40, 64, False),     # block-2 stem (Cout padded to a 64-wide tile)
+    (12, 32, 2, 36, 70, False),     # block-3 stem, ragged width
+    (48, 96, 2, 24, 40, False),     # stem-1, N = 96
+    (64, 64, 1, 24, 64, True),      # block-3 trunk conv: residual + leaky
+    (96, 96, 1, 17, 33, True),      # block-2 trunk (N = 96, CC = 8), ragged tile edges
+    (128, 128, 1, 9, 31, True),     # block-1 trunk, 2 N-tiles
+    (192, 192, 1, 8, 32, True),     # block-0 trunk, 3 N-tiles, 12 channel chunks
+    (16, 24, 1, 5, 7, False),       # tiny: one partial tile
+])
+def test_conv3x3_matches_oracle(cin, cout, stride, h, w, res):
+    rng = np.random.default_rng(cin * 1000 + cout)
+    x = rng.standard_normal((cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    want = pyoracle.conv2d(x, wt, b, stride=stride, pad=1)
+    r = rng.standard_normal(want.shape).astype(np.float32) if res else None
+    if res:
+        want = want + r
+    want = np.where(want < 0, want * np.float32(0.2), want)
+    got = amd.op_conv3x3(x, wt, b, stride=stride, residual=r, slope=np.full(cout, 0.2, np.float32))
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= conv_tol(x, wt)
+
+
+def test_conv3x3_prelu_slopes_and_identity_weights():
+    """Transpose-detecting check: asymmetric one-hot weights pick a known (channel, tap); per-channel PReLU slopes."""
+    cin, cout, h, w = 16, 40, 12, 37
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((cin, h, w)).astype(np.float32)
+    wt = np.zeros((cout, cin, 3, 3), np.float32)
+    for o in range(cout):
+        wt[o, (o * 7) % cin, (o // 3) % 3, o % 3] = 1.0
+    slope = rng.uniform(-0.9, 1.2, cout).astype(np.float32)
+    got = amd.op_conv3x3(x, wt, np.zeros(cout, np.float32), stride=1, slope=slope)
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1)))
+    for o in range(cout):
+        ky, kx = (o // 3) % 3, o % 3
+        v = xp[(o * 7) % cin, ky:ky + h, kx:kx + w]
+        want = np.where(v < 0, v * slope[o], v)
+        assert np.array_equal(got[o], want), o       # single product per output: exact
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 24, 16, 40), (192, 24, 5, 9), (96, 24, 9, 33), (32, 4, 12, 20), (128, 32, 6, 10), (256, 64, 4, 6)])
+def test_deconv4x4_matches_oracle(cin, cout, h, w):
+    rng = np.random.default_rng(cin + cout)
+    x = rng.standard_normal((cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 4, 4)) / np.sqrt(cin * 4)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    want = pyoracle.deconv2d(x, wt, b)
+    got = amd.op_deconv4x4(x, wt, b)
+    assert got.shape == want.shape == (cout, 2 * h, 2 * w)
+    assert np.abs(got - want).max() <= conv_tol(x, wt)
+
+
+def test_warp_bit_exact_including_out_of_frame():
+    rng = np.random.default_rng(9)
+    img = rng.uniform(0, 1, (3, 45, 70)).astype(np.float32)
+    flow = (rng.standard_normal((2, 45, 70)) * 9).astype(np.float32)
+    flow[:, :4] *= 20                                           # far outside: exercises the clamp-then-alpha quirk
+    assert np.array_equal(amd.op_warp(img, flow), pyoracle.warp(img, flow))
+    img32 = rng.standard_normal((32, 20, 24)).astype(np.float32)   # v2.3 context-feature shape class
+    fl = (rng.standard_normal((2, 20, 24)) * 3).astype(np.float32)
+    assert np.array_equal(amd.op_warp(img32, fl), pyoracle.warp(img32, fl))

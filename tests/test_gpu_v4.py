@@ -1,0 +1,112 @@
+"""rife-v4.6 on the HIP engine vs the CPU oracle, through the C-ABI (GPU box only).
+
+Bar (BASELINE.json north_star): <= 1 LSB per RGB channel against the reference CPU path.  Stage taps are checked
+at 1e-3 absolute (flows are O(1) px; fp32 reassociation noise through up to 40 stacked convs is ~1e-5)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tools import gen_frames
+
+pytestmark = pytest.mark.gpu
+amd = importlib.import_module("rife-ncnn-vulkan_amd")
+
+
+@pytest.fixture(scope="module")
+def engines(modeldirs):
+    d = modeldirs["rife-v4.6"]
+    g = amd.RIFE(0, rife_v4=True)
+    g.load(d)
+    o = pyoracle.OracleRIFE(rife_v4=True)
+    o.set_gpu_crop(1)     # the HIP path crops like the reference's GPU shader (rife_postproc.comp:42); identical when w % 32 == 0
+    o.load(d)
+    return g, o
+
+
+def lsb_report(a, b):
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    mse = float((d.astype(np.float64) ** 2).mean())
+    psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+    return int(d.max()), float((d == 0).mean()), float((d == 1).mean()), psnr
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (160, 96)])
+def test_stage_flows_match_oracle(engines, w, h):
+    g, o = engines
+    a, b = gen_frames.smooth_pair(w, h, 21)
+    for fi in range(4):
+        got = g.v4_extract_flow(a, b, 0.5, fi)
+        want = o.v4_extract(a, b, 0.5, "flow%d" % fi)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 1e-3, fi
+
+
+def test_flow_injection_matches_oracle(engines):
+    """The Extractor inject/extract contract TTA relies on (rife.cpp:2653-2669)."""
+    g, o = engines
+    a, b = gen_frames.smooth_pair(96, 64, 22)
+    rng = np.random.default_rng(1)
+    inj = [(rng.standard_normal((6, 64 // s, 96 // s)) * 0.3).astype(np.float32) for s in (8, 4, 2)]
+    for fi in (1, 2, 3):
+        got = g.v4_extract_flow(a, b, 0.4, fi, inject=inj[:fi])
+        want = o.v4_extract(a, b, 0.4, "flow%d" % fi, flows=inj[:fi])
+        assert np.abs(got - want).max() < 1e-3, fi
+
+
+@pytest.mark.parametrize("w,h,t,seed", [(640, 360, 0.5, 1000), (256, 192, 0.125, 1001), (100, 60, 0.7, 1002), (33, 47, 0.9, 1003)])
+def test_process_within_1_lsb(engines, w, h, t, seed):
+    g, o = engines
+    a, b = gen_frames.smooth_pair(w, h, seed)
+    got = g.process(a, b, t)
+    want = o.process(a, b, t)
+    mx, f0, f1, psnr = lsb_report(got, want)
+    assert mx <= 1, (mx, f0, f1, psnr)
+    assert f0 > 0.97 and psnr > 48.0
+
+
+def test_process_noise_frames_within_1_lsb(engines):
+    g, o = engines
+    a, b = gen_frames.noise_pair(128, 96, 7)       # F3 stress input: every pixel is an edge
+    mx, f0, f1, psnr = lsb_report(g.process(a, b, 0.5), o.process(a, b, 0.5))
+    assert mx <= 1, (mx, f0, f1, psnr)
+
+
+def test_timestep_endpoints_return_inputs(engines):
+    g, _ = engines
+    a, b = gen_frames.smooth_pair(64, 48, 3)
+    assert np.array_equal(g.process(a, b, 0.0), a)      # rife.cpp:2470-2480
+    assert np.array_equal(g.process(a, b, 1.0), b)
+
+
+def test_deterministic_and_reentrant(engines):
+    """process() is const + re-entrant in the reference (two proc threads share one RIFE, main.cpp:860-863)."""
+    import threading
+    g, _ = engines
+    a, b = gen_frames.smooth_pair(320, 192, 4)
+    ref = g.process(a, b, 0.5)
+    outs = [None] * 4
+    def work(i):
+        outs[i] = g.process(a, b, 0.5)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for o in outs:
+        assert np.array_equal(o, ref)
+
+
+def test_1080p_within_1_lsb(engines):
+    """BASELINE config 3 size (1920x1080 -> padded 1920x1088)."""
+    g, o = engines
+    a, b = gen_frames.smooth_pair(1920, 1080, 2000)
+    mx, f0, f1, psnr = lsb_report(g.process(a, b, 0.5), o.process(a, b, 0.5))
+    assert mx <= 1, (mx, f0, f1, psnr)
+    assert f0 > 0.97
+
+
+def test_load_rejects_wrong_family(modeldirs):
+    g = amd.RIFE(0, rife_v4=True)
+    with pytest.raises(amd.RifeError):
+        g.load(modeldirs["rife-v2.3"])       # flownet.param there is the v2.3 IFNet
+    with pytest.raises(amd.RifeError):
+        g.load("/nonexistent/dir")
