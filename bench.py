@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Throughput of the RIFE hot path (`RIFE::process`, rife-v4.6) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p] [--streams S]
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one frame pair (two resident u8 RGB frames -> one interpolated frame) through
+`rife_hip_process_device`, per rank.  Frame pairs shard embarrassingly (the reference runs one RIFE replica
+per device, src/main.cpp:819-866): every rank processes its own pairs, there is no data-path collective;
+RCCL is used only for the start/stop barrier.  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {"4k": (3840, 2160), "1080p": (1920, 1080)}
+F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense v_mfma_f32_32x32x2_f32 peak
+V46_GFLOP_PER_PAIR = {"4k": 701.0, "1080p": 175.2}   # 2 x MAC over Convolution + Deconvolution
+ROOFLINE_MS = {"4k": 0.701, "1080p": 0.176}           # SURVEY.md §8(d) fused-minimum HBM roofline per pair
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="4k", choices=list(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=2, help="frame pairs in flight per GPU (the reference's -j proc count, default 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    amd = importlib.import_module("rife-ncnn-vulkan_amd")
+    from tools import gen_frames, gen_models
+    modeldir = gen_models.ensure(None, "rife-v4.6")
+    if dist is not None:
+        dist.barrier()
+    eng = amd.RIFE(local, rife_v4=True)
+    eng.load(modeldir)
+
+    w, h = WORKLOADS[args.workload]
+    # a short synthetic stream of distinct pairs, resident in HBM (consecutive pairs share a frame like a video)
+    nfr = 4
+    base = gen_frames.smooth_pair(w // 4, h // 4, 1000 + rank)
+    frames = []
+    for i in range(nfr):
+        f = np.kron(np.roll(base[i % 2], 3 * i, axis=1), np.ones((4, 4, 1), np.uint8))       # cheap 4x upsample, shifted per frame
+        frames.append(torch.from_numpy(np.ascontiguousarray(f)).cuda())
+    timesteps = [0.5, 0.125, 0.25, 0.7, 0.9]
+    nstreams = max(1, args.streams)
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    outs = [torch.empty((h, w, 3), dtype=torch.uint8, device="cuda") for _ in range(nstreams)]
+
+    def step(i):
+        s = i % nstreams
+        a, b = frames[i % nfr], frames[(i + 1) % nfr]
+        eng.process_device(a.data_ptr(), b.data_ptr(), w, h, timesteps[i % len(timesteps)], outs[s].data_ptr(), streams[s].cuda_stream)
+
+    sh = importlib.import_module("rife-ncnn-vulkan_amd.sharding")
+    for i in range(args.warmup):
+        step(i)
+    sh.barrier(dist, torch.cuda.synchronize)
+    eng.profile_enable(True)
+    elapsed = sh.timed_steps(step, args.steps, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
+                             make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+
+    if rank == 0:
+        # dominant kernel: the block-3 residual trunk conv (64->64 3x3 at 1/4 resolution, 8 launches per pair)
+        dom = prof.get("trunk_b3", dict(ms=0.0, launches=0, flops=0.0))
+        conv_ms = sum(v["ms"] for k, v in prof.items() if v["flops"] > 0)
+        all_ms = sum(v["ms"] for v in prof.values())
+        roof = None
+        if dom["launches"]:
+            avg_ms = dom["ms"] / dom["launches"]
+            ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<1,2,2,16,0> (trunk_b3: 3x3 conv 64->64 + residual + LeakyReLU)",
+                    "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
+                    "flops_per_launch": dom["flops"] / dom["launches"]}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(modeldir, args.workload)
+        fps = world * args.steps / elapsed
+        line = {
+            "metric": "interpolated frames/sec (rife-v4.6, %dx%d)" % (w, h), "value": round(fps, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "rife-v4.6 %dx%d frame pairs resident in HBM, timestep sweep %s, synthetic seeded weights" % (w, h, timesteps),
+                       "pairs_in_flight_per_gpu": nstreams, "parallelism": "frame pairs sharded over ranks, no data-path collective"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "extra": {"kernel_ms_per_pair": round(all_ms / args.steps, 4), "conv_ms_per_pair": round(conv_ms / args.steps, 4),
+                      "conv_tflops_overall": round(V46_GFLOP_PER_PAIR[args.workload] / max(conv_ms / args.steps, 1e-9), 2),
+                      "frac_of_fused_hbm_roofline_e2e": round(ROOFLINE_MS[args.workload] / (elapsed / args.steps * 1e3 / 1.0), 5),
+                      "per_class_ms_per_pair": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}},
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(modeldir, workload):
+    """The reference's `-g -1` path cannot be built here (ncnn/Vulkan absent), so the CPU leg is the oracle
+    (kind "port"), timed on a bounded sample: one 1920x1080 pair; for the 4K workload the result is scaled by
+    the pixel ratio (the work is linear in pixels)."""
+    from oracle import pyoracle
+    from tools import gen_frames
+    cores = min(len(os.sched_getaffinity(0)), 64)
+    o = pyoracle.OracleRIFE(rife_v4=True, num_threads=cores)
+    o.load(modeldir)
+    a, b = gen_frames.smooth_pair(1920, 1080, 1000)
+    t0 = time.perf_counter()
+    o.process(a, b, 0.5)
+    dt = time.perf_counter() - t0
+    scale = {"1080p": 1.0, "4k": 4.0}[workload]
+    return {"value": round(1.0 / (dt * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 pair at 1920x1080 in %.2f s with %d OpenMP threads%s" % (dt, cores, "" if scale == 1.0 else "; scaled x1/4 to 3840x2160 (work is linear in pixels)")}
+
+
+if __name__ == "__main__":
+    main()

@@ -44,12 +44,21 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def default_threads():
+    """Usable cores (cgroup/affinity aware), capped: the conv loops parallelise over <= 192 output channels."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 32))
+
+
 class OracleRIFE:
     """Mirror of the reference's `RIFE(gpuid=-1, ...)` (src/rife.h:11-52) on the CPU restatement."""
 
     def __init__(self, tta_mode=False, tta_temporal_mode=False, uhd_mode=False, num_threads=None, rife_v2=False, rife_v4=False):
         if num_threads is None:
-            num_threads = os.cpu_count() or 1
+            num_threads = default_threads()
         self.num_threads = num_threads
         self.h = lib().oracle_create(int(tta_mode), int(tta_temporal_mode), int(uhd_mode), int(num_threads), int(rife_v2), int(rife_v4))
 

@@ -14,9 +14,14 @@
 //   K loop  = Cin chunks of CC channels (staged to LDS: input halo tile + the chunk's weight slab)
 //             x taps x 8-channel groups; one ds_read_b128 per lane feeds 4 consecutive MFMA k-steps:
 //             lanes 0-31 hold channels g*8+0..3, lanes 32-63 channels g*8+4..7 (A: pixel rows, B: weights).
+//   pipeline: the global loads of chunk k+1 are issued into registers before the MFMAs of chunk k and
+//             written to LDS after them (issue-early / write-late), so HBM/L2 latency hides under the
+//             matrix pipe even at one workgroup per CU.
+//   block id -> (tile, n-tile/parity): n-tile fastest, and the tile index is remapped so that each XCD
+//             (block b runs on XCD b % 8) walks a contiguous band of tiles and re-reads halos from its own L2.
 // Layouts: activations NHWC fp32 with explicit channel stride/offset (so producers can write straight into
-// concat buffers); weights pre-packed on the host (see pack_conv_weights in engine.hip) in exactly the order the
-// B-fragment ds_read_b128 wants: [ntile][chunk][tap][g][half][n][4].
+// concat buffers); weights pre-packed on the host (pack_weights in engine.hip) in exactly the order the
+// B-fragment ds_read_b128 wants: [ntile][par][chunk][tap][g][half][n][4].
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,41 +52,95 @@ struct ConvArgs {
     int res_ld, res_coff;
     int Cout;              // real output channels (stores masked beyond)
     int nchunks;           // Cin_padded / CC
-    int ntaps;             // 9 (conv) or 4 (deconv parity)
-    int npar;              // 1 (conv) or 4 (deconv)
-    int tiles_x;
-    int8_t tdy[4][9], tdx[4][9];   // tap offsets in input pixels, per parity
+    int nz;                // n-tiles x parities
+    int tiles_x, ntiles_xy;
 };
 
-// geometry helpers (compile-time)
 template <int STRIDE, int MS> struct ConvGeom {
     static constexpr int TH = 4 * MS, TW = 32;
     static constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
 };
 
-template <int STRIDE, int MS, int NS, int CC>
-constexpr int conv_lds_bytes() {
-    return (ConvGeom<STRIDE, MS>::IH * ConvGeom<STRIDE, MS>::IW * (CC + 4) + 9 * CC * NS * 32) * 4;
-}
+template <int EPI> constexpr int conv_ntaps() { return EPI == EPI_STORE ? 9 : 4; }
 
 template <int STRIDE, int MS, int NS, int CC, int EPI>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+constexpr int conv_lds_bytes() {
+    return (ConvGeom<STRIDE, MS>::IH * ConvGeom<STRIDE, MS>::IW * (CC + 4) + conv_ntaps<EPI>() * CC * NS * 32) * 4;
+}
+
+// TAG only gives a layer class its own kernel symbol (so rocprofv3 --stats reports it separately).
+template <int STRIDE, int MS, int NS, int CC, int EPI, int TAG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_mfma_kernel(ConvArgs a) {
     using G = ConvGeom<STRIDE, MS>;
     constexpr int S = CC + 4;                 // LDS pixel stride (floats): S/4 odd -> conflict-free b128 column reads
     constexpr int NT = NS * 32;
     constexpr int NG = CC / 8;
+    constexpr int NTAPS = conv_ntaps<EPI>();
+    constexpr int NPAR = EPI == EPI_STORE ? 1 : 4;
+    constexpr int NQ = CC / 4;
+    constexpr int IN_F4 = G::IH * G::IW * NQ;              // float4s of one input chunk tile
+    constexpr int W_F4 = NTAPS * CC * NT / 4;              // float4s of one weight chunk slab
+    constexpr int NIN = (IN_F4 + 255) / 256, NW = (W_F4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lds_in = lds;                                   // [IH][IW][S]
-    float* lds_w = lds + G::IH * G::IW * S;                // [ntaps][NG][2][NT][4]
+    float* lds_w = lds + G::IH * G::IW * S;                // [NTAPS][NG][2][NT][4]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int half = lane >> 5, li = lane & 31;
-    const int tile = blockIdx.x;
+
+    // ---- block id -> (tile, z), XCD-aware (bijective for any grid size) ----
+    int L;
+    {
+        const int n = gridDim.x, b = blockIdx.x;
+        const int q = n >> 3, r = n & 7, xcd = b & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int tile = L / a.nz, z = L - tile * a.nz;
+    const int par = z % NPAR, ntile = z / NPAR;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int par = blockIdx.z % a.npar, ntile = blockIdx.z / a.npar;
     const int oy0 = ty * G::TH, ox0 = tx * G::TW;
     const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;   // top-left of the staged halo tile in input pixels
+
+    // ---- per-thread staging slots (chunk-independent part of the addresses, hoisted out of the K loop) ----
+    int goff[NIN];      // global float offset of this thread's k-th input float4 (channel chunk 0); 0 when out of image
+    unsigned inside = 0;  // bit k: the k-th float4 lies inside the image (else it is the conv zero padding)
+#pragma unroll
+    for (int k = 0; k < NIN; k++) {
+        const int idx = tid + k * 256;
+        const int p = idx / NQ, q = idx - p * NQ;
+        const int py = p / G::IW, px = p - py * G::IW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        const bool ok = idx < IN_F4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        goff[k] = ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff;
+        inside |= ok ? (1u << k) : 0u;
+    }
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk) + (size_t)z * a.nchunks * W_F4;
+
+    f32x4 rin[NIN], rw[NW];   // native vector type: keeps the staging registers out of scratch
+#define RIFE_ISSUE_LOADS(CH)                                                                                  \
+    {                                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < NIN; k++)                                                       \
+            rin[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC);                             \
+        _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                      \
+            const int idx = tid + k * 256;                                                                    \
+            rw[k] = wsrc[(size_t)(CH) * W_F4 + ((W_F4 % 256 == 0 || idx < W_F4) ? idx : 0)];                  \
+        }                                                                                                     \
+    }
+#define RIFE_WRITE_LDS()                                                                                      \
+    {                                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < NIN; k++) {                                                     \
+            const int idx = tid + k * 256;                                                                    \
+            const int p = idx / NQ, q = idx - p * NQ;                                                         \
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};                                                         \
+            const f32x4 v = ((inside >> k) & 1u) ? rin[k] : zero4;                                            \
+            if (idx < IN_F4) *reinterpret_cast<f32x4*>(lds_in + p * S + q * 4) = v;                           \
+        }                                                                                                     \
+        _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                      \
+            const int idx = tid + k * 256;                                                                    \
+            if (W_F4 % 256 == 0 || idx < W_F4) reinterpret_cast<f32x4*>(lds_w)[idx] = rw[k];                  \
+        }                                                                                                     \
+    }
 
     f32x16 acc[MS][NS];
 #pragma unroll
@@ -91,48 +150,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
-    const int wchunk = a.ntaps * CC * NT;                       // floats per weight chunk
-    const float* wbase = a.wpk + (size_t)(ntile * a.npar + par) * a.nchunks * wchunk;
+    // A-fragment base (tap (0,0), group 0) and B-fragment base for this lane
+    const float* abase = lds_in + ((wv * MS * STRIDE) * G::IW + li * STRIDE) * S + half * 4;
+    const float* bbase = lds_w + (half * NT + li) * 4;
+
+    RIFE_ISSUE_LOADS(0)
+    RIFE_WRITE_LDS()
+    __syncthreads();
 
     for (int ch = 0; ch < a.nchunks; ch++) {
-        __syncthreads();
-        // ---- stage the input halo tile, channels [ch*CC, ch*CC+CC) ----
-        {
-            constexpr int NQ = CC / 4;
-            constexpr int TOTAL = G::IH * G::IW * NQ;
-            const int cbase = a.in_coff + ch * CC;
-            for (int idx = tid; idx < TOTAL; idx += 256) {
-                const int p = idx / NQ, q = idx - p * NQ;
-                const int py = p / G::IW, px = p - py * G::IW;
-                const int gy = iy0 + py, gx = ix0 + px;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v = *reinterpret_cast<const float4*>(a.in + ((size_t)gy * a.W + gx) * a.in_ld + cbase + q * 4);
-                *reinterpret_cast<float4*>(lds_in + p * S + q * 4) = v;
+        const bool more = ch + 1 < a.nchunks;
+        if (more) RIFE_ISSUE_LOADS(ch + 1)                // in flight while the matrix pipe works on chunk ch
+#pragma unroll
+        for (int t = 0; t < NTAPS; t++) {
+            int dy, dx;                                   // tap offset + 1 (halo origin)
+            if (EPI == EPI_STORE) { dy = t / 3; dx = t % 3; }
+            else {   // deconv parity p, tap bit: 0 -> d = 0; 1 -> d = (p ? +1 : -1)   (see configure() in engine.hip)
+                dy = 1 + ((t >> 1) ? ((par >> 1) ? 1 : -1) : 0);
+                dx = 1 + ((t & 1) ? ((par & 1) ? 1 : -1) : 0);
             }
-        }
-        // ---- stage the weight slab of this chunk (contiguous, pre-packed) ----
-        {
-            const float4* src = reinterpret_cast<const float4*>(wbase + (size_t)ch * wchunk);
-            const int total = wchunk / 4;
-            for (int idx = tid; idx < total; idx += 256) reinterpret_cast<float4*>(lds_w)[idx] = src[idx];
-        }
-        __syncthreads();
-        // ---- MFMA over taps x 8-channel groups ----
-        for (int t = 0; t < a.ntaps; t++) {
-            const int dy = a.tdy[par][t] + 1, dx = a.tdx[par][t] + 1;
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 f32x4 af[MS], bf[NS];
 #pragma unroll
-                for (int m = 0; m < MS; m++) {
-                    const int r = wv * MS + m;
-                    const int pix = (r * STRIDE + dy) * G::IW + li * STRIDE + dx;
-                    af[m] = *reinterpret_cast<const f32x4*>(lds_in + pix * S + g * 8 + half * 4);
-                }
+                for (int m = 0; m < MS; m++)
+                    af[m] = *reinterpret_cast<const f32x4*>(abase + ((m * STRIDE + dy) * G::IW + dx) * S + g * 8);
 #pragma unroll
                 for (int n = 0; n < NS; n++)
-                    bf[n] = *reinterpret_cast<const f32x4*>(lds_w + (((t * NG + g) * 2 + half) * NT + n * 32 + li) * 4);
+                    bf[n] = *reinterpret_cast<const f32x4*>(bbase + ((t * NG + g) * 2 * NT + n * 32) * 4);
 #pragma unroll
                 for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -142,9 +187,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][s], bf[n][s], acc[m][n], 0, 0, 0);
             }
         }
+        if (more) {
+            __syncthreads();                               // every wave is done reading chunk ch
+            RIFE_WRITE_LDS()
+            __syncthreads();
+        }
     }
+#undef RIFE_ISSUE_LOADS
+#undef RIFE_WRITE_LDS
 
     // ---- epilogue: D[i][j], j = lane&31 (channel), i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel column) ----
+    // Loads (residual) are issued 16 at a time from clamped addresses, stores are the only predicated operations.
+    const int py = par >> 1, px = par & 1;
 #pragma unroll
     for (int n = 0; n < NS; n++) {
         const int co = ntile * NT + n * 32 + li;
@@ -154,25 +208,36 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int m = 0; m < MS; m++) {
             const int oy = oy0 + wv * MS + m;
+            const bool rowok = cok && oy < a.Ho;
+            float rv[16];
+            if (EPI == EPI_STORE && a.res != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const bool ok = rowok && ox < a.Wo;
+                    rv[r] = a.res[ok ? ((size_t)oy * a.Wo + ox) * a.res_ld + a.res_coff + co : 0];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) rv[r] = 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (!cok || oy >= a.Ho || ox >= a.Wo) continue;
+                const bool ok = rowok && ox < a.Wo;
                 float v = acc[m][n][r] + bias;
                 if (EPI == EPI_STORE) {
-                    if (a.res) v += a.res[((size_t)oy * a.Wo + ox) * a.res_ld + a.res_coff + co];
+                    if (a.res != nullptr) v += rv[r];
                     v = v < 0.f ? v * slope : v;
-                    a.out[((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + co] = v;
+                    if (ok) a.out[((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + co] = v;
                 } else if (EPI == EPI_DECONV || EPI == EPI_DECONV_SIG) {
-                    const int py = par >> 1, px = par & 1;
                     if (EPI == EPI_DECONV_SIG) v = 1.f / (1.f + expf(-v));
                     else v = v < 0.f ? v * slope : v;
-                    a.out[((size_t)(2 * oy + py) * (2 * a.Wo) + 2 * ox + px) * a.out_ld + a.out_coff + co] = v;
+                    if (ok) a.out[((size_t)(2 * oy + py) * (2 * a.Wo) + 2 * ox + px) * a.out_ld + a.out_coff + co] = v;
                 } else {   // EPI_DECONV_PS: deconv pixel (2oy+py, 2ox+px), channel co -> flow[c = co>>2][.. *2 + i][.. *2 + j]
-                    const int py = par >> 1, px = par & 1;
                     const int c = co >> 2, si = (co >> 1) & 1, sj = co & 1;
                     const int fy = 2 * (2 * oy + py) + si, fx = 2 * (2 * ox + px) + sj;
-                    a.out[((size_t)fy * (4 * a.Wo) + fx) * a.out_ld + a.out_coff + c] = v;
+                    if (ok) a.out[((size_t)fy * (4 * a.Wo) + fx) * a.out_ld + a.out_coff + c] = v;
                 }
             }
         }

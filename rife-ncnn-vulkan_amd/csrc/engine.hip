@@ -51,7 +51,7 @@ struct ConvLayer {
     float *d_w = nullptr, *d_bias = nullptr, *d_slope = nullptr;
     double flops_per_pixel = 0;           // algorithmic: 2 * MAC per GEMM-M pixel
     std::string cls;                      // profile class
-    int8_t tdy[4][9], tdx[4][9];
+    int tag = 0;                          // distinct kernel symbol for the profiled layer class
 };
 
 static void free_layer(ConvLayer& L) {
@@ -73,22 +73,15 @@ static void configure(ConvLayer& L) {
     L.nchunks = L.cin_p / L.CC;
     L.ntaps = L.deconv ? 4 : 9;
     L.npar = L.deconv ? 4 : 1;
-    std::memset(L.tdy, 0, sizeof L.tdy); std::memset(L.tdx, 0, sizeof L.tdx);
-    if (!L.deconv) {
-        for (int t = 0; t < 9; t++) { L.tdy[0][t] = (int8_t)(t / 3 - 1); L.tdx[0][t] = (int8_t)(t % 3 - 1); }
-    } else {
-        // out(2y+p) gathers input y+d through kernel row k with 2(y+d) + k - 1 = 2y + p  ->  p=0: (d=0,k=1),(d=-1,k=3); p=1: (d=0,k=2),(d=+1,k=0)
-        static const int D[2][2] = {{0, -1}, {0, 1}};
-        for (int par = 0; par < 4; par++)
-            for (int t = 0; t < 4; t++) { L.tdy[par][t] = (int8_t)D[par >> 1][t >> 1]; L.tdx[par][t] = (int8_t)D[par & 1][t & 1]; }
-    }
 }
 
 // ncnn weight order [oc][ic][kh][kw] (also for Deconvolution) -> MFMA B-fragment order
 // [ntile][par][chunk][tap][g][half][n][4], channel = chunk*CC + g*8 + half*4 + s.
 static std::vector<float> pack_weights(const ConvLayer& L, const float* w) {
     const int NT = L.NS * 32, NG = L.CC / 8, K = L.deconv ? 4 : 3;
-    static const int KD[2][2] = {{1, 3}, {2, 0}};   // deconv kernel row per (parity, tap), matching D[][] in configure()
+    // deconv: out(2y+p) gathers input y+d through kernel row k with 2(y+d) + k - 1 = 2y + p
+    //   p=0: tap bit 0 -> (d=0,k=1), bit 1 -> (d=-1,k=3);  p=1: bit 0 -> (d=0,k=2), bit 1 -> (d=+1,k=0)   (offsets: conv_mfma.h)
+    static const int KD[2][2] = {{1, 3}, {2, 0}};
     std::vector<float> out((size_t)L.ntiles * L.npar * L.nchunks * L.ntaps * L.CC * NT, 0.f);
     size_t o = 0;
     for (int nt = 0; nt < L.ntiles; nt++)
@@ -129,17 +122,12 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
 // ------------------------------------------------------------------------------------------------
 // kernel dispatch
 // ------------------------------------------------------------------------------------------------
-template <int STRIDE, int MS, int NS, int CC, int EPI>
-static hipError_t launch_cfg(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    auto kfn = conv_mfma_kernel<STRIDE, MS, NS, CC, EPI>;
-    constexpr int lds = conv_lds_bytes<STRIDE, MS, NS, CC>();
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+template <int STRIDE, int MS, int NS, int CC, int EPI, int TAG>
+static hipError_t launch_cfg(const ConvArgs& a, int nblocks, hipStream_t st) {
+    auto kfn = conv_mfma_kernel<STRIDE, MS, NS, CC, EPI, TAG>;
+    constexpr int lds = conv_lds_bytes<STRIDE, MS, NS, CC, EPI>();
+    static_assert(lds <= 64 * 1024, "tile does not fit the default dynamic LDS limit");
+    hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
@@ -154,27 +142,41 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
     a.res = res ? res->p : nullptr; a.res_ld = res ? res->ld : 0; a.res_coff = res ? res->coff : 0;
     a.Ho = L.deconv ? H : (H + 2 - 3) / L.stride + 1;
     a.Wo = L.deconv ? W : (W + 2 - 3) / L.stride + 1;
-    a.Cout = L.cout; a.nchunks = L.nchunks; a.ntaps = L.ntaps; a.npar = L.npar;
-    std::memcpy(a.tdy, L.tdy, sizeof a.tdy); std::memcpy(a.tdx, L.tdx, sizeof a.tdx);
+    a.Cout = L.cout; a.nchunks = L.nchunks; a.nz = L.ntiles * L.npar;
     if (x.ld % 4 || x.coff % 4 || x.ld - x.coff < L.cin_p) return fail(RIFE_HIP_EINVAL, "conv input view is not padded to the channel chunk");
-    const int TH = 4 * L.MS;
     a.tiles_x = (a.Wo + 31) / 32;
-    const int tiles_y = (a.Ho + TH - 1) / TH;
-    dim3 grid(a.tiles_x * tiles_y, 1, L.ntiles * L.npar);
+    // rows per wave: 2 when that still gives every CU >= 1.5 workgroups, else 1 (more, smaller workgroups for the coarse blocks)
+    int MS = L.MS;
+    if (L.stride == 1) {
+        const long wg2 = (long)a.tiles_x * ((a.Ho + 7) / 8) * a.nz;
+        MS = wg2 >= 384 ? 2 : 1;
+    }
+    a.ntiles_xy = a.tiles_x * ((a.Ho + 4 * MS - 1) / (4 * MS));
+    const int nblocks = a.ntiles_xy * a.nz;
     hipError_t e = hipErrorInvalidValue;
-#define RIFE_CFG(S_, MS_, NS_, CC_, E_) \
-    if (L.stride == S_ && L.MS == MS_ && L.NS == NS_ && L.CC == CC_ && L.epi == E_) e = launch_cfg<S_, MS_, NS_, CC_, E_>(a, grid, st); else
-    RIFE_CFG(2, 1, 1, 8, EPI_STORE)
-    RIFE_CFG(2, 1, 2, 8, EPI_STORE)
-    RIFE_CFG(2, 1, 3, 8, EPI_STORE)
-    RIFE_CFG(1, 2, 1, 16, EPI_STORE)
-    RIFE_CFG(1, 2, 2, 16, EPI_STORE)
-    RIFE_CFG(1, 2, 3, 8, EPI_STORE)
-    RIFE_CFG(1, 2, 1, 16, EPI_DECONV_PS)
-    RIFE_CFG(1, 2, 1, 16, EPI_DECONV)
-    RIFE_CFG(1, 2, 2, 16, EPI_DECONV)
-    RIFE_CFG(1, 2, 3, 8, EPI_DECONV)
-    RIFE_CFG(1, 2, 1, 16, EPI_DECONV_SIG)
+#define RIFE_CFG(S_, MS_, NS_, CC_, E_, T_) \
+    if (L.stride == S_ && MS == MS_ && L.NS == NS_ && L.CC == CC_ && L.epi == E_ && L.tag == T_) e = launch_cfg<S_, MS_, NS_, CC_, E_, T_>(a, nblocks, st); else
+    RIFE_CFG(2, 1, 1, 8, EPI_STORE, 0)
+    RIFE_CFG(2, 1, 2, 8, EPI_STORE, 0)
+    RIFE_CFG(2, 1, 3, 8, EPI_STORE, 0)
+    RIFE_CFG(1, 2, 2, 16, EPI_STORE, 3)
+    RIFE_CFG(1, 1, 2, 16, EPI_STORE, 3)
+    RIFE_CFG(1, 2, 1, 16, EPI_STORE, 0)
+    RIFE_CFG(1, 2, 2, 16, EPI_STORE, 0)
+    RIFE_CFG(1, 2, 3, 8, EPI_STORE, 0)
+    RIFE_CFG(1, 1, 1, 16, EPI_STORE, 0)
+    RIFE_CFG(1, 1, 2, 16, EPI_STORE, 0)
+    RIFE_CFG(1, 1, 3, 8, EPI_STORE, 0)
+    RIFE_CFG(1, 2, 1, 16, EPI_DECONV_PS, 0)
+    RIFE_CFG(1, 1, 1, 16, EPI_DECONV_PS, 0)
+    RIFE_CFG(1, 2, 1, 16, EPI_DECONV, 0)
+    RIFE_CFG(1, 2, 2, 16, EPI_DECONV, 0)
+    RIFE_CFG(1, 2, 3, 8, EPI_DECONV, 0)
+    RIFE_CFG(1, 1, 1, 16, EPI_DECONV, 0)
+    RIFE_CFG(1, 1, 2, 16, EPI_DECONV, 0)
+    RIFE_CFG(1, 1, 3, 8, EPI_DECONV, 0)
+    RIFE_CFG(1, 2, 1, 16, EPI_DECONV_SIG, 0)
+    RIFE_CFG(1, 1, 1, 16, EPI_DECONV_SIG, 0)
     { return fail(RIFE_HIP_ENOSYS, "no conv kernel instantiation for this layer shape"); }
 #undef RIFE_CFG
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv launch: ") + hipGetErrorString(e));
@@ -460,6 +462,7 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {
                 return fail(RIFE_HIP_EMODEL, "weighted layer " + nl->name + " does not match the rife-v4.6 schedule");
             free_layer(L);
             L.cin = cin; L.cout = cout; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi; L.cls = cls;
+            L.tag = std::strcmp(cls, "trunk_b3") == 0 ? 3 : 0;
             return upload_layer(L, nl->weight.data(), nl->bias.data(), nullptr, slope);
         };
         std::snprintf(name, sizeof name, "stem0_b%d", b);

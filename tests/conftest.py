@@ -18,10 +18,9 @@ def pytest_configure(config):
 def modeldirs(tmp_path_factory):
     """Seeded synthetic model directories in the reference's on-disk format (see tools/gen_models.py)."""
     from tools import gen_models
-    base = os.environ.get("RIFE_SYNTH_MODELS", os.path.join(ROOT, "gpurun_out", "_models"))
     out = {}
     for fam in ("rife-v4.6", "rife-v2.3"):
-        out[fam] = gen_models.ensure(os.path.join(base, fam), fam)
+        out[fam] = gen_models.ensure(None, fam)
     return out
 
 

@@ -1,0 +1,90 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol; host logic; the N>1 path
+(world_size 2, gloo) of the sharding helpers bench.py uses."""
+import ctypes
+import importlib
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REFERENCE, ROOT
+
+amd = importlib.import_module("rife-ncnn-vulkan_amd")
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rife_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(rife_hip_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(amd.C_ABI_SYMBOLS)
+    L = ctypes.CDLL(amd.LIB_PATH)
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_no_cpu_fallback_without_a_device():
+    """The product path must fail loudly, not fall back, when there is no GPU."""
+    if amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(amd.RifeError):
+        amd.RIFE(0, rife_v4=True)
+    with pytest.raises(amd.RifeError):
+        amd.op_warp(np.zeros((3, 4, 4), np.float32), np.zeros((2, 4, 4), np.float32))
+
+
+def test_product_does_not_import_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rife-ncnn-vulkan_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree only in the build container")
+def test_engine_accepts_the_reference_param_and_rejects_others():
+    from tools.param_hash import param_hash
+    hdr = open(os.path.join(ROOT, "rife-ncnn-vulkan_amd", "csrc", "model_hashes.h")).read()
+    want = int(re.search(r"RIFE_V46_HASH_OUT0\s+(0x[0-9a-f]+)ull", hdr).group(1), 16)
+    assert param_hash(os.path.join(REFERENCE, "models", "rife-v4.6", "flownet.param"), "out0") == want
+    assert param_hash(os.path.join(REFERENCE, "models", "rife-v4", "flownet.param"), "out0") != want
+
+
+def test_shard_pairs_partitions_the_work():
+    from importlib import import_module
+    sh = import_module("rife-ncnn-vulkan_amd.sharding")
+    for world in (1, 2, 3, 8):
+        seen = []
+        for r in range(world):
+            seen += sh.shard_pairs(37, r, world)
+        assert sorted(seen) == list(range(37))
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sh = importlib.import_module("rife-ncnn-vulkan_amd.sharding")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    import time
+    mine = sh.shard_pairs(10, rank, world)
+    done = []
+    def step(i):
+        done.append(mine[i % len(mine)])
+        time.sleep(0.01 * (rank + 1))          # rank 1 is slower: MAX must report its time on both ranks
+    el = sh.timed_steps(step, 5, dist=dist)
+    q.put((rank, mine, el))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_timing_and_sharding():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in ps]
+    assert res[0][1] == [0, 2, 4, 6, 8] and res[1][1] == [1, 3, 5, 7, 9]
+    assert abs(res[0][2] - res[1][2]) < 1e-9          # both ranks report the same (max) elapsed time
+    assert res[0][2] >= 5 * 0.02 * 0.9                # ... which is the slow rank's

@@ -334,8 +334,16 @@ def generate(outdir, family="rife-v4.6", seed=0x51FE, real_contextnet=None):
     return outdir
 
 
-def ensure(outdir, family="rife-v4.6", seed=0x51FE):
+def default_dir(family="rife-v4.6"):
+    """<repo>/_synth_models/<family>: git-ignored, regenerated on demand (deterministic), travels with gpurun snapshots."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return os.path.join(os.environ.get("RIFE_SYNTH_MODELS", os.path.join(root, "_synth_models")), family)
+
+
+def ensure(outdir=None, family="rife-v4.6", seed=0x51FE):
     """Idempotent: (re)generate only if the directory is incomplete."""
+    if outdir is None:
+        outdir = default_dir(family)
     need = [os.path.join(outdir, n + e) for n in FAMILIES[family] for e in (".param", ".bin")]
     if not all(os.path.exists(p) for p in need):
         generate(outdir, family, seed)

@@ -23,7 +23,7 @@ for (cin, cout, h, w) in [(64, 24, 16, 40), (32, 4, 12, 20)]:
 img = rng.uniform(0, 1, (3, 45, 70)).astype(np.float32); flow = (rng.standard_normal((2, 45, 70)) * 9).astype(np.float32)
 print("warp exact", np.array_equal(amd.op_warp(img, flow), pyoracle.warp(img, flow)))
 
-d = gen_models.ensure(os.path.join("gpurun_out", "_models", "rife-v4.6"), "rife-v4.6")
+d = gen_models.ensure(None, "rife-v4.6")
 g = amd.RIFE(0, rife_v4=True); g.load(d)
 o = pyoracle.OracleRIFE(rife_v4=True); o.set_gpu_crop(1); o.load(d)
 a, b = gen_frames.smooth_pair(160, 96, 21)
