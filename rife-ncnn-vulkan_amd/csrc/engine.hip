@@ -343,8 +343,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b) {
     const int Ht = Hb / 4, Wt = Wb / 4;
     for (int i = 0; i < 8; i++) {
         Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
-        TensorView res{cur, B.c, 0};
-        if ((rc = launch_conv(B.res[i], {cur, B.c, 0}, Ht, Wt, {nxt, B.c, 0}, &res, st))) return rc;
+        if ((rc = launch_conv(B.res[i], {cur, B.c, 0}, Ht, Wt, {nxt, B.c, 0}, nullptr, st))) return rc;   // skip folded into the weights
         std::swap(cur, nxt);
     }
     {
@@ -454,7 +453,7 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {
         rife_hip::Block& B = E->blk[b];
         B.c = C[b]; B.scale = SC[b];
         char name[64];
-        auto setup = [&](ConvLayer& L, int cin, int cout, int stride, bool deconv, int epi, float slope, const char* cls) -> int {
+        auto setup = [&](ConvLayer& L, int cin, int cout, int stride, bool deconv, int epi, float slope, const char* cls, bool fold_skip = false) -> int {
             const NcnnLayer* nl = wl[k++];
             const int kk = deconv ? 16 : 9;
             if (nl->type != (deconv ? "Deconvolution" : "Convolution") || nl->geti(0, 0) != cout || (int)nl->weight.size() != cin * cout * kk ||
@@ -463,6 +462,14 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {
             free_layer(L);
             L.cin = cin; L.cout = cout; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi; L.cls = cls;
             L.tag = std::strcmp(cls, "trunk_b3") == 0 ? 3 : 0;
+            if (fold_skip) {
+                // x + conv(x) == conv'(x) with W'[o][o][1][1] = W[o][o][1][1] + 1: the skip connection of the residual
+                // block (flownet.param:13-15 "Split, Convolution, BinaryOp add") rides the centre tap of the GEMM instead
+                // of a second read of x in the epilogue.  fp16-stored weights + 1.0f are exact in fp32 down to 2^-23.
+                std::vector<float> w2(nl->weight);
+                for (int o = 0; o < cout; o++) w2[((size_t)o * cin + o) * 9 + 4] += 1.0f;
+                return upload_layer(L, w2.data(), nl->bias.data(), nullptr, slope);
+            }
             return upload_layer(L, nl->weight.data(), nl->bias.data(), nullptr, slope);
         };
         std::snprintf(name, sizeof name, "stem0_b%d", b);
@@ -471,7 +478,7 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {
         if ((rc = setup(B.stem1, C[b] / 2, C[b], 2, false, EPI_STORE, 0.2f, name))) return rc;
         std::snprintf(name, sizeof name, "trunk_b%d", b);
         for (int i = 0; i < 8; i++)
-            if ((rc = setup(B.res[i], C[b], C[b], 1, false, EPI_STORE, 0.2f, name))) return rc;
+            if ((rc = setup(B.res[i], C[b], C[b], 1, false, EPI_STORE, 0.2f, name, true))) return rc;
         std::snprintf(name, sizeof name, "head_b%d", b);
         if ((rc = setup(B.head, C[b], 24, 2, true, EPI_DECONV_PS, 1.0f, name))) return rc;
     }
