@@ -219,6 +219,127 @@ __global__ void k_final(const uint32_t* __restrict__ img0, const uint32_t* __res
     o[2] = (uint8_t)min(max((int)(b * 255.f + 0.5f), 0), 255);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// TTA (-x spatial, -z temporal), rife-v4:  rife_preproc_tta.comp:40-93, rife_v4_flow_tta_avg.comp:25-129,
+// rife_v4_flow_tta_temporal_avg.comp:19-59, rife_postproc_tta.comp:40-81, rife_out_tta_temporal_avg.comp:19-36
+// and their CPU twins rife.cpp:3319-3413, 3477-3512, 3515-3821, 4056-4144.
+// ------------------------------------------------------------------------------------------------------------
+
+// index of base pixel (i = row, j = col) of a W x H plane inside orientation ti's buffer (ti >= 4: H wide, W tall)
+__device__ __forceinline__ size_t tta_index(int ti, int i, int j, int W, int H) {
+    switch (ti) {
+        case 0: return (size_t)i * W + j;
+        case 1: return (size_t)i * W + (W - 1 - j);
+        case 2: return (size_t)(H - 1 - i) * W + (W - 1 - j);
+        case 3: return (size_t)(H - 1 - i) * W + j;
+        case 4: return (size_t)j * H + i;
+        case 5: return (size_t)j * H + (H - 1 - i);
+        case 6: return (size_t)(W - 1 - j) * H + (H - 1 - i);
+        default: return (size_t)(W - 1 - j) * H + i;
+    }
+}
+
+struct Ptr8 { void* p[8]; };
+struct Ptr16 { const void* p[16]; };
+
+// u8 HWC RGB (w x h) -> the 8 orientations of the zero-padded RGBX image
+__global__ void k_preproc_tta(const uint8_t* __restrict__ rgb, int w, int h, Ptr8 outs, int wp, int hp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wp) return;
+    uint32_t v = 0;
+    if (x < w && y < h) {
+        const uint8_t* p = rgb + ((size_t)y * w + x) * 3;
+        v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 8; ti++) reinterpret_cast<uint32_t*>(outs.p[ti])[tta_index(ti, y, x, wp, hp)] = v;
+}
+
+// forward / reversed flow consensus, in place on both [H][W][8] tensors
+__global__ void k_v4_temporal_merge(float* __restrict__ f, float* __restrict__ r, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    float* a = f + i * 8; float* b = r + i * 8;
+    const float x = (a[0] + b[2]) * 0.5f, y = (a[1] + b[3]) * 0.5f, z = (a[2] + b[0]) * 0.5f, w = (a[3] + b[1]) * 0.5f;
+    const float m = (a[4] - b[4]) * 0.5f;
+    a[0] = x; a[1] = y; a[2] = z; a[3] = w; a[4] = m;
+    b[0] = z; b[1] = w; b[2] = x; b[3] = y; b[4] = -m;
+}
+
+// 8-orientation flow / mask consensus, in place on the eight [.][.][8] tensors; W x H = size of orientation 0
+__global__ void k_v4_spatial_avg(Ptr8 fl, int W, int H) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= W) return;
+    float* q[8];
+#pragma unroll
+    for (int ti = 0; ti < 8; ti++) q[ti] = reinterpret_cast<float*>(fl.p[ti]) + tta_index(ti, i, j, W, H) * 8;
+    const float x = (q[0][0] + -q[1][0] + -q[2][0] + q[3][0] + q[4][1] + q[5][1] + -q[6][1] + -q[7][1]) * 0.125f;
+    const float y = (q[0][1] + q[1][1] + -q[2][1] + -q[3][1] + q[4][0] + -q[5][0] + -q[6][0] + q[7][0]) * 0.125f;
+    const float z = (q[0][2] + -q[1][2] + -q[2][2] + q[3][2] + q[4][3] + q[5][3] + -q[6][3] + -q[7][3]) * 0.125f;
+    const float w = (q[0][3] + q[1][3] + -q[2][3] + -q[3][3] + q[4][2] + -q[5][2] + -q[6][2] + q[7][2]) * 0.125f;
+    const float m = (q[0][4] + q[1][4] + q[2][4] + q[3][4] + q[4][4] + q[5][4] + q[6][4] + q[7][4]) * 0.125f;
+    q[0][0] = x;  q[0][1] = y;  q[0][2] = z;  q[0][3] = w;
+    q[1][0] = -x; q[1][1] = y;  q[1][2] = -z; q[1][3] = w;
+    q[2][0] = -x; q[2][1] = -y; q[2][2] = -z; q[2][3] = -w;
+    q[3][0] = x;  q[3][1] = -y; q[3][2] = z;  q[3][3] = -w;
+    q[4][0] = y;  q[4][1] = x;  q[4][2] = w;  q[4][3] = z;
+    q[5][0] = -y; q[5][1] = x;  q[5][2] = -w; q[5][3] = z;
+    q[6][0] = -y; q[6][1] = -x; q[6][2] = -w; q[6][3] = -z;
+    q[7][0] = y;  q[7][1] = -x; q[7][2] = w;  q[7][3] = -z;
+#pragma unroll
+    for (int ti = 0; ti < 8; ti++) q[ti][4] = m;
+}
+
+// tail of the graph without postproc: out0 (3 x hp x wp) kept as float4 per padded pixel, for the TTA averaging
+__global__ void k_final_float(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, const float4* __restrict__ F,
+                              const float* __restrict__ M, const float* __restrict__ flow3, float4* __restrict__ out, int wp, int hp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wp) return;
+    const size_t i = (size_t)y * wp + x;
+    const float* fl = flow3 + i * 8;
+    const float4 d = *reinterpret_cast<const float4*>(fl);
+    float4 f = F[i];
+    f.x = f.x + d.x; f.y = f.y + d.y; f.z = f.z + d.z; f.w = f.w + d.w;
+    const float mm = M[i] + fl[4];
+    const float m = 1.f / (1.f + expf(-mm));
+    const float rm = 1.0f - m;
+    const float3 w1 = warp_rgbx(img1, x, y, f.z, f.w, wp, hp);
+    const float3 w0 = warp_rgbx(img0, x, y, f.x, f.y, wp, hp);
+    out[i] = make_float4(w0.x * m + w1.x * rm, w0.y * m + w1.y * rm, w0.z * m + w1.z * rm, 0.f);
+}
+
+// gather nori (1 | 8) orientations x ntemp (1 | 2) directions of out0 back to the base frame, average, postproc.
+// outs.p[ti] = forward outputs, outs.p[8 + ti] = time-reversed outputs.
+__global__ void k_postproc_tta(Ptr16 outs, int nori, int ntemp, uint8_t* __restrict__ out, int w, int h, int wp, int hp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    float v[3], vr[3];
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {
+        if (dir >= ntemp) break;
+        float s[3];
+        if (nori == 8) {
+            float4 t[8];
+#pragma unroll
+            for (int ti = 0; ti < 8; ti++) t[ti] = reinterpret_cast<const float4*>(outs.p[dir * 8 + ti])[tta_index(ti, y, x, wp, hp)];
+            s[0] = (t[0].x + t[1].x + t[2].x + t[3].x + t[4].x + t[5].x + t[6].x + t[7].x) / 8;
+            s[1] = (t[0].y + t[1].y + t[2].y + t[3].y + t[4].y + t[5].y + t[6].y + t[7].y) / 8;
+            s[2] = (t[0].z + t[1].z + t[2].z + t[3].z + t[4].z + t[5].z + t[6].z + t[7].z) / 8;
+        } else {
+            const float4 t = reinterpret_cast<const float4*>(outs.p[dir * 8])[(size_t)y * wp + x];
+            s[0] = t.x; s[1] = t.y; s[2] = t.z;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) { if (dir == 0) v[c] = s[c]; else vr[c] = s[c]; }
+    }
+    uint8_t* o = out + ((size_t)y * w + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float r = ntemp == 2 ? (v[c] + vr[c]) * 0.5f * 255.f + 0.5f : v[c] * 255.f + 0.5f;
+        o[c] = (uint8_t)min(max((int)r, 0), 255);
+    }
+}
+
 // layout converters for the parity taps (planar CHW fp32 <-> NHWC with a channel stride)
 __global__ void k_chw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int c, int h, int w, int ld) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;

@@ -240,6 +240,7 @@ struct Ctx {
     float *X = nullptr, *S1 = nullptr, *T0 = nullptr, *T1 = nullptr; // block input, stem-1 output, trunk ping/pong
     float* flow[4] = {nullptr, nullptr, nullptr, nullptr};           // [hp/s][wp/s][8]
     float4* F = nullptr; float* M = nullptr;                         // full-resolution flow (4ch) and mask logit
+    float4* outf = nullptr;                                          // TTA only: out0 as float, padded
     std::vector<void*> allocs;
     ~Ctx() {
         for (void* p : allocs) (void)hipFree(p);
@@ -274,10 +275,13 @@ struct rife_hip {
     mutable std::mutex mu;
     mutable std::vector<std::unique_ptr<Ctx>> free_ctx;                  // pool for the host-buffer entry point
     mutable std::map<void*, std::unique_ptr<Ctx>> stream_ctx;            // one workspace per caller stream
+    mutable std::mutex tta_mu;                                           // TTA passes share one set of workspaces
+    mutable std::unique_ptr<Ctx> tta_ctx[2][8];                          // [direction][orientation]
 
     ~rife_hip() {
         (void)hipSetDevice(gpuid);
         free_ctx.clear(); stream_ctx.clear();
+        for (auto& d : tta_ctx) for (auto& c : d) c.reset();
         for (auto& b : blk) { free_layer(b.stem0); free_layer(b.stem1); for (auto& r : b.res) free_layer(r); free_layer(b.head); }
     }
 };
@@ -288,23 +292,31 @@ namespace rife {
 // models/rife-v4.6/flownet.param; tests/test_models.py proves the equivalence whenever /root/reference exists)
 static const uint64_t V46_HASH_OUT0 = RIFE_V46_HASH_OUT0;
 
-static int ensure_ctx(Ctx& c, int w, int h) {
-    const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;    // rife.cpp:2499-2500
-    if (c.wp == wp && c.hp == hp && c.w == w && c.h == h) return 0;
+// (Re)allocate a workspace for frames of w x h (padded wp x hp).  `scratch` != null: borrow the big per-layer
+// scratch tensors (block input, stem output, trunk ping/pong) from another context of the same pixel count —
+// the TTA passes run one after another on one stream, only flows / F / M / images must persist per pass.
+static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scratch = nullptr, bool own_images = true, bool want_outf = false) {
+    if (c.wp == wp && c.hp == hp && c.w == w && c.h == h && (!want_outf || c.outf)) return 0;
     for (void* p : c.allocs) (void)hipFree(p);
     c.allocs.clear();
+    c.outf = nullptr;
     c.w = w; c.h = h; c.wp = wp; c.hp = hp;
     const size_t P = (size_t)wp * hp;
     int rc;
-    if ((rc = dalloc(c, c.d_in0, (size_t)w * h * 3))) return rc;
-    if ((rc = dalloc(c, c.d_in1, (size_t)w * h * 3))) return rc;
-    if ((rc = dalloc(c, c.d_out, (size_t)w * h * 3))) return rc;
-    if ((rc = dalloc(c, c.img0, P))) return rc;
-    if ((rc = dalloc(c, c.img1, P))) return rc;
-    if ((rc = dalloc(c, c.X, P * 16))) return rc;                  // block 3: full res x 16 ch
-    if ((rc = dalloc(c, c.S1, P / 4 * 32))) return rc;             // block 3 stem-0 output: (hp/2 x wp/2) x 32; block 0: (hp/16 x wp/16) x 96
-    if ((rc = dalloc(c, c.T0, P / 16 * 64))) return rc;            // block 3 trunk: (hp/4 x wp/4) x 64 (the largest trunk)
-    if ((rc = dalloc(c, c.T1, P / 16 * 64))) return rc;
+    if (own_images) {
+        if ((rc = dalloc(c, c.img0, P))) return rc;
+        if ((rc = dalloc(c, c.img1, P))) return rc;
+    }
+    if (scratch) { c.X = scratch->X; c.S1 = scratch->S1; c.T0 = scratch->T0; c.T1 = scratch->T1; }
+    else {
+        if ((rc = dalloc(c, c.d_in0, (size_t)w * h * 3))) return rc;
+        if ((rc = dalloc(c, c.d_in1, (size_t)w * h * 3))) return rc;
+        if ((rc = dalloc(c, c.d_out, (size_t)w * h * 3))) return rc;
+        if ((rc = dalloc(c, c.X, P * 16))) return rc;                  // block 3: full res x 16 ch
+        if ((rc = dalloc(c, c.S1, P / 4 * 32))) return rc;             // block 3 stem-0 output: (hp/2 x wp/2) x 32
+        if ((rc = dalloc(c, c.T0, P / 16 * 64))) return rc;            // block 3 trunk: (hp/4 x wp/4) x 64 (the largest trunk)
+        if ((rc = dalloc(c, c.T1, P / 16 * 64))) return rc;
+    }
     static const int sc[4] = {8, 4, 2, 1};
     for (int b = 0; b < 4; b++) {
         const size_t n = P / (sc[b] * sc[b]) * 8;
@@ -313,7 +325,12 @@ static int ensure_ctx(Ctx& c, int w, int h) {
     }
     if ((rc = dalloc(c, c.F, P))) return rc;
     if ((rc = dalloc(c, c.M, P))) return rc;
+    if (want_outf && (rc = dalloc(c, c.outf, P))) return rc;
     return 0;
+}
+
+static int ensure_ctx(Ctx& c, int w, int h) {
+    return ensure_ctx_dims(c, w, h, (w + 31) / 32 * 32, (h + 31) / 32 * 32);   // pad to 32n, rife.cpp:2499-2500
 }
 
 struct Timed {
@@ -396,6 +413,85 @@ static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     {
         Timed t(E.prof, "final", 0, st);
         hipLaunchKernelGGL(k_final, grid2d(c.w, c.h), dim3(256), 0, st, c.img0, c.img1, c.F, c.M, c.flow[3], d_out, c.w, c.h, c.wp, c.hp);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+// RIFE::process_v4 with -x and/or -z (rife.cpp:2534-2930 spatial TTA, 3036-3135 temporal only; CPU twin 3246-4145):
+// nori = 8 orientations or 1, ntemp = 2 directions (in0,in1,t) / (in1,in0,1-t) or 1.  Per IFBlock stage the flows of
+// all passes are merged (temporal first, then spatial, like the reference) before any pass goes on.
+static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, const uint8_t* d_in1, int w, int h, float timestep, uint8_t* d_out) {
+    const int nori = E.tta ? 8 : 1, ntemp = E.tta_temporal ? 2 : 1;
+    const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;
+    int rc;
+    for (int dir = 0; dir < ntemp; dir++)
+        for (int ti = 0; ti < nori; ti++) {
+            auto& up = E.tta_ctx[dir][ti];
+            if (!up) up.reset(new Ctx);
+            Ctx& c = *up;
+            c.stream = st;
+            const bool swap = ti >= 4;
+            const Ctx* scratch = (dir == 0 && ti == 0) ? nullptr : E.tta_ctx[0][0].get();
+            if ((rc = ensure_ctx_dims(c, swap ? h : w, swap ? w : h, swap ? hp : wp, swap ? wp : hp, scratch, dir == 0, true))) return rc;
+            if (dir == 1) { c.img0 = E.tta_ctx[0][ti]->img1; c.img1 = E.tta_ctx[0][ti]->img0; }   // reversed pass sees the frames swapped
+        }
+    {
+        Timed t(E.prof, "preproc", 0, st);
+        dim3 g = grid2d(wp, hp);
+        if (nori == 8) {
+            Ptr8 a, b;
+            for (int ti = 0; ti < 8; ti++) { a.p[ti] = E.tta_ctx[0][ti]->img0; b.p[ti] = E.tta_ctx[0][ti]->img1; }
+            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in0, w, h, a, wp, hp);
+            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in1, w, h, b, wp, hp);
+        } else {
+            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, w, h, E.tta_ctx[0][0]->img0, wp, hp);
+            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, w, h, E.tta_ctx[0][0]->img1, wp, hp);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    static const int SC[4] = {8, 4, 2, 1};
+    for (int fi = 0; fi < 4; fi++) {
+        const int Wf = wp / SC[fi], Hf = hp / SC[fi];
+        for (int ti = 0; ti < nori; ti++) {
+            for (int dir = 0; dir < ntemp; dir++) {
+                Ctx& c = *E.tta_ctx[dir][ti];
+                if ((rc = run_assemble(E, c, fi, dir ? 1.f - timestep : timestep))) return rc;
+                if ((rc = run_block_convs(E, c, fi))) return rc;
+            }
+            if (ntemp == 2) {
+                Timed t(E.prof, "tta_merge", 0, st);
+                const size_t npix = (size_t)Wf * Hf;
+                hipLaunchKernelGGL(k_v4_temporal_merge, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st,
+                                   E.tta_ctx[0][ti]->flow[fi], E.tta_ctx[1][ti]->flow[fi], npix);
+                HIPCHK(hipGetLastError());
+            }
+        }
+        if (nori == 8) {
+            Timed t(E.prof, "tta_merge", 0, st);
+            for (int dir = 0; dir < ntemp; dir++) {
+                Ptr8 f;
+                for (int ti = 0; ti < 8; ti++) f.p[ti] = E.tta_ctx[dir][ti]->flow[fi];
+                hipLaunchKernelGGL(k_v4_spatial_avg, grid2d(Wf, Hf), dim3(256), 0, st, f, Wf, Hf);
+            }
+            HIPCHK(hipGetLastError());
+        }
+        if (fi < 3)
+            for (int ti = 0; ti < nori; ti++)
+                for (int dir = 0; dir < ntemp; dir++)
+                    if ((rc = run_flow_update(E, *E.tta_ctx[dir][ti], fi))) return rc;
+    }
+    Ptr16 outs;
+    for (int i = 0; i < 16; i++) outs.p[i] = nullptr;
+    {
+        Timed t(E.prof, "final", 0, st);
+        for (int ti = 0; ti < nori; ti++)
+            for (int dir = 0; dir < ntemp; dir++) {
+                Ctx& c = *E.tta_ctx[dir][ti];
+                hipLaunchKernelGGL(k_final_float, grid2d(c.wp, c.hp), dim3(256), 0, st, c.img0, c.img1, c.F, c.M, c.flow[3], c.outf, c.wp, c.hp);
+                outs.p[dir * 8 + ti] = c.outf;
+            }
+        hipLaunchKernelGGL(k_postproc_tta, grid2d(w, h), dim3(256), 0, st, outs, nori, ntemp, d_out, w, h, wp, hp);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -490,7 +586,6 @@ static int process_common(const rife_hip* E, int w, int h, float timestep) {
     if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
     if (!E->loaded) return fail(RIFE_HIP_EINVAL, "process() before load()");
     if (w <= 0 || h <= 0) return fail(RIFE_HIP_EINVAL, "bad frame size");
-    if (E->tta || E->tta_temporal) return fail(RIFE_HIP_ENOSYS, "TTA modes are not implemented on the HIP path yet");
     (void)timestep;
     return 0;
 }
@@ -520,7 +615,12 @@ int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1
         if (e == hipSuccess) e = hipMemcpyAsync(c->d_in1, in1, nbytes, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) rc = fail(RIFE_HIP_EHIP, std::string("H2D: ") + hipGetErrorString(e));
     }
-    if (!rc) rc = run_v4(*E, *c, c->d_in0, c->d_in1, timestep, c->d_out);
+    if (!rc) {
+        if (E->tta || E->tta_temporal) {
+            std::lock_guard<std::mutex> g(E->tta_mu);
+            rc = run_v4_tta(*E, c->stream, c->d_in0, c->d_in1, w, h, timestep, c->d_out);
+        } else rc = run_v4(*E, *c, c->d_in0, c->d_in1, timestep, c->d_out);
+    }
     if (!rc) {
         hipError_t e = hipMemcpyAsync(out, c->d_out, nbytes, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -556,8 +656,15 @@ int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* 
     if (timestep == 0.f || timestep == 1.f) {
         HIPCHK(hipMemcpyAsync(d_out, timestep == 0.f ? d_in0 : d_in1, nbytes, hipMemcpyDeviceToDevice, c->stream));
     } else {
-        if ((rc = ensure_ctx(*c, w, h))) return rc;
-        if ((rc = run_v4(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, timestep, (uint8_t*)d_out))) return rc;
+        if (E->tta || E->tta_temporal) {
+            // the TTA workspaces are shared: serialise, and drain before another stream may reuse them
+            std::lock_guard<std::mutex> g(E->tta_mu);
+            if ((rc = run_v4_tta(*E, c->stream, (const uint8_t*)d_in0, (const uint8_t*)d_in1, w, h, timestep, (uint8_t*)d_out))) return rc;
+            HIPCHK(hipStreamSynchronize(c->stream));
+        } else {
+            if ((rc = ensure_ctx(*c, w, h))) return rc;
+            if ((rc = run_v4(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, timestep, (uint8_t*)d_out))) return rc;
+        }
     }
     if (!hip_stream) HIPCHK(hipStreamSynchronize(c->stream));
     return 0;

@@ -110,3 +110,46 @@ def test_load_rejects_wrong_family(modeldirs):
         g.load(modeldirs["rife-v2.3"])       # flownet.param there is the v2.3 IFNet
     with pytest.raises(amd.RifeError):
         g.load("/nonexistent/dir")
+
+
+def test_cpp_class_shim_matches_python_path(engines, modeldirs, tmp_path):
+    """`class RIFE` (csrc/rife.h, the reference's surface) driven from C++ like src/main.cpp:360 does."""
+    import subprocess
+    from test_host_and_sharding import build_shim_demo
+    g, _ = engines
+    exe = build_shim_demo(tmp_path)
+    a, b = gen_frames.smooth_pair(200, 120, 31)
+    (tmp_path / "a.rgb").write_bytes(a.tobytes()); (tmp_path / "b.rgb").write_bytes(b.tobytes())
+    r = subprocess.run([exe, modeldirs["rife-v4.6"], "200", "120", "0.25", str(tmp_path / "a.rgb"), str(tmp_path / "b.rgb"), str(tmp_path / "o.rgb")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.frombuffer((tmp_path / "o.rgb").read_bytes(), np.uint8).reshape(120, 200, 3)
+    assert np.array_equal(got, g.process(a, b, 0.25))
+
+
+@pytest.mark.parametrize("tta,temporal,w,h", [(True, False, 100, 60), (False, True, 96, 64), (True, True, 72, 40)])
+def test_tta_modes_within_1_lsb(modeldirs, tta, temporal, w, h):
+    """BASELINE config 5 (-x -z): 8 orientations x 2 directions with per-stage flow consensus
+    (rife.cpp:2534-2930; CPU twin 3246-4145)."""
+    d = modeldirs["rife-v4.6"]
+    g = amd.RIFE(0, tta_mode=tta, tta_temporal_mode=temporal, rife_v4=True)
+    g.load(d)
+    o = pyoracle.OracleRIFE(tta_mode=tta, tta_temporal_mode=temporal, rife_v4=True)
+    o.set_gpu_crop(1)
+    o.load(d)
+    a, b = gen_frames.smooth_pair(w, h, 40 + w)
+    got = g.process(a, b, 0.3)
+    want = o.process(a, b, 0.3)
+    mx, f0, f1, psnr = lsb_report(got, want)
+    assert mx <= 1, (mx, f0, f1, psnr)
+    assert f0 > 0.97
+    assert np.array_equal(got, g.process(a, b, 0.3))      # deterministic
+
+
+def test_tta_differs_from_plain(engines, modeldirs):
+    """Sanity: the ensemble really changes the result (otherwise the test above proves nothing)."""
+    g, _ = engines
+    gt = amd.RIFE(0, tta_mode=True, rife_v4=True)
+    gt.load(modeldirs["rife-v4.6"])
+    a, b = gen_frames.smooth_pair(96, 64, 5)
+    assert not np.array_equal(g.process(a, b, 0.5), gt.process(a, b, 0.5))

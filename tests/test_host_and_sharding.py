@@ -88,3 +88,26 @@ def test_two_rank_gloo_timing_and_sharding():
     assert res[0][1] == [0, 2, 4, 6, 8] and res[1][1] == [1, 3, 5, 7, 9]
     assert abs(res[0][2] - res[1][2]) < 1e-9          # both ranks report the same (max) elapsed time
     assert res[0][2] >= 5 * 0.02 * 0.9                # ... which is the slow rank's
+
+
+def build_shim_demo(outdir):
+    """Compile the C++ driver that uses `class RIFE` the way the reference's proc thread does."""
+    import subprocess
+    amd.build()
+    exe = os.path.join(str(outdir), "shim_demo")
+    pkg = os.path.join(ROOT, "rife-ncnn-vulkan_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(pkg, "csrc"), os.path.join(ROOT, "tests", "cpp", "shim_demo.cpp"),
+                           "-o", exe, "-L" + pkg, "-lrife", "-lrife_hip", "-Wl,-rpath," + pkg])
+    return exe
+
+
+def test_cpp_class_shim_compiles_and_fails_cleanly_without_gpu(tmp_path):
+    import subprocess
+    exe = build_shim_demo(tmp_path)
+    if amd.device_count() > 0:
+        pytest.skip("a GPU is present: covered by the gpu test")
+    (tmp_path / "a.rgb").write_bytes(bytes(4 * 4 * 3))
+    r = subprocess.run([exe, "/nonexistent", "4", "4", "0.5", str(tmp_path / "a.rgb"), str(tmp_path / "a.rgb"), str(tmp_path / "o.rgb")],
+                       capture_output=True, text=True)
+    assert r.returncode == 3                      # load() reported failure, no crash, no fallback
+    assert "RIFE" in r.stderr
