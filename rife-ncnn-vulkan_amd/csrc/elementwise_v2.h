@@ -1,0 +1,182 @@
+// Bandwidth-bound kernels of the rife-v2.x schedule (IFNet + ContextNet + FusionNet; reference
+// models/rife-v2.3/{flownet,contextnet,fusionnet}.param, orchestration src/rife.cpp:878-1183 / 2139-2457).
+// Same rules as elementwise.h: literal restatement of the reference arithmetic, -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "elementwise.h"
+
+namespace rife {
+
+// 2 * Interp(x2)(flow) at full-resolution pixel (x, y); flow is float4 per pixel at (hp/2 x wp/2)
+// (flownet.param:27-28 "Resize_22, Mul_24", fusionnet.param:14-15)
+__device__ __forceinline__ float4 flow_up2x2(const float4* __restrict__ flow, int x, int y, int wh, int hh) {
+    int sx, sy; float a0, a1, b0, b1;
+    up_coeff(x, 2, wh, sx, a0, a1);
+    up_coeff(y, 2, hh, sy, b0, b1);
+    const float4 q00 = flow[(size_t)sy * wh + sx], q01 = flow[(size_t)sy * wh + sx + 1];
+    const float4 q10 = flow[(size_t)(sy + 1) * wh + sx], q11 = flow[(size_t)(sy + 1) * wh + sx + 1];
+    float4 u;
+    u.x = ((q00.x * a0 + q01.x * a1) * b0 + (q10.x * a0 + q11.x * a1) * b1) * 2.0f;
+    u.y = ((q00.y * a0 + q01.y * a1) * b0 + (q10.y * a0 + q11.y * a1) * b1) * 2.0f;
+    u.z = ((q00.z * a0 + q01.z * a1) * b0 + (q10.z * a0 + q11.z * a1) * b1) * 2.0f;
+    u.w = ((q00.w * a0 + q01.w * a1) * b0 + (q10.w * a0 + q11.w * a1) * b1) * 2.0f;
+    return u;
+}
+
+// IFNet block 0 input: Interp(1/8)(Concat(input0, input1)) -> NHWC8 {rgb0, rgb1, 0, 0}   (flownet.param:5-7)
+__global__ void k2_assemble0(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float* __restrict__ X, int wp, int hp) {
+    const int Wb = wp / 8, Hb = hp / 8;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= Wb || y >= Hb) return;
+    const size_t i00 = (size_t)(8 * y + 3) * wp + 8 * x + 3, i10 = i00 + wp;
+    const float3 a0 = unpack_rgb(img0[i00]), a1 = unpack_rgb(img0[i00 + 1]), a2 = unpack_rgb(img0[i10]), a3 = unpack_rgb(img0[i10 + 1]);
+    const float3 b0 = unpack_rgb(img1[i00]), b1 = unpack_rgb(img1[i00 + 1]), b2 = unpack_rgb(img1[i10]), b3 = unpack_rgb(img1[i10 + 1]);
+    float4* dst = reinterpret_cast<float4*>(X + ((size_t)y * Wb + x) * 8);
+    dst[0] = make_float4(down4(a0.x, a1.x, a2.x, a3.x), down4(a0.y, a1.y, a2.y, a3.y), down4(a0.z, a1.z, a2.z, a3.z), down4(b0.x, b1.x, b2.x, b3.x));
+    dst[1] = make_float4(down4(b0.y, b1.y, b2.y, b3.y), down4(b0.z, b1.z, b2.z, b3.z), 0.f, 0.f);
+}
+
+// IFNet blocks 1..3 and FusionNet input (flownet.param:27-37, 58-68, 90-99; fusionnet.param:14-23):
+//   Ff = 2*Interp(x2)(acc);  x = Interp(1/S)(Concat(warp(img0, Ff.xy), warp(img1, Ff.zw), Ff))  -> NHWC16 (10 + 6 zero)
+template <int S>
+__global__ void k2_assemble(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, const float4* __restrict__ acc,
+                            float* __restrict__ X, int wp, int hp) {
+    const int Wb = wp / S, Hb = hp / S;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= Wb || y >= Hb) return;
+    float o[10];
+    if (S == 1) {
+        const float4 f = flow_up2x2(acc, x, y, wp / 2, hp / 2);
+        const float3 w0 = warp_rgbx(img0, x, y, f.x, f.y, wp, hp);
+        const float3 w1 = warp_rgbx(img1, x, y, f.z, f.w, wp, hp);
+        o[0] = w0.x; o[1] = w0.y; o[2] = w0.z; o[3] = w1.x; o[4] = w1.y; o[5] = w1.z; o[6] = f.x; o[7] = f.y; o[8] = f.z; o[9] = f.w;
+    } else {
+        const int sx = S * x + S / 2 - 1, sy = S * y + S / 2 - 1;
+        float v[4][10];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int px = sx + (k & 1), py = sy + (k >> 1);
+            const float4 f = flow_up2x2(acc, px, py, wp / 2, hp / 2);
+            const float3 w0 = warp_rgbx(img0, px, py, f.x, f.y, wp, hp);
+            const float3 w1 = warp_rgbx(img1, px, py, f.z, f.w, wp, hp);
+            v[k][0] = w0.x; v[k][1] = w0.y; v[k][2] = w0.z; v[k][3] = w1.x; v[k][4] = w1.y; v[k][5] = w1.z;
+            v[k][6] = f.x; v[k][7] = f.y; v[k][8] = f.z; v[k][9] = f.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 10; c++) o[c] = down4(v[0][c], v[1][c], v[2][c], v[3][c]);
+    }
+    float4* dst = reinterpret_cast<float4*>(X + ((size_t)y * Wb + x) * 16);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    dst[2] = make_float4(o[8], o[9], 0.f, 0.f);
+    dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// running flow sum at half resolution: acc = (FIRST ? 0 : acc) + Interp(xS)(D)   (flownet.param:25, 56, 87, 117-119)
+// D = deconv output, float4 per pixel at (hh/S x wh/S); acc float4 at (hh x wh)
+template <int S, bool FIRST>
+__global__ void k2_flow_accum(const float4* __restrict__ D, float4* __restrict__ acc, int wh, int hh) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wh) return;
+    float4 u;
+    if (S == 1) u = D[(size_t)y * wh + x];
+    else {
+        const int Wd = wh / S, Hd = hh / S;
+        int sx, sy; float a0, a1, b0, b1;
+        up_coeff(x, S, Wd, sx, a0, a1);
+        up_coeff(y, S, Hd, sy, b0, b1);
+        const float4 q00 = D[(size_t)sy * Wd + sx], q01 = D[(size_t)sy * Wd + sx + 1];
+        const float4 q10 = D[(size_t)(sy + 1) * Wd + sx], q11 = D[(size_t)(sy + 1) * Wd + sx + 1];
+        u.x = (q00.x * a0 + q01.x * a1) * b0 + (q10.x * a0 + q11.x * a1) * b1;
+        u.y = (q00.y * a0 + q01.y * a1) * b0 + (q10.y * a0 + q11.y * a1) * b1;
+        u.z = (q00.z * a0 + q01.z * a1) * b0 + (q10.z * a0 + q11.z * a1) * b1;
+        u.w = (q00.w * a0 + q01.w * a1) * b0 + (q10.w * a0 + q11.w * a1) * b1;
+    }
+    const size_t i = (size_t)y * wh + x;
+    if (FIRST) acc[i] = u;
+    else { const float4 a = acc[i]; acc[i] = make_float4(a.x + u.x, a.y + u.y, a.z + u.z, a.w + u.w); }
+}
+
+// ContextNet input: the padded frame as NHWC8 fp32 {r, g, b, 0...}   (contextnet.param:3)
+__global__ void k2_image_nhwc8(const uint32_t* __restrict__ img, float* __restrict__ X, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float3 c = unpack_rgb(img[i]);
+    float4* dst = reinterpret_cast<float4*>(X + i * 8);
+    dst[0] = make_float4(c.x, c.y, c.z, 0.f);
+    dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// flow pyramid of the ContextNet: out = Interp(1/2)(in) * 0.5, 2 channels   (contextnet.param:14-15, 23-24, 32-33, 40-41)
+// FROM4: level 0 reads channels (c0, c0+1) of the float4 flow (the Slice into flow0 / flow1, rife.cpp:1008-1016)
+template <bool FROM4>
+__global__ void k2_flow_half(const float* __restrict__ in, int c0, float2* __restrict__ out, int win, int hin) {
+    const int wo = win / 2, ho = hin / 2;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wo || y >= ho) return;
+    const int st = FROM4 ? 4 : 2;
+    const float* p00 = in + ((size_t)(2 * y) * win + 2 * x) * st + (FROM4 ? c0 : 0);
+    const float* p10 = p00 + (size_t)win * st;
+    out[(size_t)y * wo + x] = make_float2(down4(p00[0], p00[st], p10[0], p10[st]) * 0.5f, down4(p00[1], p00[st + 1], p10[1], p10[st + 1]) * 0.5f);
+}
+
+// rife.Warp on NHWC features (C % 4 == 0) with a 2-channel flow, written into a channel slice of a concat buffer
+// (contextnet.param:17, 26, 35, 42 -> fusionnet inputs "3".."10")
+__global__ void k2_warp_nhwc(const float* __restrict__ feat, int C, const float2* __restrict__ flow, float* __restrict__ out, int out_ld, int out_coff,
+                             int w, int h) {
+    const int q = threadIdx.x;                       // float4 lane within the pixel
+    const int nq = C / 4;
+    const int pix_per_block = blockDim.x / nq;
+    const int x = blockIdx.x * pix_per_block + threadIdx.x / nq, y = blockIdx.y;
+    if (x >= w || (int)threadIdx.x >= pix_per_block * nq) return;
+    const int c4 = q % nq;
+    const float2 f = flow[(size_t)y * w + x];
+    const WarpTaps t = warp_taps(x, y, f.x, f.y, w, h);
+    const float4 a = *reinterpret_cast<const float4*>(feat + (size_t)t.i00 * C + c4 * 4);
+    const float4 b = *reinterpret_cast<const float4*>(feat + (size_t)t.i01 * C + c4 * 4);
+    const float4 c = *reinterpret_cast<const float4*>(feat + (size_t)t.i10 * C + c4 * 4);
+    const float4 d = *reinterpret_cast<const float4*>(feat + (size_t)t.i11 * C + c4 * 4);
+    float4 o;
+    o.x = warp_lerp(a.x, b.x, c.x, d.x, t.alpha, t.beta); o.y = warp_lerp(a.y, b.y, c.y, d.y, t.alpha, t.beta);
+    o.z = warp_lerp(a.z, b.z, c.z, d.z, t.alpha, t.beta); o.w = warp_lerp(a.w, b.w, c.w, d.w, t.alpha, t.beta);
+    *reinterpret_cast<float4*>(out + ((size_t)y * w + x) * out_ld + out_coff + c4 * 4) = o;
+}
+
+// channel-slice copy between NHWC views (U-Net skip connections, fusionnet.param:53, 56, 59)
+__global__ void k2_copy_view(const float* __restrict__ src, int src_ld, int src_coff, float* __restrict__ dst, int dst_ld, int dst_coff, int C, size_t npix) {
+    const int nq = C / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * nq) return;
+    const size_t p = i / nq; const int q = (int)(i - p * nq);
+    *reinterpret_cast<float4*>(dst + p * dst_ld + dst_coff + q * 4) = *reinterpret_cast<const float4*>(src + p * src_ld + src_coff + q * 4);
+}
+
+// FusionNet tail + postproc (fusionnet.param:64-74; rife.cpp:1167-1182 / 2434-2456):
+//   o = sigmoid head (4 ch, applied in the deconv epilogue); res = o.rgb*2 - 1; m = o.w;
+//   out = clip(warp(img0,Ff.xy)*m + warp(img1,Ff.zw)*(1-m) + res, 0, 1);  u8 = clamp((int)(out*255 + 0.5))
+__global__ void k2_final(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, const float4* __restrict__ flow,
+                         const float4* __restrict__ head, uint8_t* __restrict__ out, int w, int h, int wp, int hp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const float4 f = flow_up2x2(flow, x, y, wp / 2, hp / 2);
+    const float3 w0 = warp_rgbx(img0, x, y, f.x, f.y, wp, hp);
+    const float3 w1 = warp_rgbx(img1, x, y, f.z, f.w, wp, hp);
+    const float4 o = head[(size_t)y * wp + x];
+    const float m = o.w, rm = 1.0f - m;
+    float v[3];
+    v[0] = (w0.x * m + w1.x * rm) + (o.x * 2.0f - 1.0f);
+    v[1] = (w0.y * m + w1.y * rm) + (o.y * 2.0f - 1.0f);
+    v[2] = (w0.z * m + w1.z * rm) + (o.z * 2.0f - 1.0f);
+    uint8_t* dst = out + ((size_t)y * w + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float t = v[c];
+        if (t < 0.f) t = 0.f;
+        if (t > 1.f) t = 1.f;
+        dst[c] = (uint8_t)min(max((int)(t * 255.f + 0.5f), 0), 255);
+    }
+}
+
+}  // namespace rife

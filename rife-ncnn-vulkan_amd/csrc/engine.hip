@@ -22,6 +22,7 @@
 #include "../../include/rife_hip.h"
 #include "conv_mfma.h"
 #include "elementwise.h"
+#include "elementwise_v2.h"
 #include "model_hashes.h"
 #include "ncnn_model.h"
 
@@ -241,6 +242,13 @@ struct Ctx {
     float* flow[4] = {nullptr, nullptr, nullptr, nullptr};           // [hp/s][wp/s][8]
     float4* F = nullptr; float* M = nullptr;                         // full-resolution flow (4ch) and mask logit
     float4* outf = nullptr;                                          // TTA only: out0 as float, padded
+    // rife-v2.x only
+    bool v2 = false;
+    float4 *acc = nullptr, *D = nullptr, *head = nullptr;           // running half-res flow, deconv output, fusion head
+    float *I8 = nullptr, *ca = nullptr, *cb = nullptr, *cc = nullptr, *feat[4] = {nullptr, nullptr, nullptr, nullptr}, *ctmp[3] = {nullptr, nullptr, nullptr};
+    float2* fl[4] = {nullptr, nullptr, nullptr, nullptr};           // ContextNet flow pyramid
+    float *e0a = nullptr, *e0b = nullptr, *e0c = nullptr, *B1 = nullptr, *e1a = nullptr, *B2 = nullptr, *e2a = nullptr, *B3 = nullptr, *e3a = nullptr, *B4 = nullptr;
+    float *U0 = nullptr, *U1 = nullptr, *U2 = nullptr, *U3 = nullptr;
     std::vector<void*> allocs;
     ~Ctx() {
         for (void* p : allocs) (void)hipFree(p);
@@ -271,6 +279,10 @@ struct rife_hip {
     bool loaded = false;
     // v4.6 schedule: per block {stem0, stem1, res x8, head}
     struct Block { ConvLayer stem0, stem1, res[8], head; int c = 0, scale = 1; } blk[4];
+    // rife-v2.x schedule (IFNet + ContextNet + FusionNet)
+    struct V2Block { ConvLayer stem0, stem1, conv[6], head; int c = 0, scale = 1; } fblk[4];
+    ConvLayer ctxc[10];          // ContextNet convs in graph order
+    ConvLayer fus[15];           // FusionNet: 10 down convs, 4 up deconvs, sigmoid head
     mutable Profiler prof;
     mutable std::mutex mu;
     mutable std::vector<std::unique_ptr<Ctx>> free_ctx;                  // pool for the host-buffer entry point
@@ -283,6 +295,9 @@ struct rife_hip {
         free_ctx.clear(); stream_ctx.clear();
         for (auto& d : tta_ctx) for (auto& c : d) c.reset();
         for (auto& b : blk) { free_layer(b.stem0); free_layer(b.stem1); for (auto& r : b.res) free_layer(r); free_layer(b.head); }
+        for (auto& b : fblk) { free_layer(b.stem0); free_layer(b.stem1); for (auto& r : b.conv) free_layer(r); free_layer(b.head); }
+        for (auto& l : ctxc) free_layer(l);
+        for (auto& l : fus) free_layer(l);
     }
 };
 
@@ -296,7 +311,8 @@ static const uint64_t V46_HASH_OUT0 = RIFE_V46_HASH_OUT0;
 // scratch tensors (block input, stem output, trunk ping/pong) from another context of the same pixel count —
 // the TTA passes run one after another on one stream, only flows / F / M / images must persist per pass.
 static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scratch = nullptr, bool own_images = true, bool want_outf = false) {
-    if (c.wp == wp && c.hp == hp && c.w == w && c.h == h && (!want_outf || c.outf)) return 0;
+    if (!c.v2 && c.wp == wp && c.hp == hp && c.w == w && c.h == h && (!want_outf || c.outf)) return 0;
+    c.v2 = false;
     for (void* p : c.allocs) (void)hipFree(p);
     c.allocs.clear();
     c.outf = nullptr;
@@ -497,6 +513,225 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// rife-v2.x: RIFE::process, non-TTA branch (rife.cpp:878-1183) = flownet -> slice -> contextnet x2 -> fusionnet
+// ------------------------------------------------------------------------------------------------
+static int ensure_ctx_v2(Ctx& c, int w, int h) {
+    const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;     // rife.cpp:417-418
+    if (c.v2 && c.wp == wp && c.hp == hp && c.w == w && c.h == h) return 0;
+    for (void* p : c.allocs) (void)hipFree(p);
+    c.allocs.clear();
+    c.v2 = true; c.w = w; c.h = h; c.wp = wp; c.hp = hp;
+    const size_t P = (size_t)wp * hp;
+    int rc;
+#define A_(ptr, n) if ((rc = dalloc(c, ptr, (size_t)(n)))) return rc;
+    A_(c.d_in0, (size_t)w * h * 3) A_(c.d_in1, (size_t)w * h * 3) A_(c.d_out, (size_t)w * h * 3)
+    A_(c.img0, P) A_(c.img1, P)
+    A_(c.X, P * 16) A_(c.S1, P / 4 * 48) A_(c.T0, P / 16 * 96) A_(c.T1, P / 16 * 96)
+    A_(c.acc, P / 4) A_(c.D, P / 4) A_(c.head, P)
+    A_(c.I8, P * 8) A_(c.ca, P / 4 * 32) A_(c.cb, P / 4 * 32) A_(c.cc, P / 16 * 32)
+    A_(c.feat[0], P / 16 * 32) A_(c.feat[1], P / 64 * 64) A_(c.feat[2], P / 256 * 128) A_(c.feat[3], P / 1024 * 256)
+    A_(c.ctmp[0], P / 64 * 64) A_(c.ctmp[1], P / 256 * 128) A_(c.ctmp[2], P / 1024 * 256)
+    A_(c.fl[0], P / 16) A_(c.fl[1], P / 64) A_(c.fl[2], P / 256) A_(c.fl[3], P / 1024)
+    A_(c.e0a, P / 4 * 32) A_(c.e0b, P / 4 * 32) A_(c.e0c, P / 16 * 64) A_(c.B1, P / 16 * 128) A_(c.e1a, P / 64 * 128) A_(c.B2, P / 64 * 256)
+    A_(c.e2a, P / 256 * 256) A_(c.B3, P / 256 * 512) A_(c.e3a, P / 1024 * 512) A_(c.B4, P / 1024 * 1024)
+    A_(c.U0, P / 256 * 512) A_(c.U1, P / 64 * 256) A_(c.U2, P / 16 * 128) A_(c.U3, P / 4 * 32)
+#undef A_
+    return 0;
+}
+
+static int conv_t(const rife_hip& E, const ConvLayer& L, TensorView x, int H, int W, TensorView y, hipStream_t st) {
+    const int mo_h = L.deconv ? H : (H - 1) / L.stride + 1, mo_w = L.deconv ? W : (W - 1) / L.stride + 1;
+    Timed t(E.prof, L.cls, L.flops_per_pixel * mo_h * mo_w, st);
+    return launch_conv(L, x, H, W, y, nullptr, st);
+}
+
+static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t* d_in1, uint8_t* d_out) {
+    hipStream_t st = c.stream;
+    const int wp = c.wp, hp = c.hp;
+    int rc;
+    {
+        Timed t(E.prof, "preproc", 0, st);
+        dim3 g = grid2d(wp, hp);
+        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.img0, wp, hp);
+        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.img1, wp, hp);
+        HIPCHK(hipGetLastError());
+    }
+    // ---- IFNet (flownet.param): 4 blocks at scales 8,4,2,1; flow accumulated at half resolution ----
+    const int wh = wp / 2, hh = hp / 2;
+    for (int b = 0; b < 4; b++) {
+        const rife_hip::V2Block& B = E.fblk[b];
+        const int s = B.scale, Hb = hp / s, Wb = wp / s;
+        {
+            Timed t(E.prof, "v2_assemble", 0, st);
+            dim3 g = grid2d(Wb, Hb);
+            if (b == 0) hipLaunchKernelGGL(k2_assemble0, g, dim3(256), 0, st, c.img0, c.img1, c.X, wp, hp);
+            else if (s == 4) hipLaunchKernelGGL(k2_assemble<4>, g, dim3(256), 0, st, c.img0, c.img1, c.acc, c.X, wp, hp);
+            else if (s == 2) hipLaunchKernelGGL(k2_assemble<2>, g, dim3(256), 0, st, c.img0, c.img1, c.acc, c.X, wp, hp);
+            else hipLaunchKernelGGL(k2_assemble<1>, g, dim3(256), 0, st, c.img0, c.img1, c.acc, c.X, wp, hp);
+            HIPCHK(hipGetLastError());
+        }
+        if ((rc = conv_t(E, B.stem0, {c.X, b == 0 ? 8 : 16, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, st))) return rc;
+        if ((rc = conv_t(E, B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {c.T0, B.c, 0}, st))) return rc;
+        float* cur = c.T0; float* nxt = c.T1;
+        const int Ht = Hb / 4, Wt = Wb / 4;
+        for (int i = 0; i < 6; i++) {
+            if ((rc = conv_t(E, B.conv[i], {cur, B.c, 0}, Ht, Wt, {nxt, B.c, 0}, st))) return rc;
+            std::swap(cur, nxt);
+        }
+        if ((rc = conv_t(E, B.head, {cur, B.c, 0}, Ht, Wt, {reinterpret_cast<float*>(c.D), 4, 0}, st))) return rc;
+        {
+            Timed t(E.prof, "v2_flow_accum", 0, st);
+            dim3 g = grid2d(wh, hh);
+            if (b == 0) hipLaunchKernelGGL((k2_flow_accum<8, true>), g, dim3(256), 0, st, c.D, c.acc, wh, hh);
+            else if (b == 1) hipLaunchKernelGGL((k2_flow_accum<4, false>), g, dim3(256), 0, st, c.D, c.acc, wh, hh);
+            else if (b == 2) hipLaunchKernelGGL((k2_flow_accum<2, false>), g, dim3(256), 0, st, c.D, c.acc, wh, hh);
+            else hipLaunchKernelGGL((k2_flow_accum<1, false>), g, dim3(256), 0, st, c.D, c.acc, wh, hh);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    // ---- ContextNet twice (contextnet.param): (img0, flow[0:2]) -> "3".."6", (img1, flow[2:4]) -> "7".."10",
+    //      each warped level written straight into its slice of the FusionNet concat buffers ----
+    float* cat_buf[4] = {c.B1, c.B2, c.B3, c.B4};
+    const int cat_ld[4] = {128, 256, 512, 1024}, cat_off[4] = {64, 128, 256, 512}, lvl_c[4] = {32, 64, 128, 256};
+    for (int im = 0; im < 2; im++) {
+        {
+            Timed t(E.prof, "v2_ctx_misc", 0, st);
+            const size_t P = (size_t)wp * hp;
+            hipLaunchKernelGGL(k2_image_nhwc8, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, im ? c.img1 : c.img0, c.I8, P);
+            hipLaunchKernelGGL(k2_flow_half<true>, grid2d(wh / 2, hh / 2), dim3(256), 0, st, reinterpret_cast<const float*>(c.acc), im * 2, c.fl[0], wh, hh);
+            for (int l = 1; l < 4; l++)
+                hipLaunchKernelGGL(k2_flow_half<false>, grid2d((wh >> l) / 2, (hh >> l) / 2), dim3(256), 0, st, reinterpret_cast<const float*>(c.fl[l - 1]), 0, c.fl[l],
+                                   wh >> l, hh >> l);
+            HIPCHK(hipGetLastError());
+        }
+        if ((rc = conv_t(E, E.ctxc[0], {c.I8, 8, 0}, hp, wp, {c.ca, 32, 0}, st))) return rc;
+        if ((rc = conv_t(E, E.ctxc[1], {c.ca, 32, 0}, hp / 2, wp / 2, {c.cb, 32, 0}, st))) return rc;
+        if ((rc = conv_t(E, E.ctxc[2], {c.cb, 32, 0}, hp / 2, wp / 2, {c.cc, 32, 0}, st))) return rc;
+        if ((rc = conv_t(E, E.ctxc[3], {c.cc, 32, 0}, hp / 4, wp / 4, {c.feat[0], 32, 0}, st))) return rc;
+        for (int l = 1; l < 4; l++) {
+            const int Hl = hp >> (l + 1), Wl = wp >> (l + 1);      // input resolution of this level's strided conv
+            if ((rc = conv_t(E, E.ctxc[2 + 2 * l], {c.feat[l - 1], lvl_c[l - 1], 0}, Hl, Wl, {c.ctmp[l - 1], lvl_c[l], 0}, st))) return rc;
+            if ((rc = conv_t(E, E.ctxc[3 + 2 * l], {c.ctmp[l - 1], lvl_c[l], 0}, Hl / 2, Wl / 2, {c.feat[l], lvl_c[l], 0}, st))) return rc;
+        }
+        {
+            Timed t(E.prof, "v2_ctx_misc", 0, st);
+            for (int l = 0; l < 4; l++) {
+                const int Hl = hp >> (l + 2), Wl = wp >> (l + 2), nq = lvl_c[l] / 4, ppb = 256 / nq;
+                hipLaunchKernelGGL(k2_warp_nhwc, dim3((Wl + ppb - 1) / ppb, Hl), dim3(256), 0, st, c.feat[l], lvl_c[l], c.fl[l], cat_buf[l], cat_ld[l],
+                                   cat_off[l] + im * lvl_c[l], Wl, Hl);
+            }
+            HIPCHK(hipGetLastError());
+        }
+    }
+    // ---- FusionNet (fusionnet.param) ----
+    {
+        Timed t(E.prof, "v2_assemble", 0, st);
+        hipLaunchKernelGGL(k2_assemble<1>, grid2d(wp, hp), dim3(256), 0, st, c.img0, c.img1, c.acc, c.X, wp, hp);
+        HIPCHK(hipGetLastError());
+    }
+    auto copy_view = [&](const float* src, int sld, int soff, float* dst, int dld, int doff, int C, size_t npix) {
+        const size_t n = npix * (C / 4);
+        hipLaunchKernelGGL(k2_copy_view, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, sld, soff, dst, dld, doff, C, npix);
+    };
+    const ConvLayer* F = E.fus;
+    if ((rc = conv_t(E, F[0], {c.X, 16, 0}, hp, wp, {c.e0a, 32, 0}, st))) return rc;
+    if ((rc = conv_t(E, F[1], {c.e0a, 32, 0}, hp / 2, wp / 2, {c.e0b, 32, 0}, st))) return rc;
+    if ((rc = conv_t(E, F[2], {c.e0b, 32, 0}, hp / 2, wp / 2, {c.e0c, 64, 0}, st))) return rc;
+    if ((rc = conv_t(E, F[3], {c.e0c, 64, 0}, hp / 4, wp / 4, {c.B1, 128, 0}, st))) return rc;            // s0 -> B1[0:64]
+    if ((rc = conv_t(E, F[4], {c.B1, 128, 0}, hp / 4, wp / 4, {c.e1a, 128, 0}, st))) return rc;
+    if ((rc = conv_t(E, F[5], {c.e1a, 128, 0}, hp / 8, wp / 8, {c.B2, 256, 0}, st))) return rc;           // s1 -> B2[0:128]
+    if ((rc = conv_t(E, F[6], {c.B2, 256, 0}, hp / 8, wp / 8, {c.e2a, 256, 0}, st))) return rc;
+    if ((rc = conv_t(E, F[7], {c.e2a, 256, 0}, hp / 16, wp / 16, {c.B3, 512, 0}, st))) return rc;         // s2 -> B3[0:256]
+    if ((rc = conv_t(E, F[8], {c.B3, 512, 0}, hp / 16, wp / 16, {c.e3a, 512, 0}, st))) return rc;
+    if ((rc = conv_t(E, F[9], {c.e3a, 512, 0}, hp / 32, wp / 32, {c.B4, 1024, 0}, st))) return rc;        // s3 -> B4[0:512]
+    {
+        Timed t(E.prof, "v2_skip_copy", 0, st);
+        copy_view(c.B3, 512, 0, c.U0, 512, 256, 256, (size_t)(hp / 16) * (wp / 16));                      // Concat(up0, s2)
+        copy_view(c.B2, 256, 0, c.U1, 256, 128, 128, (size_t)(hp / 8) * (wp / 8));                        // Concat(up1, s1)
+        copy_view(c.B1, 128, 0, c.U2, 128, 64, 64, (size_t)(hp / 4) * (wp / 4));                          // Concat(up2, s0)
+        HIPCHK(hipGetLastError());
+    }
+    if ((rc = conv_t(E, F[10], {c.B4, 1024, 0}, hp / 32, wp / 32, {c.U0, 512, 0}, st))) return rc;
+    if ((rc = conv_t(E, F[11], {c.U0, 512, 0}, hp / 16, wp / 16, {c.U1, 256, 0}, st))) return rc;
+    if ((rc = conv_t(E, F[12], {c.U1, 256, 0}, hp / 8, wp / 8, {c.U2, 128, 0}, st))) return rc;
+    if ((rc = conv_t(E, F[13], {c.U2, 128, 0}, hp / 4, wp / 4, {c.U3, 32, 0}, st))) return rc;
+    if ((rc = conv_t(E, F[14], {c.U3, 32, 0}, hp / 2, wp / 2, {reinterpret_cast<float*>(c.head), 4, 0}, st))) return rc;
+    {
+        Timed t(E.prof, "final", 0, st);
+        hipLaunchKernelGGL(k2_final, grid2d(c.w, c.h), dim3(256), 0, st, c.img0, c.img1, c.acc, c.head, d_out, c.w, c.h, wp, hp);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+// weights of the three v2 nets -> ConvLayers (conv/deconv each optionally followed by its PReLU in the .bin stream)
+static int load_v2(rife_hip* E, const std::string& dir) {
+    NcnnModel mf, mc, mu;
+    if (!mf.load_param(dir + "/flownet.param")) return fail(RIFE_HIP_EIO, mf.error);
+    if (!mc.load_param(dir + "/contextnet.param")) return fail(RIFE_HIP_EIO, mc.error);
+    if (!mu.load_param(dir + "/fusionnet.param")) return fail(RIFE_HIP_EIO, mu.error);
+    if (mf.structural_hash("flow") != RIFE_V23_HASH_FLOW || mc.structural_hash("f1") != RIFE_V23_HASH_F1 ||
+        mc.structural_hash("f2") != RIFE_V23_HASH_F2 || mc.structural_hash("f3") != RIFE_V23_HASH_F3 ||
+        mc.structural_hash("f4") != RIFE_V23_HASH_F4 || mu.structural_hash("output") != RIFE_V23_HASH_OUTPUT)
+        return fail(RIFE_HIP_EMODEL, dir + " does not hold the rife-v2.x IFNet/ContextNet/FusionNet graphs this engine schedules");
+    if (!mf.load_bin(dir + "/flownet.bin")) return fail(RIFE_HIP_EIO, mf.error);
+    if (!mc.load_bin(dir + "/contextnet.bin")) return fail(RIFE_HIP_EIO, mc.error);
+    if (!mu.load_bin(dir + "/fusionnet.bin")) return fail(RIFE_HIP_EIO, mu.error);
+    int rc;
+    auto take = [&](std::vector<const NcnnLayer*>& wl, size_t& k, ConvLayer& L, int cin, int cout, int stride, bool deconv, int epi, const char* cls) -> int {
+        if (k >= wl.size()) return fail(RIFE_HIP_EMODEL, "weight stream ended early");
+        const NcnnLayer* nl = wl[k++];
+        const int kk = deconv ? 16 : 9;
+        if (nl->type != (deconv ? "Deconvolution" : "Convolution") || nl->geti(0, 0) != cout || (int)nl->weight.size() != cin * cout * kk ||
+            nl->geti(3, 1) != stride)
+            return fail(RIFE_HIP_EMODEL, "weighted layer " + nl->name + " does not match the rife-v2.x schedule");
+        const float* slope = nullptr;
+        if (k < wl.size() && wl[k]->type == "PReLU") {
+            if ((int)wl[k]->slope.size() != cout) return fail(RIFE_HIP_EMODEL, "PReLU width mismatch after " + nl->name);
+            slope = wl[k++]->slope.data();
+        }
+        free_layer(L);
+        L.cin = cin; L.cout = cout; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi; L.cls = cls; L.tag = 0;
+        return upload_layer(L, nl->weight.data(), nl->bias.data(), slope, 1.0f);
+    };
+    {
+        std::vector<const NcnnLayer*> wl = mf.weighted(); size_t k = 0;
+        static const int C[4] = {384, 256, 192, 96}, SC[4] = {8, 4, 2, 1};
+        for (int b = 0; b < 4; b++) {
+            rife_hip::V2Block& B = E->fblk[b];
+            B.c = C[b]; B.scale = SC[b];
+            if ((rc = take(wl, k, B.stem0, b == 0 ? 6 : 10, C[b] / 2, 2, false, EPI_STORE, "v2_flow_stem"))) return rc;
+            if ((rc = take(wl, k, B.stem1, C[b] / 2, C[b], 2, false, EPI_STORE, "v2_flow_stem"))) return rc;
+            for (int i = 0; i < 6; i++)
+                if ((rc = take(wl, k, B.conv[i], C[b], C[b], 1, false, EPI_STORE, b == 0 ? "v2_flow_trunk_b0" : b == 1 ? "v2_flow_trunk_b1" : b == 2 ? "v2_flow_trunk_b2" : "v2_flow_trunk_b3"))) return rc;
+            if ((rc = take(wl, k, B.head, C[b], 4, 2, true, EPI_DECONV, "v2_flow_head"))) return rc;
+        }
+        if (k != wl.size()) return fail(RIFE_HIP_EMODEL, "flownet.bin has extra weighted layers");
+    }
+    {
+        std::vector<const NcnnLayer*> wl = mc.weighted(); size_t k = 0;
+        static const int CI[10] = {3, 32, 32, 32, 32, 64, 64, 128, 128, 256}, CO[10] = {32, 32, 32, 32, 64, 64, 128, 128, 256, 256};
+        static const int ST[10] = {2, 1, 2, 1, 2, 1, 2, 1, 2, 1};
+        for (int i = 0; i < 10; i++)
+            if ((rc = take(wl, k, E->ctxc[i], CI[i], CO[i], ST[i], false, EPI_STORE, "v2_context"))) return rc;
+        if (k != wl.size()) return fail(RIFE_HIP_EMODEL, "contextnet.bin has extra weighted layers");
+    }
+    {
+        std::vector<const NcnnLayer*> wl = mu.weighted(); size_t k = 0;
+        static const int CI[10] = {10, 32, 32, 64, 128, 128, 256, 256, 512, 512}, CO[10] = {32, 32, 64, 64, 128, 128, 256, 256, 512, 512};
+        static const int ST[10] = {2, 1, 2, 1, 2, 1, 2, 1, 2, 1};
+        for (int i = 0; i < 10; i++)
+            if ((rc = take(wl, k, E->fus[i], CI[i], CO[i], ST[i], false, EPI_STORE, "v2_fusion_down"))) return rc;
+        static const int UI[4] = {1024, 512, 256, 128}, UO[4] = {256, 128, 64, 32};
+        for (int i = 0; i < 4; i++)
+            if ((rc = take(wl, k, E->fus[10 + i], UI[i], UO[i], 2, true, EPI_DECONV, "v2_fusion_up"))) return rc;
+        if ((rc = take(wl, k, E->fus[14], 32, 4, 2, true, EPI_DECONV_SIG, "v2_fusion_head"))) return rc;
+        if (k != wl.size()) return fail(RIFE_HIP_EMODEL, "fusionnet.bin has extra weighted layers");
+    }
+    return 0;
+}
+
 static int check_device(int gpuid) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RIFE_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
@@ -534,7 +769,14 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {
     if (!E || !modeldir) return fail(RIFE_HIP_EINVAL, "null argument");
     int rc;
     if ((rc = check_device(E->gpuid))) return rc;
-    if (!E->v4) return fail(RIFE_HIP_ENOSYS, "only the rife-v4.x family is implemented on the HIP path so far");
+    if (E->v2 && !E->v4) {
+        if (E->tta || E->tta_temporal) return fail(RIFE_HIP_ENOSYS, "TTA is implemented for the rife-v4 family only");
+        if (E->uhd) return fail(RIFE_HIP_ENOSYS, "UHD mode (-u) is not implemented on the HIP path yet");
+        if ((rc = load_v2(E, modeldir))) return rc;
+        E->loaded = true;
+        return 0;
+    }
+    if (!E->v4) return fail(RIFE_HIP_ENOSYS, "the rife-v1 family (rife, rife-HD, rife-UHD, rife-anime) is not implemented");
     NcnnModel m;
     const std::string base = std::string(modeldir) + "/flownet";
     if (!m.load_param(base + ".param")) return fail(RIFE_HIP_EIO, m.error);
@@ -609,14 +851,15 @@ int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
         c->own_stream = true;
     }
-    rc = ensure_ctx(*c, w, h);
+    rc = E->v4 ? ensure_ctx(*c, w, h) : ensure_ctx_v2(*c, w, h);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(c->d_in0, in0, nbytes, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->d_in1, in1, nbytes, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) rc = fail(RIFE_HIP_EHIP, std::string("H2D: ") + hipGetErrorString(e));
     }
     if (!rc) {
-        if (E->tta || E->tta_temporal) {
+        if (!E->v4) rc = run_v2(*E, *c, c->d_in0, c->d_in1, c->d_out);
+        else if (E->tta || E->tta_temporal) {
             std::lock_guard<std::mutex> g(E->tta_mu);
             rc = run_v4_tta(*E, c->stream, c->d_in0, c->d_in1, w, h, timestep, c->d_out);
         } else rc = run_v4(*E, *c, c->d_in0, c->d_in1, timestep, c->d_out);
@@ -656,7 +899,10 @@ int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* 
     if (timestep == 0.f || timestep == 1.f) {
         HIPCHK(hipMemcpyAsync(d_out, timestep == 0.f ? d_in0 : d_in1, nbytes, hipMemcpyDeviceToDevice, c->stream));
     } else {
-        if (E->tta || E->tta_temporal) {
+        if (!E->v4) {
+            if ((rc = ensure_ctx_v2(*c, w, h))) return rc;
+            if ((rc = run_v2(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, (uint8_t*)d_out))) return rc;
+        } else if (E->tta || E->tta_temporal) {
             // the TTA workspaces are shared: serialise, and drain before another stream may reuse them
             std::lock_guard<std::mutex> g(E->tta_mu);
             if ((rc = run_v4_tta(*E, c->stream, (const uint8_t*)d_in0, (const uint8_t*)d_in1, w, h, timestep, (uint8_t*)d_out))) return rc;
@@ -702,6 +948,7 @@ int rife_hip_v4_extract_flow(const rife_hip_t* E, const uint8_t* in0, const uint
                              const float* const* inject, int n_inject, float* out6chw) {
     int rc;
     if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (!E->v4) return fail(RIFE_HIP_EINVAL, "stage taps exist for the rife-v4 family only");
     if (fi < 0 || fi > 3 || n_inject < 0 || n_inject > fi) return fail(RIFE_HIP_EINVAL, "bad stage index");
     if ((rc = check_device(E->gpuid))) return rc;
     Ctx c;

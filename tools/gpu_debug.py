@@ -39,3 +39,13 @@ g.profile_enable(True)
 for _ in range(3): g.process(a, b, 0.5)
 for k, v in sorted(g.profile_read().items(), key=lambda kv: -kv[1]["ms"]):
     print("%-14s launches %4d  ms %9.3f  TFLOP/s %7.2f" % (k, v["launches"], v["ms"], v["flops"] / max(v["ms"], 1e-9) / 1e9))
+
+# ---- rife-v2.3 ----
+d2 = gen_models.ensure(None, "rife-v2.3")
+g2 = amd.RIFE(0, rife_v2=True); g2.load(d2)
+o2 = pyoracle.OracleRIFE(rife_v2=True); o2.set_gpu_crop(1); o2.load(d2)
+for (w, h) in [(64, 64), (160, 96), (640, 360)]:
+    a, b = gen_frames.smooth_pair(w, h, 300)
+    got = g2.process(a, b, 0.5); want = o2.process(a, b, 0.5)
+    dd = np.abs(got.astype(int) - want.astype(int))
+    print("v2.3 process", w, h, "maxLSB", dd.max(), "frac0", (dd == 0).mean(), "mean", got.mean(), want.mean())
