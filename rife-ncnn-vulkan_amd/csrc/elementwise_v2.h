@@ -9,6 +9,32 @@
 
 namespace rife {
 
+// Image accessors: the padded frame is RGBX u8 (normal mode) or, for the UHD half-resolution flow estimate, a float4
+// image produced by Interp(0.5) of the fp32 frame (rife_uhd_downscale_image, rife.cpp:294-306, 928-931).
+struct ImgU8 { const uint32_t* p; __device__ __forceinline__ float3 at(size_t i) const { return unpack_rgb(p[i]); } };
+struct ImgF4 { const float4* p; __device__ __forceinline__ float3 at(size_t i) const { const float4 v = p[i]; return make_float3(v.x, v.y, v.z); } };
+
+template <typename IMG>
+__device__ __forceinline__ float3 warp_img(const IMG& img, int x, int y, float fx, float fy, int w, int h) {
+    const WarpTaps t = warp_taps(x, y, fx, fy, w, h);
+    const float3 a = img.at(t.i00), b = img.at(t.i01), c = img.at(t.i10), d = img.at(t.i11);
+    return make_float3(warp_lerp(a.x, b.x, c.x, d.x, t.alpha, t.beta), warp_lerp(a.y, b.y, c.y, d.y, t.alpha, t.beta),
+                       warp_lerp(a.z, b.z, c.z, d.z, t.alpha, t.beta));
+}
+
+// UHD: in_downscaled = Interp(0.5)(in_padded) as float4 per pixel (rife.cpp:928-931)
+__global__ void k2_image_half(const uint32_t* __restrict__ img, float4* __restrict__ out, int wp, int hp) {
+    const int wo = wp / 2, ho = hp / 2;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wo || y >= ho) return;
+    const size_t i00 = (size_t)(2 * y) * wp + 2 * x, i10 = i00 + wp;
+    const float3 a = unpack_rgb(img[i00]), b = unpack_rgb(img[i00 + 1]), c = unpack_rgb(img[i10]), d = unpack_rgb(img[i10 + 1]);
+    out[(size_t)y * wo + x] = make_float4(down4(a.x, b.x, c.x, d.x), down4(a.y, b.y, c.y, d.y), down4(a.z, b.z, c.z, d.z), 0.f);
+}
+
+// UHD: flow = Interp(x2)(flow_downscaled) * 2   (rife_uhd_upscale_flow + rife_uhd_double_flow, rife.cpp:308-332, 940-944)
+__global__ void k2_flow_up2_double(const float4* __restrict__ in, float4* __restrict__ out, int wo, int ho);
+
 // 2 * Interp(x2)(flow) at full-resolution pixel (x, y); flow is float4 per pixel at (hp/2 x wp/2)
 // (flownet.param:27-28 "Resize_22, Mul_24", fusionnet.param:14-15)
 __device__ __forceinline__ float4 flow_up2x2(const float4* __restrict__ flow, int x, int y, int wh, int hh) {
@@ -26,13 +52,14 @@ __device__ __forceinline__ float4 flow_up2x2(const float4* __restrict__ flow, in
 }
 
 // IFNet block 0 input: Interp(1/8)(Concat(input0, input1)) -> NHWC8 {rgb0, rgb1, 0, 0}   (flownet.param:5-7)
-__global__ void k2_assemble0(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float* __restrict__ X, int wp, int hp) {
+template <typename IMG>
+__global__ void k2_assemble0(IMG img0, IMG img1, float* __restrict__ X, int wp, int hp) {
     const int Wb = wp / 8, Hb = hp / 8;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= Wb || y >= Hb) return;
     const size_t i00 = (size_t)(8 * y + 3) * wp + 8 * x + 3, i10 = i00 + wp;
-    const float3 a0 = unpack_rgb(img0[i00]), a1 = unpack_rgb(img0[i00 + 1]), a2 = unpack_rgb(img0[i10]), a3 = unpack_rgb(img0[i10 + 1]);
-    const float3 b0 = unpack_rgb(img1[i00]), b1 = unpack_rgb(img1[i00 + 1]), b2 = unpack_rgb(img1[i10]), b3 = unpack_rgb(img1[i10 + 1]);
+    const float3 a0 = img0.at(i00), a1 = img0.at(i00 + 1), a2 = img0.at(i10), a3 = img0.at(i10 + 1);
+    const float3 b0 = img1.at(i00), b1 = img1.at(i00 + 1), b2 = img1.at(i10), b3 = img1.at(i10 + 1);
     float4* dst = reinterpret_cast<float4*>(X + ((size_t)y * Wb + x) * 8);
     dst[0] = make_float4(down4(a0.x, a1.x, a2.x, a3.x), down4(a0.y, a1.y, a2.y, a3.y), down4(a0.z, a1.z, a2.z, a3.z), down4(b0.x, b1.x, b2.x, b3.x));
     dst[1] = make_float4(down4(b0.y, b1.y, b2.y, b3.y), down4(b0.z, b1.z, b2.z, b3.z), 0.f, 0.f);
@@ -40,17 +67,16 @@ __global__ void k2_assemble0(const uint32_t* __restrict__ img0, const uint32_t* 
 
 // IFNet blocks 1..3 and FusionNet input (flownet.param:27-37, 58-68, 90-99; fusionnet.param:14-23):
 //   Ff = 2*Interp(x2)(acc);  x = Interp(1/S)(Concat(warp(img0, Ff.xy), warp(img1, Ff.zw), Ff))  -> NHWC16 (10 + 6 zero)
-template <int S>
-__global__ void k2_assemble(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, const float4* __restrict__ acc,
-                            float* __restrict__ X, int wp, int hp) {
+template <int S, typename IMG>
+__global__ void k2_assemble(IMG img0, IMG img1, const float4* __restrict__ acc, float* __restrict__ X, int wp, int hp) {
     const int Wb = wp / S, Hb = hp / S;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= Wb || y >= Hb) return;
     float o[10];
     if (S == 1) {
         const float4 f = flow_up2x2(acc, x, y, wp / 2, hp / 2);
-        const float3 w0 = warp_rgbx(img0, x, y, f.x, f.y, wp, hp);
-        const float3 w1 = warp_rgbx(img1, x, y, f.z, f.w, wp, hp);
+        const float3 w0 = warp_img(img0, x, y, f.x, f.y, wp, hp);
+        const float3 w1 = warp_img(img1, x, y, f.z, f.w, wp, hp);
         o[0] = w0.x; o[1] = w0.y; o[2] = w0.z; o[3] = w1.x; o[4] = w1.y; o[5] = w1.z; o[6] = f.x; o[7] = f.y; o[8] = f.z; o[9] = f.w;
     } else {
         const int sx = S * x + S / 2 - 1, sy = S * y + S / 2 - 1;
@@ -59,8 +85,8 @@ __global__ void k2_assemble(const uint32_t* __restrict__ img0, const uint32_t* _
         for (int k = 0; k < 4; k++) {
             const int px = sx + (k & 1), py = sy + (k >> 1);
             const float4 f = flow_up2x2(acc, px, py, wp / 2, hp / 2);
-            const float3 w0 = warp_rgbx(img0, px, py, f.x, f.y, wp, hp);
-            const float3 w1 = warp_rgbx(img1, px, py, f.z, f.w, wp, hp);
+            const float3 w0 = warp_img(img0, px, py, f.x, f.y, wp, hp);
+            const float3 w1 = warp_img(img1, px, py, f.z, f.w, wp, hp);
             v[k][0] = w0.x; v[k][1] = w0.y; v[k][2] = w0.z; v[k][3] = w1.x; v[k][4] = w1.y; v[k][5] = w1.z;
             v[k][6] = f.x; v[k][7] = f.y; v[k][8] = f.z; v[k][9] = f.w;
         }
@@ -177,6 +203,12 @@ __global__ void k2_final(const uint32_t* __restrict__ img0, const uint32_t* __re
         if (t > 1.f) t = 1.f;
         dst[c] = (uint8_t)min(max((int)(t * 255.f + 0.5f), 0), 255);
     }
+}
+
+__global__ void k2_flow_up2_double(const float4* __restrict__ in, float4* __restrict__ out, int wo, int ho) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wo) return;
+    out[(size_t)y * wo + x] = flow_up2x2(in, x, y, wo / 2, ho / 2);      // (Interp x2) * 2.0: the same arithmetic as the in-graph "Resize, Mul 2"
 }
 
 }  // namespace rife

@@ -245,6 +245,7 @@ struct Ctx {
     // rife-v2.x only
     bool v2 = false;
     float4 *acc = nullptr, *D = nullptr, *head = nullptr;           // running half-res flow, deconv output, fusion head
+    float4 *h0 = nullptr, *h1 = nullptr, *acc_s = nullptr;          // UHD: half-resolution fp32 frames and their (quarter-res) flow
     float *I8 = nullptr, *ca = nullptr, *cb = nullptr, *cc = nullptr, *feat[4] = {nullptr, nullptr, nullptr, nullptr}, *ctmp[3] = {nullptr, nullptr, nullptr};
     float2* fl[4] = {nullptr, nullptr, nullptr, nullptr};           // ContextNet flow pyramid
     float *e0a = nullptr, *e0b = nullptr, *e0c = nullptr, *B1 = nullptr, *e1a = nullptr, *B2 = nullptr, *e2a = nullptr, *B3 = nullptr, *e3a = nullptr, *B4 = nullptr;
@@ -516,9 +517,10 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
 // ------------------------------------------------------------------------------------------------
 // rife-v2.x: RIFE::process, non-TTA branch (rife.cpp:878-1183) = flownet -> slice -> contextnet x2 -> fusionnet
 // ------------------------------------------------------------------------------------------------
-static int ensure_ctx_v2(Ctx& c, int w, int h) {
+static int ensure_ctx_v2(Ctx& c, int w, int h, bool uhd) {
     const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;     // rife.cpp:417-418
-    if (c.v2 && c.wp == wp && c.hp == hp && c.w == w && c.h == h) return 0;
+    if (c.v2 && c.wp == wp && c.hp == hp && c.w == w && c.h == h && (!uhd || c.h0)) return 0;
+    c.h0 = c.h1 = c.acc_s = nullptr;
     for (void* p : c.allocs) (void)hipFree(p);
     c.allocs.clear();
     c.v2 = true; c.w = w; c.h = h; c.wp = wp; c.hp = hp;
@@ -536,6 +538,7 @@ static int ensure_ctx_v2(Ctx& c, int w, int h) {
     A_(c.e0a, P / 4 * 32) A_(c.e0b, P / 4 * 32) A_(c.e0c, P / 16 * 64) A_(c.B1, P / 16 * 128) A_(c.e1a, P / 64 * 128) A_(c.B2, P / 64 * 256)
     A_(c.e2a, P / 256 * 256) A_(c.B3, P / 256 * 512) A_(c.e3a, P / 1024 * 512) A_(c.B4, P / 1024 * 1024)
     A_(c.U0, P / 256 * 512) A_(c.U1, P / 64 * 256) A_(c.U2, P / 16 * 128) A_(c.U3, P / 4 * 32)
+    if (uhd) { A_(c.h0, P / 4) A_(c.h1, P / 4) A_(c.acc_s, P / 16) }
 #undef A_
     return 0;
 }
@@ -546,29 +549,23 @@ static int conv_t(const rife_hip& E, const ConvLayer& L, TensorView x, int H, in
     return launch_conv(L, x, H, W, y, nullptr, st);
 }
 
-static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t* d_in1, uint8_t* d_out) {
+// IFNet of rife-v2.x on frames of wp x hp (flownet.param): 4 blocks at scales 8,4,2,1; the flow is accumulated at
+// half of that resolution into `acc` (float4 per pixel).
+template <typename IMG>
+static int run_v2_ifnet(const rife_hip& E, Ctx& c, IMG img0, IMG img1, int wp, int hp, float4* acc) {
     hipStream_t st = c.stream;
-    const int wp = c.wp, hp = c.hp;
-    int rc;
-    {
-        Timed t(E.prof, "preproc", 0, st);
-        dim3 g = grid2d(wp, hp);
-        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.img0, wp, hp);
-        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.img1, wp, hp);
-        HIPCHK(hipGetLastError());
-    }
-    // ---- IFNet (flownet.param): 4 blocks at scales 8,4,2,1; flow accumulated at half resolution ----
     const int wh = wp / 2, hh = hp / 2;
+    int rc;
     for (int b = 0; b < 4; b++) {
         const rife_hip::V2Block& B = E.fblk[b];
         const int s = B.scale, Hb = hp / s, Wb = wp / s;
         {
             Timed t(E.prof, "v2_assemble", 0, st);
             dim3 g = grid2d(Wb, Hb);
-            if (b == 0) hipLaunchKernelGGL(k2_assemble0, g, dim3(256), 0, st, c.img0, c.img1, c.X, wp, hp);
-            else if (s == 4) hipLaunchKernelGGL(k2_assemble<4>, g, dim3(256), 0, st, c.img0, c.img1, c.acc, c.X, wp, hp);
-            else if (s == 2) hipLaunchKernelGGL(k2_assemble<2>, g, dim3(256), 0, st, c.img0, c.img1, c.acc, c.X, wp, hp);
-            else hipLaunchKernelGGL(k2_assemble<1>, g, dim3(256), 0, st, c.img0, c.img1, c.acc, c.X, wp, hp);
+            if (b == 0) hipLaunchKernelGGL(k2_assemble0<IMG>, g, dim3(256), 0, st, img0, img1, c.X, wp, hp);
+            else if (s == 4) hipLaunchKernelGGL((k2_assemble<4, IMG>), g, dim3(256), 0, st, img0, img1, acc, c.X, wp, hp);
+            else if (s == 2) hipLaunchKernelGGL((k2_assemble<2, IMG>), g, dim3(256), 0, st, img0, img1, acc, c.X, wp, hp);
+            else hipLaunchKernelGGL((k2_assemble<1, IMG>), g, dim3(256), 0, st, img0, img1, acc, c.X, wp, hp);
             HIPCHK(hipGetLastError());
         }
         if ((rc = conv_t(E, B.stem0, {c.X, b == 0 ? 8 : 16, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, st))) return rc;
@@ -583,13 +580,43 @@ static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
         {
             Timed t(E.prof, "v2_flow_accum", 0, st);
             dim3 g = grid2d(wh, hh);
-            if (b == 0) hipLaunchKernelGGL((k2_flow_accum<8, true>), g, dim3(256), 0, st, c.D, c.acc, wh, hh);
-            else if (b == 1) hipLaunchKernelGGL((k2_flow_accum<4, false>), g, dim3(256), 0, st, c.D, c.acc, wh, hh);
-            else if (b == 2) hipLaunchKernelGGL((k2_flow_accum<2, false>), g, dim3(256), 0, st, c.D, c.acc, wh, hh);
-            else hipLaunchKernelGGL((k2_flow_accum<1, false>), g, dim3(256), 0, st, c.D, c.acc, wh, hh);
+            if (b == 0) hipLaunchKernelGGL((k2_flow_accum<8, true>), g, dim3(256), 0, st, c.D, acc, wh, hh);
+            else if (b == 1) hipLaunchKernelGGL((k2_flow_accum<4, false>), g, dim3(256), 0, st, c.D, acc, wh, hh);
+            else if (b == 2) hipLaunchKernelGGL((k2_flow_accum<2, false>), g, dim3(256), 0, st, c.D, acc, wh, hh);
+            else hipLaunchKernelGGL((k2_flow_accum<1, false>), g, dim3(256), 0, st, c.D, acc, wh, hh);
             HIPCHK(hipGetLastError());
         }
     }
+    return 0;
+}
+
+static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t* d_in1, uint8_t* d_out) {
+    hipStream_t st = c.stream;
+    const int wp = c.wp, hp = c.hp;
+    int rc;
+    {
+        Timed t(E.prof, "preproc", 0, st);
+        dim3 g = grid2d(wp, hp);
+        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.img0, wp, hp);
+        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.img1, wp, hp);
+        HIPCHK(hipGetLastError());
+    }
+    // ---- IFNet (flownet.param); UHD mode estimates the flow on half-resolution frames (rife.cpp:928-945) ----
+    const int wh = wp / 2, hh = hp / 2;
+    if (E.uhd) {
+        {
+            Timed t(E.prof, "v2_uhd_resample", 0, st);
+            hipLaunchKernelGGL(k2_image_half, grid2d(wh, hh), dim3(256), 0, st, c.img0, c.h0, wp, hp);
+            hipLaunchKernelGGL(k2_image_half, grid2d(wh, hh), dim3(256), 0, st, c.img1, c.h1, wp, hp);
+            HIPCHK(hipGetLastError());
+        }
+        if ((rc = run_v2_ifnet(E, c, ImgF4{c.h0}, ImgF4{c.h1}, wh, hh, c.acc_s))) return rc;
+        {
+            Timed t(E.prof, "v2_uhd_resample", 0, st);
+            hipLaunchKernelGGL(k2_flow_up2_double, grid2d(wh, hh), dim3(256), 0, st, c.acc_s, c.acc, wh, hh);
+            HIPCHK(hipGetLastError());
+        }
+    } else if ((rc = run_v2_ifnet(E, c, ImgU8{c.img0}, ImgU8{c.img1}, wp, hp, c.acc))) return rc;
     // ---- ContextNet twice (contextnet.param): (img0, flow[0:2]) -> "3".."6", (img1, flow[2:4]) -> "7".."10",
     //      each warped level written straight into its slice of the FusionNet concat buffers ----
     float* cat_buf[4] = {c.B1, c.B2, c.B3, c.B4};
@@ -627,7 +654,7 @@ static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     // ---- FusionNet (fusionnet.param) ----
     {
         Timed t(E.prof, "v2_assemble", 0, st);
-        hipLaunchKernelGGL(k2_assemble<1>, grid2d(wp, hp), dim3(256), 0, st, c.img0, c.img1, c.acc, c.X, wp, hp);
+        hipLaunchKernelGGL((k2_assemble<1, ImgU8>), grid2d(wp, hp), dim3(256), 0, st, ImgU8{c.img0}, ImgU8{c.img1}, c.acc, c.X, wp, hp);
         HIPCHK(hipGetLastError());
     }
     auto copy_view = [&](const float* src, int sld, int soff, float* dst, int dld, int doff, int C, size_t npix) {
@@ -771,7 +798,6 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {
     if ((rc = check_device(E->gpuid))) return rc;
     if (E->v2 && !E->v4) {
         if (E->tta || E->tta_temporal) return fail(RIFE_HIP_ENOSYS, "TTA is implemented for the rife-v4 family only");
-        if (E->uhd) return fail(RIFE_HIP_ENOSYS, "UHD mode (-u) is not implemented on the HIP path yet");
         if ((rc = load_v2(E, modeldir))) return rc;
         E->loaded = true;
         return 0;
@@ -829,6 +855,8 @@ static int process_common(const rife_hip* E, int w, int h, float timestep) {
     if (!E->loaded) return fail(RIFE_HIP_EINVAL, "process() before load()");
     if (w <= 0 || h <= 0) return fail(RIFE_HIP_EINVAL, "bad frame size");
     (void)timestep;
+    if (E->uhd && !E->v4 && (((w + 31) / 32 * 32 / 2) % 32 || ((h + 31) / 32 * 32 / 2) % 32))
+        return fail(RIFE_HIP_EINVAL, "UHD mode needs a padded frame whose half size is a multiple of 32 (the reference's graph mis-sizes otherwise)");
     return 0;
 }
 
@@ -851,7 +879,7 @@ int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
         c->own_stream = true;
     }
-    rc = E->v4 ? ensure_ctx(*c, w, h) : ensure_ctx_v2(*c, w, h);
+    rc = E->v4 ? ensure_ctx(*c, w, h) : ensure_ctx_v2(*c, w, h, E->uhd);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(c->d_in0, in0, nbytes, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->d_in1, in1, nbytes, hipMemcpyHostToDevice, c->stream);
@@ -900,7 +928,7 @@ int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* 
         HIPCHK(hipMemcpyAsync(d_out, timestep == 0.f ? d_in0 : d_in1, nbytes, hipMemcpyDeviceToDevice, c->stream));
     } else {
         if (!E->v4) {
-            if ((rc = ensure_ctx_v2(*c, w, h))) return rc;
+            if ((rc = ensure_ctx_v2(*c, w, h, E->uhd))) return rc;
             if ((rc = run_v2(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, (uint8_t*)d_out))) return rc;
         } else if (E->tta || E->tta_temporal) {
             // the TTA workspaces are shared: serialise, and drain before another stream may reuse them

@@ -57,3 +57,24 @@ def test_v23_rejects_v4_graph(modeldirs):
     g = amd.RIFE(0, rife_v2=True)
     with pytest.raises(amd.RifeError):
         g.load(modeldirs["rife-v4.6"])
+
+
+@pytest.mark.parametrize("w,h", [(128, 64), (320, 192)])
+def test_v23_uhd_mode_within_1_lsb(modeldirs, w, h):
+    """-u: flow estimated on half-resolution frames, upsampled x2 and doubled (rife.cpp:294-332, 928-945)."""
+    d = modeldirs["rife-v2.3"]
+    g = amd.RIFE(0, uhd_mode=True, rife_v2=True); g.load(d)
+    o = pyoracle.OracleRIFE(uhd_mode=True, rife_v2=True); o.set_gpu_crop(1); o.load(d)
+    a, b = gen_frames.smooth_pair(w, h, 77)
+    got, want = g.process(a, b, 0.5), o.process(a, b, 0.5)
+    mx, f0 = report(got, want)
+    assert mx <= 1, (mx, f0)
+    plain = amd.RIFE(0, rife_v2=True); plain.load(d)
+    assert not np.array_equal(got, plain.process(a, b, 0.5))     # the mode really changes the computation
+
+
+def test_v23_uhd_rejects_unsupported_size(modeldirs):
+    g = amd.RIFE(0, uhd_mode=True, rife_v2=True); g.load(modeldirs["rife-v2.3"])
+    a, b = gen_frames.smooth_pair(96, 64, 1)        # padded 96 -> half 48, not a multiple of 32
+    with pytest.raises(amd.RifeError):
+        g.process(a, b, 0.5)
