@@ -22,10 +22,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {"4k": (3840, 2160), "1080p": (1920, 1080)}
+# name -> (model family, w, h, GFLOP per pair [SURVEY.md §8(d) / App. E: 2 x MAC over Convolution + Deconvolution],
+#          fused-minimum HBM roofline ms per pair [SURVEY §8(d); None where the survey gives none], tta, tta_temporal)
+WORKLOADS = {
+    "4k": ("rife-v4.6", 3840, 2160, 701.0, 0.701, False, False),          # BASELINE config 4 on one GPU (-u is a no-op for v4)
+    "1080p": ("rife-v4.6", 1920, 1080, 175.2, 0.176, False, False),       # BASELINE config 3
+    "v23-1080p": ("rife-v2.3", 1920, 1080, 597.5, None, False, False),    # BASELINE config 2
+    "4k-tta": ("rife-v4.6", 3840, 2160, 16 * 701.0, 16 * 0.701, True, True),   # BASELINE config 5 (-x -z) on one GPU
+}
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense v_mfma_f32_32x32x2_f32 peak
-V46_GFLOP_PER_PAIR = {"4k": 701.0, "1080p": 175.2}   # 2 x MAC over Convolution + Deconvolution
-ROOFLINE_MS = {"4k": 0.701, "1080p": 0.176}           # SURVEY.md §8(d) fused-minimum HBM roofline per pair
+DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_mfma_kernel<1,2,2,16,0,3> (IFNet block-3 trunk: 3x3 conv 64->64, skip folded, LeakyReLU)"),
+            "rife-v2.3": ("v2_flow_trunk_b3", "conv_mfma_kernel<1,2,3,8,0,0> (IFNet block-3 trunk: 3x3 conv 96->96 + PReLU)")}
 
 
 def main():
@@ -53,13 +60,13 @@ def main():
 
     amd = importlib.import_module("rife-ncnn-vulkan_amd")
     from tools import gen_frames, gen_models
-    modeldir = gen_models.ensure(None, "rife-v4.6")
+    family, w, h, gflop_pair, roofline_ms, tta, tta_temporal = WORKLOADS[args.workload]
+    modeldir = gen_models.ensure(None, family)
     if dist is not None:
         dist.barrier()
-    eng = amd.RIFE(local, rife_v4=True)
+    eng = amd.RIFE(local, tta_mode=tta, tta_temporal_mode=tta_temporal, rife_v2=family.startswith("rife-v2"), rife_v4=family.startswith("rife-v4"))
     eng.load(modeldir)
 
-    w, h = WORKLOADS[args.workload]
     # a short synthetic stream of distinct pairs, resident in HBM (consecutive pairs share a frame like a video)
     nfr = 4
     base = gen_frames.smooth_pair(w // 4, h // 4, 1000 + rank)
@@ -88,33 +95,34 @@ def main():
     eng.profile_enable(False)
 
     if rank == 0:
-        # dominant kernel: the block-3 residual trunk conv (64->64 3x3 at 1/4 resolution, 8 launches per pair)
-        dom = prof.get("trunk_b3", dict(ms=0.0, launches=0, flops=0.0))
+        # dominant kernel: the block-3 trunk conv of the IFNet (one shape per class, so flops per launch are well defined)
+        dom_cls, dom_name = DOMINANT[family]
+        dom = prof.get(dom_cls, dict(ms=0.0, launches=0, flops=0.0))
         conv_ms = sum(v["ms"] for k, v in prof.items() if v["flops"] > 0)
         all_ms = sum(v["ms"] for v in prof.values())
         roof = None
         if dom["launches"]:
             avg_ms = dom["ms"] / dom["launches"]
             ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<1,2,2,16,0> (trunk_b3: 3x3 conv 64->64 + residual + LeakyReLU)",
+            roof = {"bound": "mfma", "kernel": dom_name,
                     "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "flops_per_launch": dom["flops"] / dom["launches"]}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(modeldir, args.workload)
+            cpu = cpu_baseline(modeldir, family, w * h, 16 if tta and tta_temporal else 1)
         fps = world * args.steps / elapsed
         line = {
-            "metric": "interpolated frames/sec (rife-v4.6, %dx%d)" % (w, h), "value": round(fps, 3), "unit": "frames/s",
+            "metric": "interpolated frames/sec (%s, %dx%d%s)" % (family, w, h, " -x -z" if tta else ""), "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "rife-v4.6 %dx%d frame pairs resident in HBM, timestep sweep %s, synthetic seeded weights" % (w, h, timesteps),
+            "config": {"workload": "%s %dx%d%s frame pairs resident in HBM, timestep sweep %s, synthetic seeded weights" % (family, w, h, " -x -z (TTA)" if tta else "", timesteps),
                        "pairs_in_flight_per_gpu": nstreams, "parallelism": "frame pairs sharded over ranks, no data-path collective"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "extra": {"kernel_ms_per_pair": round(all_ms / args.steps, 4), "conv_ms_per_pair": round(conv_ms / args.steps, 4),
-                      "conv_tflops_overall": round(V46_GFLOP_PER_PAIR[args.workload] / max(conv_ms / args.steps, 1e-9), 2),
-                      "frac_of_fused_hbm_roofline_e2e": round(ROOFLINE_MS[args.workload] / (elapsed / args.steps * 1e3 / 1.0), 5),
+                      "conv_tflops_overall": round(gflop_pair / max(conv_ms / args.steps, 1e-9), 2),
+                      "frac_of_fused_hbm_roofline_e2e": None if roofline_ms is None else round(roofline_ms / (elapsed / args.steps * 1e3), 5),
                       "per_class_ms_per_pair": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}},
         }
         print(json.dumps(line))
@@ -123,22 +131,22 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(modeldir, workload):
+def cpu_baseline(modeldir, family, pixels, passes):
     """The reference's `-g -1` path cannot be built here (ncnn/Vulkan absent), so the CPU leg is the oracle
-    (kind "port"), timed on a bounded sample: one 1920x1080 pair; for the 4K workload the result is scaled by
-    the pixel ratio (the work is linear in pixels)."""
+    (kind "port"), timed on a bounded sample: one plain 1920x1080 pair of the same model; the result is scaled by the
+    pixel ratio (and x16 passes for -x -z): the work is linear in both."""
     from oracle import pyoracle
     from tools import gen_frames
     cores = min(len(os.sched_getaffinity(0)), 64)
-    o = pyoracle.OracleRIFE(rife_v4=True, num_threads=cores)
+    o = pyoracle.OracleRIFE(rife_v2=family.startswith("rife-v2"), rife_v4=family.startswith("rife-v4"), num_threads=cores)
     o.load(modeldir)
     a, b = gen_frames.smooth_pair(1920, 1080, 1000)
     t0 = time.perf_counter()
     o.process(a, b, 0.5)
     dt = time.perf_counter() - t0
-    scale = {"1080p": 1.0, "4k": 4.0}[workload]
+    scale = pixels / float(1920 * 1080) * passes
     return {"value": round(1.0 / (dt * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "1 pair at 1920x1080 in %.2f s with %d OpenMP threads%s" % (dt, cores, "" if scale == 1.0 else "; scaled x1/4 to 3840x2160 (work is linear in pixels)")}
+            "sample": "1 plain %s pair at 1920x1080 in %.2f s with %d OpenMP threads; scaled by x%.3g (pixels x TTA passes, work is linear in both)" % (family, dt, cores, 1.0 / scale)}
 
 
 if __name__ == "__main__":

@@ -50,6 +50,8 @@ struct ConvLayer {
     int MS = 2, NS = 2, CC = 16;          // kernel configuration
     int ntiles = 1, nchunks = 1, ntaps = 9, npar = 1;
     float *d_w = nullptr, *d_bias = nullptr, *d_slope = nullptr;
+    float* d_w8 = nullptr;                // weights packed with CC = 8 for conv_mfma8_kernel (stride-1 3x3 layers only)
+    int nchunks8 = 0;
     double flops_per_pixel = 0;           // algorithmic: 2 * MAC per GEMM-M pixel
     std::string cls;                      // profile class
     int tag = 0;                          // distinct kernel symbol for the profiled layer class
@@ -59,7 +61,8 @@ static void free_layer(ConvLayer& L) {
     if (L.d_w) (void)hipFree(L.d_w);
     if (L.d_bias) (void)hipFree(L.d_bias);
     if (L.d_slope) (void)hipFree(L.d_slope);
-    L.d_w = L.d_bias = L.d_slope = nullptr;
+    if (L.d_w8) (void)hipFree(L.d_w8);
+    L.d_w = L.d_bias = L.d_slope = L.d_w8 = nullptr;
 }
 
 // Choose the kernel configuration for a layer (see conv_mfma.h for the meaning of MS / NS / CC).
@@ -117,6 +120,16 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
     HIPCHK(hipMemcpy(L.d_slope, s.data(), cp * 4, hipMemcpyHostToDevice));
     const int K = L.deconv ? 16 : 9;
     L.flops_per_pixel = 2.0 * L.cin * L.cout * K;
+    if (!L.deconv && L.stride == 1 && L.epi == EPI_STORE && L.NS >= 2 && L.cin % 8 == 0) {
+        if (L.CC == 8) { L.d_w8 = nullptr; L.nchunks8 = L.nchunks; }     // the normal packing already is CC = 8
+        else {
+            ConvLayer T = L; T.CC = 8; T.cin_p = L.cin; T.nchunks = L.cin / 8;
+            std::vector<float> pk8 = pack_weights(T, w);
+            HIPCHK(hipMalloc(&L.d_w8, pk8.size() * 4));
+            HIPCHK(hipMemcpy(L.d_w8, pk8.data(), pk8.size() * 4, hipMemcpyHostToDevice));
+            L.nchunks8 = T.nchunks;
+        }
+    }
     return 0;
 }
 
@@ -134,6 +147,9 @@ static hipError_t launch_cfg(const ConvArgs& a, int nblocks, hipStream_t st) {
 
 struct TensorView { float* p; int ld, coff; };
 
+// RIFE_HIP_CONV8=0 disables the 8-wave trunk kernel (A/B measurements)
+static const bool g_use_conv8 = []() { const char* e = getenv("RIFE_HIP_CONV8"); return !(e && e[0] == '0'); }();
+
 // x: NHWC input (H x W), y: output; for deconv layers y has 2H x 2W pixels (or the 4H x 4W flow tensor with EPI_DECONV_PS).
 static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorView y, const TensorView* res, hipStream_t st) {
     ConvArgs a;
@@ -145,12 +161,43 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
     a.Wo = L.deconv ? W : (W + 2 - 3) / L.stride + 1;
     a.Cout = L.cout; a.nchunks = L.nchunks; a.nz = L.ntiles * L.npar;
     if (x.ld % 4 || x.coff % 4 || x.ld - x.coff < L.cin_p) return fail(RIFE_HIP_EINVAL, "conv input view is not padded to the channel chunk");
+    if (L.epi != EPI_DECONV_PS && (y.ld % 4 || y.coff % 4 || L.cout % 4 || (res && (res->ld % 4 || res->coff % 4))))
+        return fail(RIFE_HIP_EINVAL, "conv output / residual views must be 16-byte aligned per pixel (channel counts multiples of 4)");
     a.tiles_x = (a.Wo + 31) / 32;
     // rows per wave: 2 when that still gives every CU >= 1.5 workgroups, else 1 (more, smaller workgroups for the coarse blocks)
     int MS = L.MS;
     if (L.stride == 1) {
         const long wg2 = (long)a.tiles_x * ((a.Ho + 7) / 8) * a.nz;
         MS = wg2 >= 384 ? 2 : 1;
+    }
+    // layers with >= 2 full waves of 8-row tiles take the double-buffered 8-wave kernel
+    if (L.nchunks8 > 0 && g_use_conv8) {
+        const long wg8 = (long)a.tiles_x * ((a.Ho + 7) / 8) * a.nz;
+        if (wg8 >= 448) {
+            a.ntiles_xy = a.tiles_x * ((a.Ho + 7) / 8);
+            a.nchunks = L.nchunks8;
+            if (L.d_w8) a.wpk = L.d_w8;
+            const int nb = a.ntiles_xy * a.nz;
+            constexpr int lds28 = conv8_lds_bytes<2, 8>(), lds38 = conv8_lds_bytes<3, 8>();
+            static_assert(lds28 <= 80 * 1024 && lds38 <= 160 * 1024, "LDS budget");
+            {   // > 64 KB of dynamic LDS needs an opt-in per kernel and device
+                static std::mutex amu; static std::map<int, bool> done;
+                int dev = 0; (void)hipGetDevice(&dev);
+                std::lock_guard<std::mutex> g(amu);
+                if (!done[dev]) {
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma8_kernel<2, 8, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds28));
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma8_kernel<2, 8, 4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds28));
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma8_kernel<3, 8, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds38));
+                    done[dev] = true;
+                }
+            }
+            if (L.NS == 2 && L.tag == 3) hipLaunchKernelGGL((conv_mfma8_kernel<2, 8, 4, 3>), dim3(nb), dim3(512), lds28, st, a);
+            else if (L.NS == 2) hipLaunchKernelGGL((conv_mfma8_kernel<2, 8, 4, 0>), dim3(nb), dim3(512), lds28, st, a);
+            else hipLaunchKernelGGL((conv_mfma8_kernel<3, 8, 2, 0>), dim3(nb), dim3(512), lds38, st, a);
+            hipError_t e8 = hipGetLastError();
+            if (e8 != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv8 launch: ") + hipGetErrorString(e8));
+            return 0;
+        }
     }
     a.ntiles_xy = a.tiles_x * ((a.Ho + 4 * MS - 1) / (4 * MS));
     const int nblocks = a.ntiles_xy * a.nz;
@@ -1072,6 +1119,48 @@ int rife_hip_op_warp(int gpuid, const float* image, const float* flow, int c, in
     (void)hipFree(d_i); (void)hipFree(d_f); (void)hipFree(d_o);
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("op_warp: ") + hipGetErrorString(e));
     return 0;
+}
+
+// bench-only: time the 8-wave trunk kernel on a synthetic (h x w x c) -> c layer; variant bits: 256 no stores,
+// 512 no global loads after chunk 1, 1024 no barriers (the last two compute garbage; timing ablations only)
+int rife_hip_bench_conv8(int gpuid, int c, int h, int w, int variant, int iters, float* ms_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    if (c != 64) return fail(RIFE_HIP_EINVAL, "bench supports c = 64");
+    std::vector<float> wts((size_t)c * c * 9, 0.01f), bias(c, 0.f);
+    ConvLayer L; L.cin = c; L.cout = c; L.stride = 1; L.epi = EPI_STORE;
+    if ((rc = upload_layer(L, wts.data(), bias.data(), nullptr, 0.2f))) return rc;
+    float *x = nullptr, *y = nullptr;
+    HIPCHK(hipMalloc(&x, (size_t)h * w * c * 4)); HIPCHK(hipMalloc(&y, (size_t)h * w * c * 4));
+    HIPCHK(hipMemset(x, 0, (size_t)h * w * c * 4));
+    ConvArgs a;
+    a.in = x; a.in_ld = c; a.in_coff = 0; a.H = h; a.W = w; a.out = y; a.out_ld = c; a.out_coff = 0;
+    a.wpk = L.d_w8; a.bias = L.d_bias; a.slope = L.d_slope; a.res = nullptr; a.res_ld = 0; a.res_coff = 0;
+    a.Ho = h; a.Wo = w; a.Cout = c; a.nchunks = L.nchunks8; a.nz = 1; a.tiles_x = (w + 31) / 32; a.ntiles_xy = a.tiles_x * ((h + 7) / 8);
+    constexpr int lds = conv8_lds_bytes<2, 8>();
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](auto kfn) -> int {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(a.ntiles_xy), dim3(512), lds, 0, a);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kfn, dim3(a.ntiles_xy), dim3(512), lds, 0, a);
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    switch (variant) {
+        case 0: rc = run(conv_mfma8_kernel<2, 8, 4, 4096>); break;
+        case 256: rc = run(conv_mfma8_kernel<2, 8, 4, 4096 + 256>); break;
+        case 512: rc = run(conv_mfma8_kernel<2, 8, 4, 4096 + 512>); break;
+        case 1024: rc = run(conv_mfma8_kernel<2, 8, 4, 4096 + 1024>); break;
+        case 768: rc = run(conv_mfma8_kernel<2, 8, 4, 4096 + 768>); break;
+        case 1792: rc = run(conv_mfma8_kernel<2, 8, 4, 4096 + 1792>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    (void)hipFree(x); (void)hipFree(y); free_layer(L);
+    return rc;
 }
 
 // tooling: structural hash of a named blob of a .param file (used to derive / test the compiled-in constants)
