@@ -385,4 +385,171 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// conv_h2_kernel: trunk 3x3 stride-1 convolution on the f16 matrix pipe at fp32 accuracy ("split-f16").
+//   * weights are fp16 on disk (ncnn tag 0x01306B47), so they enter the MFMA exactly;
+//   * every fp32 activation a is split while it is staged into LDS:  hi = f16(a),  lo = f16((a - hi) * 2048)
+//     => a == hi + lo/2048 up to 2^-22 relative; below the f16 normal range (|a| < 6.2e-5) hi is forced to 0 so that no
+//     f16 denormal ever reaches the matrix pipe, and a is carried by lo alone: absolute error <= 1.5e-8 there;
+//   * two v_mfma_f32_32x32x16_f16 per 16-channel k-step accumulate W*hi and W*lo in separate fp32 accumulators;
+//     the epilogue forms acc_hi + acc_lo/2048 + bias.  Products are exact in fp32 (11 x 11 bit significands), so the
+//     result differs from the fp32 kernel only by summation order.
+//   * optional tap 9 = centre pixel with identity weights: the residual skip (x + conv(x)) inside the GEMM.
+//   One k-step covers 16 channels: lanes 0-31 supply channels 0-7, lanes 32-63 channels 8-15 (8 f16 = 16 B per lane).
+//   LDS pixel record = 32 B hi + 32 B lo + 16 B pad (80 B = 5 slots: conflict-free ds_read_b128 columns).
+//   8 waves, tile 8 rows x 32 columns x 32*NS channels, chunk = 16 channels, two LDS buffers, loads issued two
+//   chunks ahead into two alternating register sets (the matrix work per chunk is only ~1 us).
+// ------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int NS, int NTAPS>
+constexpr int convh2_lds_bytes() { return 2 * (10 * 34 * 80 + NTAPS * 2 * NS * 32 * 16); }
+
+template <int NS, int NTAPS, int TAG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h2_kernel(ConvArgs a) {
+    constexpr int IH = 10, IW = 34, CC = 16, NT = NS * 32;
+    constexpr int PIXB = 80;                                   // bytes per pixel record in LDS
+    constexpr int IN_F4 = IH * IW * 4;                         // float4 (4-channel) slots of one input chunk tile
+    constexpr int W_16 = NTAPS * 2 * NT;                       // 16-byte units of one weight chunk slab
+    constexpr int NIN = (IN_F4 + 511) / 512, NW = (W_16 + 511) / 512;
+    constexpr int BUFB = IH * IW * PIXB + W_16 * 16;           // bytes per LDS buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int half = lane >> 5, li = lane & 31;
+    int L;
+    {
+        const int n = gridDim.x, b = blockIdx.x;
+        const int q = n >> 3, r = n & 7, xcd = b & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int tile = L / a.nz, ntile = L - tile * a.nz;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * 8, ox0 = tx * 32;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+
+    int goff[NIN];
+    unsigned inside = 0;
+#pragma unroll
+    for (int k = 0; k < NIN; k++) {
+        const int idx = tid + k * 512;
+        const int p = idx >> 2, q = idx & 3;
+        const int py = p / IW, px = p - py * IW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        const bool ok = idx < IN_F4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        goff[k] = ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff;
+        inside |= ok ? (1u << k) : 0u;
+    }
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk) + (size_t)ntile * a.nchunks * W_16;   // 16-byte units (8 f16)
+
+    f32x4 rinA[NIN], rinB[NIN], rwA[NW], rwB[NW];
+#define H2_ISSUE(RIN, RW, CH)                                                                               \
+    {                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < NIN; k++)                                                     \
+            RIN[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC);                           \
+        _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                    \
+            const int idx = tid + k * 512;                                                                  \
+            RW[k] = wsrc[(size_t)(CH) * W_16 + ((W_16 % 512 == 0 || idx < W_16) ? idx : 0)];                \
+        }                                                                                                   \
+    }
+#define H2_WRITE(RIN, RW, BUFP)                                                                             \
+    {                                                                                                       \
+        unsigned char* lin_ = (BUFP); unsigned char* lw_ = (BUFP) + IH * IW * PIXB;                         \
+        _Pragma("unroll") for (int k = 0; k < NIN; k++) {                                                   \
+            const int idx = tid + k * 512;                                                                  \
+            const int p = idx >> 2, q = idx & 3;                                                            \
+            f16x4 hi4, lo4;                                                                                 \
+            _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                 \
+                const float v = ((inside >> k) & 1u) ? RIN[k][e] : 0.f;                                     \
+                const _Float16 h = __builtin_fabsf(v) < 6.2e-5f ? (_Float16)0.f : (_Float16)v;              \
+                hi4[e] = h;                                                                                 \
+                lo4[e] = (_Float16)((v - (float)h) * 2048.f);                                               \
+            }                                                                                               \
+            if (IN_F4 % 512 == 0 || idx < IN_F4) {                                                          \
+                *reinterpret_cast<f16x4*>(lin_ + p * PIXB + q * 8) = hi4;                                   \
+                *reinterpret_cast<f16x4*>(lin_ + p * PIXB + 32 + q * 8) = lo4;                              \
+            }                                                                                               \
+        }                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                    \
+            const int idx = tid + k * 512;                                                                  \
+            if (W_16 % 512 == 0 || idx < W_16) reinterpret_cast<f32x4*>(lw_)[idx] = RW[k];                  \
+        }                                                                                                   \
+    }
+#define H2_TAPS(BUFP, T0, T1)                                                                               \
+    {                                                                                                       \
+        const unsigned char* ab_ = (BUFP) + (wv * IW + li) * PIXB + half * 16;                              \
+        const unsigned char* bb_ = (BUFP) + IH * IW * PIXB + (half * NT + li) * 16;                         \
+        _Pragma("unroll") for (int t = (T0); t < (T1); t++) {                                               \
+            const int dy = t == 9 ? 1 : t / 3, dx = t == 9 ? 1 : t % 3;                                     \
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(ab_ + (dy * IW + dx) * PIXB);                  \
+            const f16x8 al = *reinterpret_cast<const f16x8*>(ab_ + (dy * IW + dx) * PIXB + 32);             \
+            _Pragma("unroll") for (int n = 0; n < NS; n++) {                                                \
+                const f16x8 bw = *reinterpret_cast<const f16x8*>(bb_ + (t * 2 * NT + n * 32) * 16);         \
+                acch[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, ah, acch[n], 0, 0, 0);                 \
+                accl[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, al, accl[n], 0, 0, 0);                 \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+
+    f32x16 acch[NS], accl[NS];
+#pragma unroll
+    for (int n = 0; n < NS; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acch[n][r] = 0.f; accl[n][r] = 0.f; }
+
+    const int nch = a.nchunks;
+    unsigned char* buf0 = ldsb; unsigned char* buf1 = ldsb + BUFB;
+    H2_ISSUE(rinA, rwA, 0)
+    if (nch > 1) H2_ISSUE(rinB, rwB, 1)
+    H2_WRITE(rinA, rwA, buf0)
+    if (nch > 2) H2_ISSUE(rinA, rwA, 2)
+    __syncthreads();
+    // two chunks per trip so that the register sets are named statically: even chunks live in A / buf0, odd in B / buf1
+    for (int ch = 0; ch < nch; ch += 2) {
+        // chunk ch (buf0); registers B hold chunk ch+1, registers A hold chunk ch+2 (in flight)
+        H2_TAPS(buf0, 0, NTAPS / 2)
+        if (ch + 1 < nch) H2_WRITE(rinB, rwB, buf1)
+        if (ch + 3 < nch) H2_ISSUE(rinB, rwB, ch + 3)
+        H2_TAPS(buf0, NTAPS / 2, NTAPS)
+        __syncthreads();
+        if (ch + 1 < nch) {
+            // chunk ch+1 (buf1); registers A hold chunk ch+2, registers B hold chunk ch+3 (in flight)
+            H2_TAPS(buf1, 0, NTAPS / 2)
+            if (ch + 2 < nch) H2_WRITE(rinA, rwA, buf0)
+            if (ch + 4 < nch) H2_ISSUE(rinA, rwA, ch + 4)
+            H2_TAPS(buf1, NTAPS / 2, NTAPS)
+            __syncthreads();
+        }
+    }
+#undef H2_ISSUE
+#undef H2_WRITE
+#undef H2_TAPS
+
+    const int oy = oy0 + wv, ox = ox0 + li;
+    const bool pok = oy < a.Ho && ox < a.Wo;
+#pragma unroll
+    for (int n = 0; n < NS; n++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c0 = ntile * NT + n * 32 + 8 * q + 4 * half;
+            const bool ok = pok && c0 < a.Cout;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = (acch[n][4 * q + k] + accl[n][4 * q + k] * (1.f / 2048.f)) + b4[k];
+            if (a.res != nullptr) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(a.res + (ok ? ((size_t)oy * a.Wo + ox) * a.res_ld + a.res_coff + c0 : 0));
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] += r4[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k];
+            if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
+        }
+    }
+}
+
 }  // namespace rife

@@ -52,6 +52,9 @@ struct ConvLayer {
     float *d_w = nullptr, *d_bias = nullptr, *d_slope = nullptr;
     float* d_w8 = nullptr;                // weights packed with CC = 8 for conv_mfma8_kernel (stride-1 3x3 layers only)
     int nchunks8 = 0;
+    uint16_t* d_wh = nullptr;             // fp16 weights packed for conv_h2_kernel (split-f16 trunk path)
+    int nchunksh = 0;
+    bool skip = false;                    // layer is x + conv(x): identity folded into the GEMM
     double flops_per_pixel = 0;           // algorithmic: 2 * MAC per GEMM-M pixel
     std::string cls;                      // profile class
     int tag = 0;                          // distinct kernel symbol for the profiled layer class
@@ -62,7 +65,8 @@ static void free_layer(ConvLayer& L) {
     if (L.d_bias) (void)hipFree(L.d_bias);
     if (L.d_slope) (void)hipFree(L.d_slope);
     if (L.d_w8) (void)hipFree(L.d_w8);
-    L.d_w = L.d_bias = L.d_slope = L.d_w8 = nullptr;
+    if (L.d_wh) (void)hipFree(L.d_wh);
+    L.d_w = L.d_bias = L.d_slope = L.d_w8 = nullptr; L.d_wh = nullptr;
 }
 
 // Choose the kernel configuration for a layer (see conv_mfma.h for the meaning of MS / NS / CC).
@@ -106,8 +110,62 @@ static std::vector<float> pack_weights(const ConvLayer& L, const float* w) {
     return out;
 }
 
+static uint16_t f2h(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+    uint32_t m = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0));
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int sh = 14 - e;
+        uint32_t r = m >> sh;
+        const uint32_t rem = m & ((1u << sh) - 1), halfway = 1u << (sh - 1);
+        if (rem > halfway || (rem == halfway && (r & 1))) r++;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((uint32_t)e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) r++;
+    return (uint16_t)(sign | r);
+}
+
+// fp16 B... A-fragment order of conv_h2_kernel: [ntile][chunk of 16 ch][tap][half][n][8], channel = chunk*16 + half*8 + e;
+// tap 9 (only when the layer carries a skip connection) = identity on the centre pixel.
+static std::vector<uint16_t> pack_weights_h2(const ConvLayer& L, const float* w, int ntaps) {
+    const int NT = L.NS * 32, nch = L.cin / 16;
+    std::vector<uint16_t> out((size_t)L.ntiles * nch * ntaps * 2 * NT * 8, 0);
+    size_t o = 0;
+    for (int nt = 0; nt < L.ntiles; nt++)
+        for (int ch = 0; ch < nch; ch++)
+            for (int t = 0; t < ntaps; t++)
+                for (int half = 0; half < 2; half++)
+                    for (int n = 0; n < NT; n++)
+                        for (int e = 0; e < 8; e++, o++) {
+                            const int c = ch * 16 + half * 8 + e, oc = nt * NT + n;
+                            if (oc >= L.cout) continue;
+                            float v;
+                            if (t == 9) v = (c == oc) ? 1.f : 0.f;
+                            else v = w[((size_t)oc * L.cin + c) * 9 + t];
+                            out[o] = f2h(v);
+                        }
+    return out;
+}
+
 static int upload_layer(ConvLayer& L, const float* w, const float* bias, const float* slope /*per-channel or null*/, float uniform_slope) {
     configure(L);
+    std::vector<float> wskip;
+    const float* w_orig = w;
+    if (L.skip) {
+        // x + conv(x) == conv'(x) with W'[o][o][1][1] = W[o][o][1][1] + 1: the skip connection of the residual block
+        // (flownet.param:13-15 "Split, Convolution, BinaryOp add") rides the centre tap of the fp32 GEMM instead of a second
+        // read of x in the epilogue.  fp16-stored weights + 1.0f are exact in fp32 down to 2^-23.
+        wskip.assign(w, w + (size_t)L.cin * L.cout * 9);
+        for (int o = 0; o < L.cout; o++) wskip[((size_t)o * L.cin + o) * 9 + 4] += 1.0f;
+        w = wskip.data();
+    }
     std::vector<float> pk = pack_weights(L, w);
     const int cp = L.ntiles * L.NS * 32;
     std::vector<float> b(cp, 0.f), s(cp, 1.f);
@@ -130,6 +188,23 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             L.nchunks8 = T.nchunks;
         }
     }
+    if (!L.deconv && L.stride == 1 && L.epi == EPI_STORE && L.NS >= 2 && L.cin % 16 == 0) {
+        bool exact = true;   // the split-f16 path needs weights that are exactly fp16 (true for ncnn fp16-stored models)
+        for (size_t i = 0; i < (size_t)L.cin * L.cout * 9 && exact; i++) {
+            const uint16_t h = f2h(w_orig[i]);
+            const uint32_t sgn = (uint32_t)(h & 0x8000u) << 16, ex = (h >> 10) & 0x1f, mn = h & 0x3ffu;
+            float back;
+            if (ex == 0) back = std::ldexp((float)mn, -24) * (sgn ? -1.f : 1.f);
+            else { const uint32_t bits = sgn | ((ex + 112) << 23) | (mn << 13); std::memcpy(&back, &bits, 4); }
+            exact = back == w_orig[i];
+        }
+        if (exact) {
+            std::vector<uint16_t> ph = pack_weights_h2(L, w_orig, L.skip ? 10 : 9);
+            HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
+            HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
+            L.nchunksh = L.cin / 16;
+        }
+    }
     return 0;
 }
 
@@ -147,6 +222,8 @@ static hipError_t launch_cfg(const ConvArgs& a, int nblocks, hipStream_t st) {
 
 struct TensorView { float* p; int ld, coff; };
 
+// RIFE_HIP_TRUNK=f32 keeps the trunk convolutions on the fp32 matrix path (default: split-f16, see conv_h2_kernel)
+static const bool g_trunk_h2 = []() { const char* e = getenv("RIFE_HIP_TRUNK"); return !(e && std::strcmp(e, "f32") == 0); }();
 // RIFE_HIP_CONV8=0 disables the 8-wave trunk kernel (A/B measurements)
 static const bool g_use_conv8 = []() { const char* e = getenv("RIFE_HIP_CONV8"); return !(e && e[0] == '0'); }();
 
@@ -169,6 +246,35 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
     if (L.stride == 1) {
         const long wg2 = (long)a.tiles_x * ((a.Ho + 7) / 8) * a.nz;
         MS = wg2 >= 384 ? 2 : 1;
+    }
+    // trunk layers: split-f16 matrix path (fp32-grade accuracy at 8x the fp32 MFMA rate) unless RIFE_HIP_TRUNK=f32
+    if (L.nchunksh > 0 && g_trunk_h2 && res == nullptr) {
+        a.ntiles_xy = a.tiles_x * ((a.Ho + 7) / 8);
+        a.nchunks = L.nchunksh;
+        a.wpk = reinterpret_cast<const float*>(L.d_wh);
+        const int nb = a.ntiles_xy * a.nz;
+        constexpr int l29 = convh2_lds_bytes<2, 9>(), l210 = convh2_lds_bytes<2, 10>(), l39 = convh2_lds_bytes<3, 9>(), l310 = convh2_lds_bytes<3, 10>();
+        {
+            static std::mutex amu; static std::map<int, bool> done;
+            int dev = 0; (void)hipGetDevice(&dev);
+            std::lock_guard<std::mutex> g(amu);
+            if (!done[dev]) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<2, 9, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, l29));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<2, 10, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, l210));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<2, 10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, l210));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<3, 9, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, l39));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<3, 10, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, l310));
+                done[dev] = true;
+            }
+        }
+        if (L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2_kernel<2, 10, 3>), dim3(nb), dim3(512), l210, st, a);
+        else if (L.NS == 2 && L.skip) hipLaunchKernelGGL((conv_h2_kernel<2, 10, 0>), dim3(nb), dim3(512), l210, st, a);
+        else if (L.NS == 2) hipLaunchKernelGGL((conv_h2_kernel<2, 9, 0>), dim3(nb), dim3(512), l29, st, a);
+        else if (L.skip) hipLaunchKernelGGL((conv_h2_kernel<3, 10, 0>), dim3(nb), dim3(512), l310, st, a);
+        else hipLaunchKernelGGL((conv_h2_kernel<3, 9, 0>), dim3(nb), dim3(512), l39, st, a);
+        hipError_t eh = hipGetLastError();
+        if (eh != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_h2 launch: ") + hipGetErrorString(eh));
+        return 0;
     }
     // layers with >= 2 full waves of 8-row tiles take the double-buffered 8-wave kernel
     if (L.nchunks8 > 0 && g_use_conv8) {
@@ -873,14 +979,7 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {
             free_layer(L);
             L.cin = cin; L.cout = cout; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi; L.cls = cls;
             L.tag = std::strcmp(cls, "trunk_b3") == 0 ? 3 : 0;
-            if (fold_skip) {
-                // x + conv(x) == conv'(x) with W'[o][o][1][1] = W[o][o][1][1] + 1: the skip connection of the residual
-                // block (flownet.param:13-15 "Split, Convolution, BinaryOp add") rides the centre tap of the GEMM instead
-                // of a second read of x in the epilogue.  fp16-stored weights + 1.0f are exact in fp32 down to 2^-23.
-                std::vector<float> w2(nl->weight);
-                for (int o = 0; o < cout; o++) w2[((size_t)o * cin + o) * 9 + 4] += 1.0f;
-                return upload_layer(L, w2.data(), nl->bias.data(), nullptr, slope);
-            }
+            L.skip = fold_skip;
             return upload_layer(L, nl->weight.data(), nl->bias.data(), nullptr, slope);
         };
         std::snprintf(name, sizeof name, "stem0_b%d", b);
