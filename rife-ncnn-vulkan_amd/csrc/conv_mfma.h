@@ -388,12 +388,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 // ------------------------------------------------------------------------------------------------------------
 // conv_h2_kernel: trunk 3x3 stride-1 convolution on the f16 matrix pipe at fp32 accuracy ("split-f16").
 //   * weights are fp16 on disk (ncnn tag 0x01306B47), so they enter the MFMA exactly;
-//   * every fp32 activation a is split while it is staged into LDS:  hi = f16(a),  lo = f16((a - hi) * 2048)
-//     => a == hi + lo/2048 up to 2^-22 relative; below the f16 normal range (|a| < 6.2e-5) hi is forced to 0 so that no
-//     f16 denormal ever reaches the matrix pipe, and a is carried by lo alone: absolute error <= 1.5e-8 there;
-//   * two v_mfma_f32_32x32x16_f16 per 16-channel k-step accumulate W*hi and W*lo in separate fp32 accumulators;
-//     the epilogue forms acc_hi + acc_lo/2048 + bias.  Products are exact in fp32 (11 x 11 bit significands), so the
-//     result differs from the fp32 kernel only by summation order.
+//   * every fp32 activation a is split while it is staged into LDS:  hi = f16(a),  lo = f16(a - hi)
+//     => a == hi + lo up to max(2^-22 |a|, 3e-8): lo is allowed to be an f16 subnormal — the gfx950 matrix pipe keeps f16
+//     subnormal inputs (hipcc's default denorm mode; asserted by tests/test_gpu_kernels.py::test_f16_mfma_keeps_subnormals);
+//   * two v_mfma_f32_32x32x16_f16 per 16-channel k-step accumulate W*hi and W*lo into the same fp32 accumulator.
+//     Products are exact in fp32 (11 x 11 bit significands), so the result differs from the fp32 kernel only by
+//     summation order and the 2^-22 split error.
 //   * optional tap 9 = centre pixel with identity weights: the residual skip (x + conv(x)) inside the GEMM.
 //   One k-step covers 16 channels: lanes 0-31 supply channels 0-7, lanes 32-63 channels 8-15 (8 f16 = 16 B per lane).
 //   LDS pixel record = 32 B hi + 32 B lo + 16 B pad (80 B = 5 slots: conflict-free ds_read_b128 columns).
@@ -463,9 +463,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             f16x4 hi4, lo4;                                                                                 \
             _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                 \
                 const float v = ((inside >> k) & 1u) ? RIN[k][e] : 0.f;                                     \
-                const _Float16 h = __builtin_fabsf(v) < 6.2e-5f ? (_Float16)0.f : (_Float16)v;              \
+                const _Float16 h = (_Float16)v;                                                             \
                 hi4[e] = h;                                                                                 \
-                lo4[e] = (_Float16)((v - (float)h) * 2048.f);                                               \
+                lo4[e] = (_Float16)(v - (float)h);                                                          \
             }                                                                                               \
             if (IN_F4 % 512 == 0 || idx < IN_F4) {                                                          \
                 *reinterpret_cast<f16x4*>(lin_ + p * PIXB + q * 8) = hi4;                                   \
@@ -485,19 +485,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int dy = t == 9 ? 1 : t / 3, dx = t == 9 ? 1 : t % 3;                                     \
             const f16x8 ah = *reinterpret_cast<const f16x8*>(ab_ + (dy * IW + dx) * PIXB);                  \
             const f16x8 al = *reinterpret_cast<const f16x8*>(ab_ + (dy * IW + dx) * PIXB + 32);             \
-            _Pragma("unroll") for (int n = 0; n < NS; n++) {                                                \
-                const f16x8 bw = *reinterpret_cast<const f16x8*>(bb_ + (t * 2 * NT + n * 32) * 16);         \
-                acch[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, ah, acch[n], 0, 0, 0);                 \
-                accl[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, al, accl[n], 0, 0, 0);                 \
-            }                                                                                               \
+            f16x8 bw[NS];                                                                                   \
+            _Pragma("unroll") for (int n = 0; n < NS; n++)                                                  \
+                bw[n] = *reinterpret_cast<const f16x8*>(bb_ + (t * 2 * NT + n * 32) * 16);                  \
+            _Pragma("unroll") for (int n = 0; n < NS; n++)                                                  \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[n], ah, acc[n], 0, 0, 0);                \
+            _Pragma("unroll") for (int n = 0; n < NS; n++)                                                  \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[n], al, acc[n], 0, 0, 0);                \
         }                                                                                                   \
     }
 
-    f32x16 acch[NS], accl[NS];
+    f32x16 acc[NS];
 #pragma unroll
     for (int n = 0; n < NS; n++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) { acch[n][r] = 0.f; accl[n][r] = 0.f; }
+        for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
 
     const int nch = a.nchunks;
     unsigned char* buf0 = ldsb; unsigned char* buf1 = ldsb + BUFB;
@@ -539,12 +541,160 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
             f32x4 v;
 #pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = (acch[n][4 * q + k] + accl[n][4 * q + k] * (1.f / 2048.f)) + b4[k];
+            for (int k = 0; k < 4; k++) v[k] = acc[n][4 * q + k] + b4[k];
             if (a.res != nullptr) {
                 const f32x4 r4 = *reinterpret_cast<const f32x4*>(a.res + (ok ? ((size_t)oy * a.Wo + ox) * a.res_ld + a.res_coff + c0 : 0));
 #pragma unroll
                 for (int k = 0; k < 4; k++) v[k] += r4[k];
             }
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k];
+            if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// conv_h2b_kernel: conv_h2_kernel re-balanced for two workgroups per CU (16 waves): the input tile is double
+// buffered, the weight slab is not (2 x 27.2 KB + 20.5 KB = 75 KB), so a second workgroup's matrix work covers this
+// one's load latency, barriers, prologue and epilogue.  One register set; the input prefetch of chunk k+2 is issued
+// as soon as chunk k+1 has been written to LDS (mid-chunk), the weight prefetch right after the weight slab swap.
+// ------------------------------------------------------------------------------------------------------------
+template <int NS, int NTAPS>
+constexpr int convh2b_lds_bytes() { return 2 * 10 * 34 * 80 + NTAPS * 2 * NS * 32 * 16; }
+
+template <int NS, int NTAPS, int TAG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_h2b_kernel(ConvArgs a) {
+    constexpr int IH = 10, IW = 34, CC = 16, NT = NS * 32;
+    constexpr int PIXB = 80;
+    constexpr int IN_F4 = IH * IW * 4;
+    constexpr int W_16 = NTAPS * 2 * NT;
+    constexpr int NIN = (IN_F4 + 511) / 512, NW = (W_16 + 511) / 512;
+    constexpr int INB = IH * IW * PIXB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char* const lw = ldsb + 2 * INB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int half = lane >> 5, li = lane & 31;
+    int L;
+    {
+        const int n = gridDim.x, b = blockIdx.x;
+        const int q = n >> 3, r = n & 7, xcd = b & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int tile = L / a.nz, ntile = L - tile * a.nz;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * 8, ox0 = tx * 32;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+
+    int goff[NIN];
+    unsigned inside = 0;
+#pragma unroll
+    for (int k = 0; k < NIN; k++) {
+        const int idx = tid + k * 512;
+        const int p = idx >> 2, q = idx & 3;
+        const int py = p / IW, px = p - py * IW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        const bool ok = idx < IN_F4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        goff[k] = ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff;
+        inside |= ok ? (1u << k) : 0u;
+    }
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk) + (size_t)ntile * a.nchunks * W_16;
+
+    f32x4 rin[NIN], rw[NW];
+#define H2B_ISSUE_IN(CH)                                                                                    \
+    _Pragma("unroll") for (int k = 0; k < NIN; k++) rin[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC);
+#define H2B_ISSUE_W(CH)                                                                                     \
+    _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                        \
+        const int idx = tid + k * 512;                                                                      \
+        rw[k] = wsrc[(size_t)(CH) * W_16 + ((W_16 % 512 == 0 || idx < W_16) ? idx : 0)];                    \
+    }
+#define H2B_WRITE_IN(BUFP)                                                                                  \
+    _Pragma("unroll") for (int k = 0; k < NIN; k++) {                                                       \
+        const int idx = tid + k * 512;                                                                      \
+        const int p = idx >> 2, q = idx & 3;                                                                \
+        f16x4 hi4, lo4;                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                     \
+            const float v = ((inside >> k) & 1u) ? rin[k][e] : 0.f;                                         \
+            const _Float16 h = (_Float16)v;                                                                 \
+            hi4[e] = h;                                                                                     \
+            lo4[e] = (_Float16)(v - (float)h);                                                              \
+        }                                                                                                   \
+        if (IN_F4 % 512 == 0 || idx < IN_F4) {                                                              \
+            *reinterpret_cast<f16x4*>((BUFP) + p * PIXB + q * 8) = hi4;                                     \
+            *reinterpret_cast<f16x4*>((BUFP) + p * PIXB + 32 + q * 8) = lo4;                                \
+        }                                                                                                   \
+    }
+#define H2B_WRITE_W()                                                                                       \
+    _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                        \
+        const int idx = tid + k * 512;                                                                      \
+        if (W_16 % 512 == 0 || idx < W_16) reinterpret_cast<f32x4*>(lw)[idx] = rw[k];                       \
+    }
+#define H2B_TAPS(BUFP, T0, T1)                                                                              \
+    {                                                                                                       \
+        const unsigned char* ab_ = (BUFP) + (wv * IW + li) * PIXB + half * 16;                              \
+        const unsigned char* bb_ = lw + (half * NT + li) * 16;                                              \
+        _Pragma("unroll") for (int t = (T0); t < (T1); t++) {                                               \
+            const int dy = t == 9 ? 1 : t / 3, dx = t == 9 ? 1 : t % 3;                                     \
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(ab_ + (dy * IW + dx) * PIXB);                  \
+            const f16x8 al = *reinterpret_cast<const f16x8*>(ab_ + (dy * IW + dx) * PIXB + 32);             \
+            f16x8 bw[NS];                                                                                   \
+            _Pragma("unroll") for (int n = 0; n < NS; n++)                                                  \
+                bw[n] = *reinterpret_cast<const f16x8*>(bb_ + (t * 2 * NT + n * 32) * 16);                  \
+            _Pragma("unroll") for (int n = 0; n < NS; n++)                                                  \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[n], ah, acc[n], 0, 0, 0);                \
+            _Pragma("unroll") for (int n = 0; n < NS; n++)                                                  \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[n], al, acc[n], 0, 0, 0);                \
+        }                                                                                                   \
+    }
+
+    f32x16 acc[NS];
+#pragma unroll
+    for (int n = 0; n < NS; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+
+    const int nch = a.nchunks;
+    H2B_ISSUE_IN(0)
+    H2B_ISSUE_W(0)
+    H2B_WRITE_IN(ldsb)
+    H2B_WRITE_W()
+    if (nch > 1) { H2B_ISSUE_IN(1) H2B_ISSUE_W(1) }
+    __syncthreads();
+    for (int ch = 0; ch < nch; ch++) {
+        unsigned char* cur = ldsb + (ch & 1) * INB;
+        unsigned char* oth = ldsb + ((ch & 1) ^ 1) * INB;
+        H2B_TAPS(cur, 0, NTAPS / 2)
+        if (ch + 1 < nch) { H2B_WRITE_IN(oth) }                 // input of chunk ch+1 (issued half a chunk + ago)
+        if (ch + 2 < nch) { H2B_ISSUE_IN(ch + 2) }
+        H2B_TAPS(cur, NTAPS / 2, NTAPS)
+        if (ch + 1 < nch) {
+            __syncthreads();                                    // everyone is done with the weight slab of chunk ch
+            H2B_WRITE_W()
+            if (ch + 2 < nch) { H2B_ISSUE_W(ch + 2) }
+            __syncthreads();
+        }
+    }
+#undef H2B_ISSUE_IN
+#undef H2B_ISSUE_W
+#undef H2B_WRITE_IN
+#undef H2B_WRITE_W
+#undef H2B_TAPS
+
+    const int oy = oy0 + wv, ox = ox0 + li;
+    const bool pok = oy < a.Ho && ox < a.Wo;
+#pragma unroll
+    for (int n = 0; n < NS; n++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c0 = ntile * NT + n * 32 + 8 * q + 4 * half;
+            const bool ok = pok && c0 < a.Cout;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = acc[n][4 * q + k] + b4[k];
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k];
             if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;

@@ -224,6 +224,7 @@ struct TensorView { float* p; int ld, coff; };
 
 // RIFE_HIP_TRUNK=f32 keeps the trunk convolutions on the fp32 matrix path (default: split-f16, see conv_h2_kernel)
 static const bool g_trunk_h2 = []() { const char* e = getenv("RIFE_HIP_TRUNK"); return !(e && std::strcmp(e, "f32") == 0); }();
+static const bool g_h2b = []() { const char* e = getenv("RIFE_HIP_H2B"); return !(e && e[0] == '0'); }();   // A/B: 2-workgroup variant
 // RIFE_HIP_CONV8=0 disables the 8-wave trunk kernel (A/B measurements)
 static const bool g_use_conv8 = []() { const char* e = getenv("RIFE_HIP_CONV8"); return !(e && e[0] == '0'); }();
 
@@ -267,7 +268,22 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
                 done[dev] = true;
             }
         }
-        if (L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2_kernel<2, 10, 3>), dim3(nb), dim3(512), l210, st, a);
+        constexpr int lb9 = convh2b_lds_bytes<2, 9>(), lb10 = convh2b_lds_bytes<2, 10>();
+        {
+            static std::mutex bmu; static std::map<int, bool> bdone;
+            int dev = 0; (void)hipGetDevice(&dev);
+            std::lock_guard<std::mutex> g(bmu);
+            if (!bdone[dev]) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 9, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb9));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb10));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lb10));
+                bdone[dev] = true;
+            }
+        }
+        if (g_h2b && L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 3>), dim3(nb), dim3(512), lb10, st, a);
+        else if (g_h2b && L.NS == 2 && L.skip) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 0>), dim3(nb), dim3(512), lb10, st, a);
+        else if (g_h2b && L.NS == 2) hipLaunchKernelGGL((conv_h2b_kernel<2, 9, 0>), dim3(nb), dim3(512), lb9, st, a);
+        else if (L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2_kernel<2, 10, 3>), dim3(nb), dim3(512), l210, st, a);
         else if (L.NS == 2 && L.skip) hipLaunchKernelGGL((conv_h2_kernel<2, 10, 0>), dim3(nb), dim3(512), l210, st, a);
         else if (L.NS == 2) hipLaunchKernelGGL((conv_h2_kernel<2, 9, 0>), dim3(nb), dim3(512), l29, st, a);
         else if (L.skip) hipLaunchKernelGGL((conv_h2_kernel<3, 10, 0>), dim3(nb), dim3(512), l310, st, a);
@@ -1260,6 +1276,28 @@ int rife_hip_bench_conv8(int gpuid, int c, int h, int w, int variant, int iters,
     }
     (void)hipFree(x); (void)hipFree(y); free_layer(L);
     return rc;
+}
+
+// hardware probe: does v_mfma_f32_32x32x16_f16 keep f16 subnormal inputs?  out[0] = sum over k of a_k*b_k with
+// a_k = 2^-20 (f16 subnormal), b_k = 1  -> 16 * 2^-20 = 1.52587890625e-05 if preserved, 0 if flushed.
+__global__ void k_probe_f16_denorm(float* out) {
+    f16x8 a, b;
+    for (int e = 0; e < 8; e++) { a[e] = (_Float16)9.5367431640625e-07f; b[e] = (_Float16)1.0f; }
+    f32x16 c;
+    for (int r = 0; r < 16; r++) c[r] = 0.f;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    if (threadIdx.x == 0) out[0] = c[0];
+}
+
+int rife_hip_probe_f16_denorm(int gpuid, float* out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    float* d = nullptr;
+    HIPCHK(hipMalloc(&d, 4));
+    hipLaunchKernelGGL(k_probe_f16_denorm, dim3(1), dim3(64), 0, 0, d);
+    HIPCHK(hipMemcpy(out, d, 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
 }
 
 // tooling: structural hash of a named blob of a .param file (used to derive / test the compiled-in constants)

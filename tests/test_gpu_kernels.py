@@ -61,7 +61,7 @@ def test_conv3x3_prelu_slopes_and_identity_weights():
         want = np.where(v < 0, v * slope[o], v)
         # single product per output: exact on the fp32 path; the split-f16 path (taken here, the weights are exactly fp16)
         # reconstructs x as hi + lo/2048, which is x up to 2^-22 relative
-        assert np.all(np.abs(got[o] - want) <= 3.6e-7 * np.abs(want) + 2e-8), o   # 2^-22 (split) + 2^-24 (final add); |x| < 6.2e-5 keeps only its lo part: abs error <= 1.5e-8
+        assert np.all(np.abs(got[o] - want) <= 3.6e-7 * np.abs(want) + 6e-8), o   # 2^-22 (split) + 2^-24 (final add); f16-subnormal lo parts: abs error <= 3e-8 each
 
 
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 24, 16, 40), (192, 24, 5, 9), (96, 24, 9, 33), (32, 4, 12, 20), (128, 32, 6, 10), (256, 64, 4, 6)])
@@ -104,3 +104,12 @@ def test_conv3x3_split_f16_trunk_path_matches_oracle(c, h, w):
     # fp32-grade, not f16-grade: measured 1.1e-6 of the output range (the fp32-MFMA kernel gives 0.7e-6, f16 storage would give ~5e-4)
     assert err.max() <= 4e-6 * np.abs(want).max()
     assert err[:, 7:].max() <= 1e-4           # rows fed only by O(1) activations
+
+
+def test_f16_mfma_keeps_subnormals():
+    """conv_h2*_kernel relies on the matrix pipe preserving f16 subnormal inputs (lo = f16(a - hi) is often subnormal)."""
+    import ctypes
+    L = amd.lib()
+    out = ctypes.c_float()
+    assert L.rife_hip_probe_f16_denorm(0, ctypes.byref(out)) == 0
+    assert out.value == 16 * 2.0 ** -20
