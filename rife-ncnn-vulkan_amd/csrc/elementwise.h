@@ -108,13 +108,10 @@ __global__ void k_assemble0(const uint32_t* __restrict__ img0, const uint32_t* _
 
 // Blocks 1..3 input (flownet.param:52-62, 107-115, 160-165):
 //   x = Concat(Interp(1/S)(Concat(warp(in0,F.xy), warp(in1,F.zw), in2, M)), Interp(1/S)(F)/S)  -> NHWC16 (12 + 4 zero)
+// one pixel (bx, by) of the block input at 1/S resolution: 12 channels {warp(in0,F.xy) rgb, warp(in1,F.zw) rgb, t, M, F/S xyzw}
 template <int S>
-__global__ void k_assemble(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float timestep,
-                           const float4* __restrict__ F, const float* __restrict__ M, float* __restrict__ X, int wp, int hp) {
-    const int Wb = wp / S, Hb = hp / S;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= Wb || y >= Hb) return;
-    float o[12];
+__device__ __forceinline__ void assemble_pixel(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float timestep,
+                                               const float4* __restrict__ F, const float* __restrict__ M, int wp, int hp, int x, int y, float o[12]) {
     if (S == 1) {
         const size_t i = (size_t)y * wp + x;
         const float4 f = F[i];
@@ -141,6 +138,16 @@ __global__ void k_assemble(const uint32_t* __restrict__ img0, const uint32_t* __
 #pragma unroll
         for (int c = 8; c < 12; c++) o[c] = o[c] / (float)S;        // BinaryOp div by scalar (flownet.param:53,108)
     }
+}
+
+template <int S>
+__global__ void k_assemble(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float timestep,
+                           const float4* __restrict__ F, const float* __restrict__ M, float* __restrict__ X, int wp, int hp) {
+    const int Wb = wp / S, Hb = hp / S;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= Wb || y >= Hb) return;
+    float o[12];
+    assemble_pixel<S>(img0, img1, timestep, F, M, wp, hp, x, y, o);
     float4* dst = reinterpret_cast<float4*>(X + ((size_t)y * Wb + x) * 16);
     dst[0] = make_float4(o[0], o[1], o[2], o[3]);
     dst[1] = make_float4(o[4], o[5], o[6], o[7]);

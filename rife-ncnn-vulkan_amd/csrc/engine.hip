@@ -23,6 +23,7 @@
 #include "conv_mfma.h"
 #include "elementwise.h"
 #include "elementwise_v2.h"
+#include "stem_fused.h"
 #include "model_hashes.h"
 #include "ncnn_model.h"
 
@@ -135,7 +136,7 @@ static uint16_t f2h(float f) {
 // fp16 B... A-fragment order of conv_h2_kernel: [ntile][chunk of 16 ch][tap][half][n][8], channel = chunk*16 + half*8 + e;
 // tap 9 (only when the layer carries a skip connection) = identity on the centre pixel.
 static std::vector<uint16_t> pack_weights_h2(const ConvLayer& L, const float* w, int ntaps) {
-    const int NT = L.NS * 32, nch = L.cin / 16;
+    const int NT = L.NS * 32, nch = (L.cin + 15) / 16;
     std::vector<uint16_t> out((size_t)L.ntiles * nch * ntaps * 2 * NT * 8, 0);
     size_t o = 0;
     for (int nt = 0; nt < L.ntiles; nt++)
@@ -145,7 +146,7 @@ static std::vector<uint16_t> pack_weights_h2(const ConvLayer& L, const float* w,
                     for (int n = 0; n < NT; n++)
                         for (int e = 0; e < 8; e++, o++) {
                             const int c = ch * 16 + half * 8 + e, oc = nt * NT + n;
-                            if (oc >= L.cout) continue;
+                            if (oc >= L.cout || c >= L.cin) continue;
                             float v;
                             if (t == 9) v = (c == oc) ? 1.f : 0.f;
                             else v = w[((size_t)oc * L.cin + c) * 9 + t];
@@ -188,6 +189,16 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             L.nchunks8 = T.nchunks;
         }
     }
+    if (!L.deconv && L.stride == 2 && L.cin == 12 && L.ntiles == 1) {      // v4 stem-0 of blocks 1..3: fused assemble + conv kernel
+        std::vector<uint16_t> ph = pack_weights_h2(L, w_orig, 9);
+        bool exact = true;
+        for (size_t i = 0; i < (size_t)L.cin * L.cout * 9 && exact; i++) exact = (float)(_Float16)w_orig[i] == w_orig[i];
+        if (exact) {
+            HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
+            HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
+            L.nchunksh = 1;
+        }
+    }
     if (!L.deconv && L.stride == 1 && L.epi == EPI_STORE && L.NS >= 2 && L.cin % 16 == 0) {
         bool exact = true;   // the split-f16 path needs weights that are exactly fp16 (true for ncnn fp16-stored models)
         for (size_t i = 0; i < (size_t)L.cin * L.cout * 9 && exact; i++) {
@@ -224,6 +235,7 @@ struct TensorView { float* p; int ld, coff; };
 
 // RIFE_HIP_TRUNK=f32 keeps the trunk convolutions on the fp32 matrix path (default: split-f16, see conv_h2_kernel)
 static const bool g_trunk_h2 = []() { const char* e = getenv("RIFE_HIP_TRUNK"); return !(e && std::strcmp(e, "f32") == 0); }();
+static const bool g_fuse_stem = []() { const char* e = getenv("RIFE_HIP_FUSE_STEM"); return !(e && e[0] == '0'); }();
 static const bool g_h2b = []() { const char* e = getenv("RIFE_HIP_H2B"); return !(e && e[0] == '0'); }();   // A/B: 2-workgroup variant
 // RIFE_HIP_CONV8=0 disables the 8-wave trunk kernel (A/B measurements)
 static const bool g_use_conv8 = []() { const char* e = getenv("RIFE_HIP_CONV8"); return !(e && e[0] == '0'); }();
@@ -249,7 +261,7 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         MS = wg2 >= 384 ? 2 : 1;
     }
     // trunk layers: split-f16 matrix path (fp32-grade accuracy at 8x the fp32 MFMA rate) unless RIFE_HIP_TRUNK=f32
-    if (L.nchunksh > 0 && g_trunk_h2 && res == nullptr) {
+    if (L.nchunksh > 0 && L.stride == 1 && g_trunk_h2 && res == nullptr) {
         a.ntiles_xy = a.tiles_x * ((a.Ho + 7) / 8);
         a.nchunks = L.nchunksh;
         a.wpk = reinterpret_cast<const float*>(L.d_wh);
@@ -527,14 +539,51 @@ struct Timed {
 
 static inline dim3 grid2d(int w, int h) { return dim3((w + 255) / 256, h); }
 
+static int run_assemble(const rife_hip& E, Ctx& c, int b, float timestep) {
+    hipStream_t st = c.stream;
+    Timed t(E.prof, "assemble", 0, st);
+    const int s = E.blk[b].scale;
+    dim3 g = grid2d(c.wp / s, c.hp / s);
+    if (b == 0) hipLaunchKernelGGL(k_assemble0, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.X, c.wp, c.hp);
+    else if (s == 4) hipLaunchKernelGGL(k_assemble<4>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
+    else if (s == 2) hipLaunchKernelGGL(k_assemble<2>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
+    else hipLaunchKernelGGL(k_assemble<1>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // One IFBlock: stems, 8 residual convs, head -> flow[b]   (flownet.param:11-46, 63-98, 116-151, 166-201)
-static int run_block_convs(const rife_hip& E, Ctx& c, int b) {
+static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep) {
     const rife_hip::Block& B = E.blk[b];
     hipStream_t st = c.stream;
     const int s = B.scale, Hb = c.hp / s, Wb = c.wp / s;
     const int xin_ld = b == 0 ? 8 : 16;
     int rc;
-    {
+    if (b == 0 && (rc = run_assemble(E, c, 0, timestep))) return rc;
+    if (b > 0 && B.stem0.d_wh && g_trunk_h2 && g_fuse_stem) {
+        // assemble + stem-0 in one kernel (stem_fused.h): the block input never goes to HBM
+        Timed t(E.prof, B.stem0.cls, B.stem0.flops_per_pixel * (Hb / 2) * (Wb / 2), st);
+        StemFusedArgs fa;
+        fa.img0 = c.img0; fa.img1 = c.img1; fa.F = c.F; fa.M = c.M; fa.wpk = B.stem0.d_wh; fa.bias = B.stem0.d_bias; fa.slope = B.stem0.d_slope;
+        fa.out = c.S1; fa.timestep = timestep; fa.wp = c.wp; fa.hp = c.hp; fa.Ho = Hb / 2; fa.Wo = Wb / 2; fa.out_ld = B.c / 2; fa.Cout = B.c / 2;
+        fa.tiles_x = (fa.Wo + 31) / 32;
+        const int nb = fa.tiles_x * ((fa.Ho + 3) / 4);
+        {
+            static std::mutex fmu; static std::map<int, bool> fdone;
+            int dev = 0; (void)hipGetDevice(&dev);
+            std::lock_guard<std::mutex> g(fmu);
+            if (!fdone[dev]) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+                fdone[dev] = true;
+            }
+        }
+        if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(256), stemf_lds_bytes<2>(), st, fa);
+        else if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2>), dim3(nb), dim3(256), stemf_lds_bytes<2>(), st, fa);
+        else hipLaunchKernelGGL((stem0_fused_kernel<1, 1>), dim3(nb), dim3(256), stemf_lds_bytes<1>(), st, fa);
+        HIPCHK(hipGetLastError());
+    } else {
+        if (b > 0 && (rc = run_assemble(E, c, b, timestep))) return rc;
         Timed t(E.prof, B.stem0.cls, B.stem0.flops_per_pixel * (Hb / 2) * (Wb / 2), st);
         if ((rc = launch_conv(B.stem0, {c.X, xin_ld, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, nullptr, st))) return rc;
     }
@@ -553,19 +602,6 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b) {
         Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);
         if ((rc = launch_conv(B.head, {cur, B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st))) return rc;
     }
-    return 0;
-}
-
-static int run_assemble(const rife_hip& E, Ctx& c, int b, float timestep) {
-    hipStream_t st = c.stream;
-    Timed t(E.prof, "assemble", 0, st);
-    const int s = E.blk[b].scale;
-    dim3 g = grid2d(c.wp / s, c.hp / s);
-    if (b == 0) hipLaunchKernelGGL(k_assemble0, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.X, c.wp, c.hp);
-    else if (s == 4) hipLaunchKernelGGL(k_assemble<4>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
-    else if (s == 2) hipLaunchKernelGGL(k_assemble<2>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
-    else hipLaunchKernelGGL(k_assemble<1>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
-    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -592,8 +628,7 @@ static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
         HIPCHK(hipGetLastError());
     }
     for (int b = 0; b < 4; b++) {
-        if ((rc = run_assemble(E, c, b, timestep))) return rc;
-        if ((rc = run_block_convs(E, c, b))) return rc;
+        if ((rc = run_block_convs(E, c, b, timestep))) return rc;
         if (b < 3 && (rc = run_flow_update(E, c, b))) return rc;
     }
     {
@@ -642,8 +677,7 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
         for (int ti = 0; ti < nori; ti++) {
             for (int dir = 0; dir < ntemp; dir++) {
                 Ctx& c = *E.tta_ctx[dir][ti];
-                if ((rc = run_assemble(E, c, fi, dir ? 1.f - timestep : timestep))) return rc;
-                if ((rc = run_block_convs(E, c, fi))) return rc;
+                if ((rc = run_block_convs(E, c, fi, dir ? 1.f - timestep : timestep))) return rc;
             }
             if (ntemp == 2) {
                 Timed t(E.prof, "tta_merge", 0, st);
@@ -1159,8 +1193,7 @@ int rife_hip_v4_extract_flow(const rife_hip_t* E, const uint8_t* in0, const uint
             HIPCHK(hipMemcpyAsync(tmp, inject[b], (size_t)Hb * Wb * 6 * 4, hipMemcpyHostToDevice, c.stream));
             hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(Wb, Hb), dim3(256), 0, c.stream, tmp, c.flow[b], 6, Hb, Wb, 8);
         } else {
-            if ((rc = run_assemble(*E, c, b, timestep))) return rc;
-            if ((rc = run_block_convs(*E, c, b))) return rc;
+            if ((rc = run_block_convs(*E, c, b, timestep))) return rc;
         }
         if (b < fi && (rc = run_flow_update(*E, c, b))) return rc;
     }
