@@ -24,6 +24,7 @@
 #include "elementwise.h"
 #include "elementwise_v2.h"
 #include "stem_fused.h"
+#include "head_h2.h"
 #include "model_hashes.h"
 #include "ncnn_model.h"
 
@@ -155,6 +156,34 @@ static std::vector<uint16_t> pack_weights_h2(const ConvLayer& L, const float* w,
     return out;
 }
 
+// host mirror of head_uses() / the pair order of head_h2.h
+static bool head_uses_h(int t, int par) {
+    const int dy = t / 3 - 1, dx = t % 3 - 1, py = par >> 1, px = par & 1;
+    return (dy == 0 || dy == (py ? 1 : -1)) && (dx == 0 || dx == (px ? 1 : -1));
+}
+
+// v4 head (Deconvolution C -> 24, k4 s2 p1) for head_h2_kernel: fp16 [chunk][(tap, parity) pair 16][half][n 32][8].
+// Kernel row for (parity p, offset d): p=0: d=0 -> k=1, d=-1 -> k=3;  p=1: d=0 -> k=2, d=+1 -> k=0.
+static std::vector<uint16_t> pack_weights_head_h2(const ConvLayer& L, const float* w) {
+    const int nch = L.cin / 16;
+    std::vector<uint16_t> out((size_t)nch * 16 * 2 * 32 * 8, 0);
+    size_t o = 0;
+    for (int ch = 0; ch < nch; ch++)
+        for (int t = 0; t < 9; t++)
+            for (int par = 0; par < 4; par++) {
+                if (!head_uses_h(t, par)) continue;
+                const int dy = t / 3 - 1, dx = t % 3 - 1, py = par >> 1, px = par & 1;
+                const int ky = dy == 0 ? (py ? 2 : 1) : (py ? 0 : 3), kx = dx == 0 ? (px ? 2 : 1) : (px ? 0 : 3);
+                for (int half = 0; half < 2; half++)
+                    for (int n = 0; n < 32; n++)
+                        for (int e = 0; e < 8; e++, o++) {
+                            const int c = ch * 16 + half * 8 + e;
+                            if (n < L.cout) out[o] = f2h(w[(((size_t)n * L.cin + c) * 4 + ky) * 4 + kx]);
+                        }
+            }
+    return out;
+}
+
 static int upload_layer(ConvLayer& L, const float* w, const float* bias, const float* slope /*per-channel or null*/, float uniform_slope) {
     configure(L);
     std::vector<float> wskip;
@@ -187,6 +216,16 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             HIPCHK(hipMalloc(&L.d_w8, pk8.size() * 4));
             HIPCHK(hipMemcpy(L.d_w8, pk8.data(), pk8.size() * 4, hipMemcpyHostToDevice));
             L.nchunks8 = T.nchunks;
+        }
+    }
+    if (L.deconv && L.epi == EPI_DECONV_PS && L.cout == 24 && L.cin % 16 == 0) {   // v4 heads: split-f16 kernel, 4 parities per workgroup
+        bool exact = true;
+        for (size_t i = 0; i < (size_t)L.cin * L.cout * 16 && exact; i++) exact = (float)(_Float16)w_orig[i] == w_orig[i];
+        if (exact) {
+            std::vector<uint16_t> ph = pack_weights_head_h2(L, w_orig);
+            HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
+            HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
+            L.nchunksh = L.cin / 16;
         }
     }
     if (!L.deconv && L.stride == 2 && L.cin == 12 && L.ntiles == 1) {      // v4 stem-0 of blocks 1..3: fused assemble + conv kernel
@@ -236,6 +275,7 @@ struct TensorView { float* p; int ld, coff; };
 // RIFE_HIP_TRUNK=f32 keeps the trunk convolutions on the fp32 matrix path (default: split-f16, see conv_h2_kernel)
 static const bool g_trunk_h2 = []() { const char* e = getenv("RIFE_HIP_TRUNK"); return !(e && std::strcmp(e, "f32") == 0); }();
 static const bool g_fuse_stem = []() { const char* e = getenv("RIFE_HIP_FUSE_STEM"); return !(e && e[0] == '0'); }();
+static const bool g_head_h2 = []() { const char* e = getenv("RIFE_HIP_HEAD_H2"); return !(e && e[0] == '0'); }();
 static const bool g_h2b = []() { const char* e = getenv("RIFE_HIP_H2B"); return !(e && e[0] == '0'); }();   // A/B: 2-workgroup variant
 // RIFE_HIP_CONV8=0 disables the 8-wave trunk kernel (A/B measurements)
 static const bool g_use_conv8 = []() { const char* e = getenv("RIFE_HIP_CONV8"); return !(e && e[0] == '0'); }();
@@ -259,6 +299,24 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
     if (L.stride == 1) {
         const long wg2 = (long)a.tiles_x * ((a.Ho + 7) / 8) * a.nz;
         MS = wg2 >= 384 ? 2 : 1;
+    }
+    if (L.nchunksh > 0 && L.deconv && g_trunk_h2 && g_head_h2) {
+        a.ntiles_xy = a.tiles_x * ((a.Ho + 7) / 8);
+        a.nchunks = L.nchunksh;
+        a.wpk = reinterpret_cast<const float*>(L.d_wh);
+        {
+            static std::mutex hmu; static std::map<int, bool> hdone;
+            int dev = 0; (void)hipGetDevice(&dev);
+            std::lock_guard<std::mutex> g(hmu);
+            if (!hdone[dev]) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
+                hdone[dev] = true;
+            }
+        }
+        hipLaunchKernelGGL(head_h2_kernel<0>, dim3(a.ntiles_xy), dim3(512), headh2_lds_bytes(), st, a);
+        hipError_t eh = hipGetLastError();
+        if (eh != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("head_h2 launch: ") + hipGetErrorString(eh));
+        return 0;
     }
     // trunk layers: split-f16 matrix path (fp32-grade accuracy at 8x the fp32 MFMA rate) unless RIFE_HIP_TRUNK=f32
     if (L.nchunksh > 0 && L.stride == 1 && g_trunk_h2 && res == nullptr) {

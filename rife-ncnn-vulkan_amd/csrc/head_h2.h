@@ -1,0 +1,165 @@
+// head_h2_kernel<TAG>: the IFBlock head of rife-v4 — Deconvolution 4x4 stride 2 pad 1 (C -> 24) + PixelShuffle(2)
+// (flownet.param:45-46, 97-98, 150-151, 200-201) on the f16 matrix pipe with the split-f16 scheme of conv_h2_kernel.
+// All four output parities of the transposed convolution are computed by one workgroup from one staged input tile:
+// parity (py, px) is a 2x2-tap convolution over the 3x3 neighbourhood, so each of the 9 neighbourhood taps feeds 1, 2
+// or 4 of the four 32-wide accumulators (16 (tap, parity) pairs in total; 24 of 32 channels are real).
+//   8 waves, tile = 8 rows x 32 columns of trunk pixels, chunk = 16 channels, input double buffered, weight slab single
+//   buffered (2 x 27.2 KB + 16 KB = 70.4 KB -> two workgroups per CU).
+//   Epilogue: + bias, PixelShuffle scatter into the flow tensor [4H][4W][8].
+#pragma once
+#include "conv_mfma.h"
+
+namespace rife {
+
+// (tap, parity) pair table: tap = dy*3 + dx over the 3x3 neighbourhood (dy, dx in 0..2 <-> offsets -1..+1).
+// parity p uses offset 0 and (p ? +1 : -1) in each axis (see pack_weights: out(2y+p) <- in(y+d) through kernel row k).
+__device__ __forceinline__ constexpr bool head_uses(int t, int par) {
+    const int dy = t / 3 - 1, dx = t % 3 - 1, py = par >> 1, px = par & 1;
+    const bool uy = dy == 0 || dy == (py ? 1 : -1);
+    const bool ux = dx == 0 || dx == (px ? 1 : -1);
+    return uy && ux;
+}
+__device__ __forceinline__ constexpr int head_pair_index(int t, int par) {   // position of (t, par) in the packed order
+    int n = 0;
+    for (int tt = 0; tt < 9; tt++)
+        for (int pp = 0; pp < 4; pp++) {
+            if (tt == t && pp == par) return n;
+            if (head_uses(tt, pp)) n++;
+        }
+    return -1;
+}
+
+constexpr int headh2_lds_bytes() { return 2 * 10 * 34 * 80 + 16 * 2 * 32 * 16; }
+
+template <int TAG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void head_h2_kernel(ConvArgs a) {
+    constexpr int IH = 10, IW = 34, CC = 16, NT = 32;
+    constexpr int PIXB = 80;
+    constexpr int IN_F4 = IH * IW * 4;
+    constexpr int W_16 = 16 * 2 * NT;                        // 16-byte units per weight chunk (16 pairs)
+    constexpr int NIN = (IN_F4 + 511) / 512, NW = (W_16 + 511) / 512;
+    constexpr int INB = IH * IW * PIXB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char* const lw = ldsb + 2 * INB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int half = lane >> 5, li = lane & 31;
+    int L;
+    {
+        const int n = gridDim.x, b = blockIdx.x;
+        const int q = n >> 3, r = n & 7, xcd = b & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int ty = L / a.tiles_x, tx = L - ty * a.tiles_x;
+    const int oy0 = ty * 8, ox0 = tx * 32;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+
+    int goff[NIN];
+    unsigned inside = 0;
+#pragma unroll
+    for (int k = 0; k < NIN; k++) {
+        const int idx = tid + k * 512;
+        const int p = idx >> 2, q = idx & 3;
+        const int py = p / IW, px = p - py * IW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        const bool ok = idx < IN_F4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        goff[k] = ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff;
+        inside |= ok ? (1u << k) : 0u;
+    }
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk);
+
+    f32x4 rin[NIN], rw[NW];
+#define HD_ISSUE_IN(CH)                                                                                     \
+    _Pragma("unroll") for (int k = 0; k < NIN; k++) rin[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC);
+#define HD_ISSUE_W(CH)                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < NW; k++) rw[k] = wsrc[(size_t)(CH) * W_16 + tid + k * 512];
+#define HD_WRITE_IN(BUFP)                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < NIN; k++) {                                                       \
+        const int idx = tid + k * 512;                                                                      \
+        const int p = idx >> 2, q = idx & 3;                                                                \
+        f16x4 hi4, lo4;                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                     \
+            const float v = ((inside >> k) & 1u) ? rin[k][e] : 0.f;                                         \
+            const _Float16 h = (_Float16)v;                                                                 \
+            hi4[e] = h;                                                                                     \
+            lo4[e] = (_Float16)(v - (float)h);                                                              \
+        }                                                                                                   \
+        if (IN_F4 % 512 == 0 || idx < IN_F4) {                                                              \
+            *reinterpret_cast<f16x4*>((BUFP) + p * PIXB + q * 8) = hi4;                                     \
+            *reinterpret_cast<f16x4*>((BUFP) + p * PIXB + 32 + q * 8) = lo4;                                \
+        }                                                                                                   \
+    }
+#define HD_WRITE_W() _Pragma("unroll") for (int k = 0; k < NW; k++) reinterpret_cast<f32x4*>(lw)[tid + k * 512] = rw[k];
+#define HD_TAPS(BUFP, T0, T1)                                                                               \
+    {                                                                                                       \
+        const unsigned char* ab_ = (BUFP) + (wv * IW + li) * PIXB + half * 16;                              \
+        const unsigned char* bb_ = lw + (half * NT + li) * 16;                                              \
+        _Pragma("unroll") for (int t = (T0); t < (T1); t++) {                                               \
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(ab_ + ((t / 3) * IW + (t % 3)) * PIXB);        \
+            const f16x8 al = *reinterpret_cast<const f16x8*>(ab_ + ((t / 3) * IW + (t % 3)) * PIXB + 32);   \
+            _Pragma("unroll") for (int par = 0; par < 4; par++)                                             \
+                if (head_uses(t, par)) {                                                                    \
+                    const f16x8 bw = *reinterpret_cast<const f16x8*>(bb_ + head_pair_index(t, par) * 2 * NT * 16); \
+                    acc[par] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, ah, acc[par], 0, 0, 0);           \
+                    acc[par] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, al, acc[par], 0, 0, 0);           \
+                }                                                                                           \
+        }                                                                                                   \
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+
+    static_assert(W_16 % 512 == 0, "weight slab must be a whole number of 512-thread passes");
+    const int nch = a.nchunks;
+    HD_ISSUE_IN(0)
+    HD_ISSUE_W(0)
+    HD_WRITE_IN(ldsb)
+    HD_WRITE_W()
+    if (nch > 1) { HD_ISSUE_IN(1) HD_ISSUE_W(1) }
+    __syncthreads();
+    for (int ch = 0; ch < nch; ch++) {
+        unsigned char* cur = ldsb + (ch & 1) * INB;
+        unsigned char* oth = ldsb + ((ch & 1) ^ 1) * INB;
+        HD_TAPS(cur, 0, 4)
+        if (ch + 1 < nch) { HD_WRITE_IN(oth) }
+        if (ch + 2 < nch) { HD_ISSUE_IN(ch + 2) }
+        HD_TAPS(cur, 4, 9)
+        if (ch + 1 < nch) {
+            __syncthreads();
+            HD_WRITE_W()
+            if (ch + 2 < nch) { HD_ISSUE_W(ch + 2) }
+            __syncthreads();
+        }
+    }
+#undef HD_ISSUE_IN
+#undef HD_ISSUE_W
+#undef HD_WRITE_IN
+#undef HD_WRITE_W
+#undef HD_TAPS
+
+    // epilogue: deconv pixel (2oy+py, 2ox+px), channels c0..c0+3 (one PixelShuffle group c = c0>>2) -> 2x2 block of the flow tensor
+    const int oy = oy0 + wv, ox = ox0 + li;
+    const bool pok = oy < a.Ho && ox < a.Wo;
+#pragma unroll
+    for (int par = 0; par < 4; par++) {
+        const int py = par >> 1, px = par & 1;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {                      // 24 real channels: q = 3 would be channels 24..31 (padding)
+            const int c0 = 8 * q + 4 * half;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
+            const int c = c0 >> 2;
+            const int fy = 2 * (2 * oy + py), fx = 2 * (2 * ox + px);
+            if (pok) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    a.out[((size_t)(fy + (k >> 1)) * (4 * a.Wo) + fx + (k & 1)) * a.out_ld + a.out_coff + c] = acc[par][4 * q + k] + b4[k];
+            }
+        }
+    }
+}
+
+}  // namespace rife
