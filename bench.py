@@ -30,9 +30,39 @@ WORKLOADS = {
     "v23-1080p": ("rife-v2.3", 1920, 1080, 597.5, None, False, False),    # BASELINE config 2
     "4k-tta": ("rife-v4.6", 3840, 2160, 16 * 701.0, 16 * 0.701, True, True),   # BASELINE config 5 (-x -z) on one GPU
 }
-F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense v_mfma_f32_32x32x2_f32 peak
-DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_mfma_kernel<1,2,2,16,0,3> (IFNet block-3 trunk: 3x3 conv 64->64, skip folded, LeakyReLU)"),
-            "rife-v2.3": ("v2_flow_trunk_b3", "conv_mfma_kernel<1,2,3,8,0,0> (IFNet block-3 trunk: 3x3 conv 96->96 + PReLU)")}
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense v_mfma_f32_32x32x2_f32 peak
+F16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
+HBM_PEAK_TBPS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak
+# dominant kernel per family: (profile class, kernel symbol, channels C of the C->C 3x3 trunk conv, MFMA work factor of the
+# split-f16 scheme = 2 MFMAs per product (+ the identity tap of the folded skip connection for v4: 10/9))
+DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_h2b_kernel<2,10,3> (IFNet block-3 trunk: 3x3 conv 64->64 + skip + LeakyReLU, split-f16)", 64, 2.0 * 10 / 9),
+            "rife-v2.3": ("v2_flow_trunk_b3", "conv_h2_kernel<3,9,0> (IFNet block-3 trunk: 3x3 conv 96->96 + PReLU, split-f16)", 96, 2.0)}
+
+
+def roofline_of(dom, family, w, h, f32_mode):
+    """Roofline object for the dominant kernel from the live HIP-event timing of its launches.
+    Algorithmic bytes per launch: fp32 NHWC input + output of the C->C trunk conv at 1/4 of the padded
+    resolution + weights; algorithmic flops = 2*C*C*9 per output pixel."""
+    cls, name, C, mfma_factor = DOMINANT[family]
+    if not dom["launches"]:
+        return None
+    wp, hp = (w + 31) // 32 * 32, (h + 31) // 32 * 32
+    pix = (hp // 4) * (wp // 4)
+    bytes_launch = 2.0 * pix * C * 4 + C * C * 9 * 2
+    flops_launch = dom["flops"] / dom["launches"]
+    avg_ms = dom["ms"] / dom["launches"]
+    tflops = flops_launch / (avg_ms * 1e-3) / 1e12
+    tbps = bytes_launch / (avg_ms * 1e-3) / 1e12
+    if f32_mode:
+        return {"bound": "mfma", "kernel": name.replace("split-f16", "fp32 MFMA"), "achieved": round(tflops, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tflops / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "launches": dom["launches"], "flops_per_launch": flops_launch, "bytes_per_launch": bytes_launch}
+    # split-f16: arithmetic intensity 144-216 flop/B puts the HBM roof (8 TB/s) and the effective matrix roof
+    # (2.5 PF / mfma_factor) within a few % of each other; report against HBM (the SURVEY's fused-minimum roofline is HBM)
+    return {"bound": "hbm", "kernel": name, "achieved": round(tbps * 1e3, 1), "peak": HBM_PEAK_TBPS * 1e3, "unit": "GB/s",
+            "frac": round(tbps / HBM_PEAK_TBPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
+            "flops_per_launch": flops_launch, "bytes_per_launch": bytes_launch,
+            "algorithmic_tflops": round(tflops, 1), "mfma_frac_of_f16_peak": round(tflops * mfma_factor / F16_MFMA_PEAK_TFLOPS, 4)}
 
 
 def main():
@@ -96,18 +126,16 @@ def main():
 
     if rank == 0:
         # dominant kernel: the block-3 trunk conv of the IFNet (one shape per class, so flops per launch are well defined)
-        dom_cls, dom_name = DOMINANT[family]
-        dom = prof.get(dom_cls, dict(ms=0.0, launches=0, flops=0.0))
+        f32_mode = os.environ.get("RIFE_HIP_TRUNK", "") == "f32"
+        dom = prof.get(DOMINANT[family][0], dict(ms=0.0, launches=0, flops=0.0))
         conv_ms = sum(v["ms"] for k, v in prof.items() if v["flops"] > 0)
         all_ms = sum(v["ms"] for v in prof.values())
-        roof = None
-        if dom["launches"]:
-            avg_ms = dom["ms"] / dom["launches"]
-            ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom_name,
-                    "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
-                    "flops_per_launch": dom["flops"] / dom["launches"]}
+        roof = roofline_of(dom, family, w, h, f32_mode)
+        traffic_file = os.path.join(ROOT, "profiles", "r1", "pmc_%s.json" % args.workload)
+        if roof is not None and os.path.exists(traffic_file):
+            tf = json.load(open(traffic_file))                   # from the committed rocprofv3 --pmc passes (not live)
+            roof["traffic"] = tf["hbm_bytes_per_launch"]
+            roof["traffic_source"] = tf["source"]
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(modeldir, family, w * h, 16 if tta and tta_temporal else 1)
@@ -115,7 +143,8 @@ def main():
         line = {
             "metric": "interpolated frames/sec (%s, %dx%d%s)" % (family, w, h, " -x -z" if tta else ""), "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if f32_mode else "f16x2-split MFMA + f32 accumulate (fp32-equivalent; activations stored f32)", "data": "synthetic",
             "config": {"workload": "%s %dx%d%s frame pairs resident in HBM, timestep sweep %s, synthetic seeded weights" % (family, w, h, " -x -z (TTA)" if tta else "", timesteps),
                        "pairs_in_flight_per_gpu": nstreams, "parallelism": "frame pairs sharded over ranks, no data-path collective"},
             "roofline": roof,
