@@ -702,4 +702,135 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// conv_h2s2_kernel: 3x3 stride-2 convolution (the second stem conv of every IFBlock, c/2 -> c) on the split-f16 pipe.
+//   256 threads = 4 waves, tile = 4 x 32 outputs <- 9 x 65 input pixels per 16-channel chunk (46.8 KB) + weight slab;
+//   single LDS buffer, next chunk prefetched into registers (issue early / write late); two workgroups per CU.
+// ------------------------------------------------------------------------------------------------------------
+template <int NS>
+constexpr int convh2s2_lds_bytes() { return 9 * 65 * 80 + 9 * 2 * NS * 32 * 16; }
+
+template <int NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h2s2_kernel(ConvArgs a) {
+    constexpr int IH = 9, IW = 65, CC = 16, NT = NS * 32, PIXB = 80;
+    constexpr int IN_F4 = IH * IW * 4;
+    constexpr int W_16 = 9 * 2 * NT;
+    constexpr int NIN = (IN_F4 + 255) / 256, NW = (W_16 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char* const lw = ldsb + IH * IW * PIXB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int half = lane >> 5, li = lane & 31;
+    int L;
+    {
+        const int n = gridDim.x, b = blockIdx.x;
+        const int q = n >> 3, r = n & 7, xcd = b & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int tile = L / a.nz, ntile = L - tile * a.nz;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * 4, ox0 = tx * 32;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+
+    int goff[NIN];
+    unsigned inside = 0;
+#pragma unroll
+    for (int k = 0; k < NIN; k++) {
+        const int idx = tid + k * 256;
+        const int p = idx >> 2, q = idx & 3;
+        const int py = p / IW, px = p - py * IW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        const bool ok = idx < IN_F4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        goff[k] = ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff;
+        inside |= ok ? (1u << k) : 0u;
+    }
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk) + (size_t)ntile * a.nchunks * W_16;
+
+    f32x4 rin[NIN], rw[NW];
+#define S2_ISSUE(CH)                                                                                        \
+    {                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < NIN; k++) rin[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC); \
+        _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                    \
+            const int idx = tid + k * 256;                                                                  \
+            rw[k] = wsrc[(size_t)(CH) * W_16 + ((W_16 % 256 == 0 || idx < W_16) ? idx : 0)];                \
+        }                                                                                                   \
+    }
+#define S2_WRITE()                                                                                          \
+    {                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < NIN; k++) {                                                   \
+            const int idx = tid + k * 256;                                                                  \
+            const int p = idx >> 2, q = idx & 3;                                                            \
+            f16x4 hi4, lo4;                                                                                 \
+            _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                 \
+                const float v = ((inside >> k) & 1u) ? rin[k][e] : 0.f;                                     \
+                const _Float16 h = (_Float16)v;                                                             \
+                hi4[e] = h;                                                                                 \
+                lo4[e] = (_Float16)(v - (float)h);                                                          \
+            }                                                                                               \
+            if (IN_F4 % 256 == 0 || idx < IN_F4) {                                                          \
+                *reinterpret_cast<f16x4*>(ldsb + p * PIXB + q * 8) = hi4;                                   \
+                *reinterpret_cast<f16x4*>(ldsb + p * PIXB + 32 + q * 8) = lo4;                              \
+            }                                                                                               \
+        }                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                    \
+            const int idx = tid + k * 256;                                                                  \
+            if (W_16 % 256 == 0 || idx < W_16) reinterpret_cast<f32x4*>(lw)[idx] = rw[k];                   \
+        }                                                                                                   \
+    }
+
+    f32x16 acc[NS];
+#pragma unroll
+    for (int n = 0; n < NS; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+    const unsigned char* ab = ldsb + ((2 * wv) * IW + 2 * li) * PIXB + half * 16;
+    const unsigned char* bb = lw + (half * NT + li) * 16;
+
+    S2_ISSUE(0)
+    S2_WRITE()
+    __syncthreads();
+    for (int ch = 0; ch < a.nchunks; ch++) {
+        const bool more = ch + 1 < a.nchunks;
+        if (more) S2_ISSUE(ch + 1)
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int dy = t / 3, dx = t % 3;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB + 32);
+            f16x8 bw[NS];
+#pragma unroll
+            for (int n = 0; n < NS; n++) bw[n] = *reinterpret_cast<const f16x8*>(bb + (t * 2 * NT + n * 32) * 16);
+#pragma unroll
+            for (int n = 0; n < NS; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[n], ah, acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NS; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[n], al, acc[n], 0, 0, 0);
+        }
+        if (more) {
+            __syncthreads();
+            S2_WRITE()
+            __syncthreads();
+        }
+    }
+#undef S2_ISSUE
+#undef S2_WRITE
+
+    const int oy = oy0 + wv, ox = ox0 + li;
+    const bool pok = oy < a.Ho && ox < a.Wo;
+#pragma unroll
+    for (int n = 0; n < NS; n++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c0 = ntile * NT + n * 32 + 8 * q + 4 * half;
+            const bool ok = pok && c0 < a.Cout;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { v[k] = acc[n][4 * q + k] + b4[k]; v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k]; }
+            if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
+        }
+    }
+}
+
 }  // namespace rife

@@ -238,6 +238,16 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             L.nchunksh = 1;
         }
     }
+    if (!L.deconv && L.stride == 2 && L.epi == EPI_STORE && L.cin % 16 == 0 && L.cin >= 16) {      // stem-1 class: split-f16 stride-2 kernel
+        bool exact = true;
+        for (size_t i = 0; i < (size_t)L.cin * L.cout * 9 && exact; i++) exact = (float)(_Float16)w_orig[i] == w_orig[i];
+        if (exact) {
+            std::vector<uint16_t> ph = pack_weights_h2(L, w_orig, 9);
+            HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
+            HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
+            L.nchunksh = L.cin / 16;
+        }
+    }
     if (!L.deconv && L.stride == 1 && L.epi == EPI_STORE && L.NS >= 2 && L.cin % 16 == 0) {
         bool exact = true;   // the split-f16 path needs weights that are exactly fp16 (true for ncnn fp16-stored models)
         for (size_t i = 0; i < (size_t)L.cin * L.cout * 9 && exact; i++) {
@@ -276,6 +286,7 @@ struct TensorView { float* p; int ld, coff; };
 static const bool g_trunk_h2 = []() { const char* e = getenv("RIFE_HIP_TRUNK"); return !(e && std::strcmp(e, "f32") == 0); }();
 static const bool g_fuse_stem = []() { const char* e = getenv("RIFE_HIP_FUSE_STEM"); return !(e && e[0] == '0'); }();
 static const bool g_head_h2 = []() { const char* e = getenv("RIFE_HIP_HEAD_H2"); return !(e && e[0] == '0'); }();
+static const bool g_s2_h2 = []() { const char* e = getenv("RIFE_HIP_S2_H2"); return !(e && e[0] == '0'); }();
 static const bool g_h2b = []() { const char* e = getenv("RIFE_HIP_H2B"); return !(e && e[0] == '0'); }();   // A/B: 2-workgroup variant
 // RIFE_HIP_CONV8=0 disables the 8-wave trunk kernel (A/B measurements)
 static const bool g_use_conv8 = []() { const char* e = getenv("RIFE_HIP_CONV8"); return !(e && e[0] == '0'); }();
@@ -299,6 +310,29 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
     if (L.stride == 1) {
         const long wg2 = (long)a.tiles_x * ((a.Ho + 7) / 8) * a.nz;
         MS = wg2 >= 384 ? 2 : 1;
+    }
+    if (L.nchunksh > 0 && !L.deconv && L.stride == 2 && L.cin >= 16 && g_trunk_h2 && g_s2_h2 && res == nullptr) {
+        a.ntiles_xy = a.tiles_x * ((a.Ho + 3) / 4);
+        a.nchunks = L.nchunksh;
+        a.wpk = reinterpret_cast<const float*>(L.d_wh);
+        const int nb = a.ntiles_xy * a.nz;
+        constexpr int ls1 = convh2s2_lds_bytes<1>(), ls2 = convh2s2_lds_bytes<2>(), ls3 = convh2s2_lds_bytes<3>();
+        {
+            static std::mutex smu; static std::map<int, bool> sdone;
+            int dev = 0; (void)hipGetDevice(&dev);
+            std::lock_guard<std::mutex> g(smu);
+            if (!sdone[dev]) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2s2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, ls2));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2s2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, ls3));
+                sdone[dev] = true;
+            }
+        }
+        if (L.NS == 1) hipLaunchKernelGGL(conv_h2s2_kernel<1>, dim3(nb), dim3(256), ls1, st, a);
+        else if (L.NS == 2) hipLaunchKernelGGL(conv_h2s2_kernel<2>, dim3(nb), dim3(256), ls2, st, a);
+        else hipLaunchKernelGGL(conv_h2s2_kernel<3>, dim3(nb), dim3(256), ls3, st, a);
+        hipError_t eh = hipGetLastError();
+        if (eh != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_h2s2 launch: ") + hipGetErrorString(eh));
+        return 0;
     }
     if (L.nchunksh > 0 && L.deconv && g_trunk_h2 && g_head_h2) {
         a.ntiles_xy = a.tiles_x * ((a.Ho + 7) / 8);

@@ -113,3 +113,17 @@ def test_f16_mfma_keeps_subnormals():
     out = ctypes.c_float()
     assert L.rife_hip_probe_f16_denorm(0, ctypes.byref(out)) == 0
     assert out.value == 16 * 2.0 ** -20
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(32, 64, 36, 70), (48, 96, 24, 40), (96, 192, 18, 66), (64, 128, 10, 32), (16, 32, 12, 20)])
+def test_conv3x3_stride2_split_f16_path_matches_oracle(cin, cout, h, w):
+    """Stride-2 stem-1 class (c/2 -> c) with fp16-exact weights -> conv_h2s2_kernel."""
+    rng = np.random.default_rng(cin + cout)
+    x = (rng.standard_normal((cin, h, w)) * 2).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    want = pyoracle.conv2d(x, wt, b, stride=2, pad=1)
+    want = np.where(want < 0, want * np.float32(0.2), want)
+    got = amd.op_conv3x3(x, wt, b, stride=2, slope=np.full(cout, 0.2, np.float32))
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 4e-6 * np.abs(want).max() + 1e-6
