@@ -670,9 +670,9 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep) {
                 fdone[dev] = true;
             }
         }
-        if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(256), stemf_lds_bytes<2>(), st, fa);
-        else if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2>), dim3(nb), dim3(256), stemf_lds_bytes<2>(), st, fa);
-        else hipLaunchKernelGGL((stem0_fused_kernel<1, 1>), dim3(nb), dim3(256), stemf_lds_bytes<1>(), st, fa);
+        if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+        else if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+        else hipLaunchKernelGGL((stem0_fused_kernel<1, 1>), dim3(nb), dim3(512), stemf_lds_bytes<1>(), st, fa);
         HIPCHK(hipGetLastError());
     } else {
         if (b > 0 && (rc = run_assemble(E, c, b, timestep))) return rc;

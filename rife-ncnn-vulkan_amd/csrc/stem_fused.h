@@ -4,7 +4,8 @@
 // code of k_assemble), split into f16 hi/lo and written to LDS only; the convolution runs on the f16 matrix pipe with
 // fp32 accumulation (see conv_h2_kernel for the split-f16 scheme).  Saves writing and re-reading the 16-channel block
 // input (535 MB per pair for block 3 at 4K) and one launch.
-//   256 threads = 4 waves; tile = 4 x 32 outputs (stride 2) <- 9 x 65 input pixels; wave w owns output row w.
+//   512 threads = 8 waves: all of them gather the 9 x 65 halo tile (the kernel is gather-latency bound), then wave w
+//   computes output row w & 3 of the 4 x 32 tile for the N-subtile w >> 2 (waves 4-7 are idle in the tiny MFMA phase if NS = 1).
 #pragma once
 #include "conv_mfma.h"
 #include "elementwise.h"
@@ -26,7 +27,7 @@ template <int NS>
 constexpr int stemf_lds_bytes() { return 9 * 65 * 80 + 9 * 2 * NS * 32 * 16; }
 
 template <int S, int NS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void stem0_fused_kernel(StemFusedArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem0_fused_kernel(StemFusedArgs a) {
     constexpr int IH = 9, IW = 65, PIXB = 80, NT = NS * 32;
     constexpr int NPIX = IH * IW;
     constexpr int W_16 = 9 * 2 * NT;
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     unsigned char* const lw = ldsb + NPIX * PIXB;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv8 = tid >> 6;
+    const int wv = wv8 & 3, nsel = wv8 >> 2;          // output row, N-subtile of this wave
     const int half = lane >> 5, li = lane & 31;
     int L;
     {
@@ -48,10 +50,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     const int Hb = a.hp / S, Wb = a.wp / S;
 
     // weights -> LDS (one 16-channel chunk covers the 12 input channels)
-    for (int idx = tid; idx < W_16; idx += 256) reinterpret_cast<f32x4*>(lw)[idx] = reinterpret_cast<const f32x4*>(a.wpk)[idx];
+    for (int idx = tid; idx < W_16; idx += 512) reinterpret_cast<f32x4*>(lw)[idx] = reinterpret_cast<const f32x4*>(a.wpk)[idx];
 
     // block-input halo tile -> LDS as f16 hi | lo
-    for (int p = tid; p < NPIX; p += 256) {
+    for (int p = tid; p < NPIX; p += 512) {
         const int py = p / IW, px = p - py * IW;
         const int by = iy0 + py, bx = ix0 + px;
         float o[12];
@@ -75,42 +77,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
     __syncthreads();
 
-    f32x16 acc[NS];
+    if (nsel >= NS) return;                                // NS = 1: waves 4-7 only helped with the gather
+    f32x16 acc;
 #pragma unroll
-    for (int n = 0; n < NS; n++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
     const unsigned char* ab = ldsb + ((2 * wv) * IW + 2 * li) * PIXB + half * 16;
-    const unsigned char* bb = lw + (half * NT + li) * 16;
+    const unsigned char* bb = lw + (half * NT + nsel * 32 + li) * 16;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
         const int dy = t / 3, dx = t % 3;
         const f16x8 ah = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB);
         const f16x8 al = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB + 32);
-        f16x8 bw[NS];
-#pragma unroll
-        for (int n = 0; n < NS; n++) bw[n] = *reinterpret_cast<const f16x8*>(bb + (t * 2 * NT + n * 32) * 16);
-#pragma unroll
-        for (int n = 0; n < NS; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[n], ah, acc[n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < NS; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[n], al, acc[n], 0, 0, 0);
+        const f16x8 bw = *reinterpret_cast<const f16x8*>(bb + (t * 2 * NT) * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, ah, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, al, acc, 0, 0, 0);
     }
 
     const int oy = oy0 + wv, ox = ox0 + li;
     const bool pok = oy < a.Ho && ox < a.Wo;
 #pragma unroll
-    for (int n = 0; n < NS; n++) {
+    for (int q = 0; q < 4; q++) {
+        const int c0 = nsel * 32 + 8 * q + 4 * half;
+        const bool ok = pok && c0 < a.Cout;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
+        f32x4 v;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c0 = n * 32 + 8 * q + 4 * half;
-            const bool ok = pok && c0 < a.Cout;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
-            f32x4 v;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { v[k] = acc[n][4 * q + k] + b4[k]; v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k]; }
-            if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + c0) = v;
-        }
+        for (int k = 0; k < 4; k++) { v[k] = acc[4 * q + k] + b4[k]; v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k]; }
+        if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + c0) = v;
     }
 }
 
