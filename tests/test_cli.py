@@ -1,0 +1,78 @@
+"""The reference's command line (src/main.cpp) re-hosted on the HIP engine: schedule + validation on CPU, end to end on GPU."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+cli = importlib.import_module("rife-ncnn-vulkan_amd.cli")
+
+
+def test_schedule_default_doubles_frame_count():
+    """numframe = 2*count: outputs alternate t=0 (a copy of frame k) and t=0.5; the tail clamps to (count-2, 1.0)
+    (src/main.cpp:705-731)."""
+    s = cli.build_schedule(4, 0)
+    assert s == [(0, 0.0), (0, 0.5), (1, 0.0), (1, 0.5), (2, 0.0), (2, 0.5), (2, 1.0), (2, 1.0)]
+
+
+def test_schedule_arbitrary_count():
+    s = cli.build_schedule(3, 7)          # scale = 3/7
+    assert len(s) == 7 and s[0] == (0, 0.0)
+    for i, (sx, fx) in enumerate(s):
+        assert 0 <= sx <= 1 and 0.0 <= fx <= 1.0
+        if i * 3 / 7 < 2:
+            assert abs(sx + fx - i * 3 / 7) < 1e-6
+    assert s[-1] == (1, 1.0) or abs(s[-1][0] + s[-1][1] - 6 * 3 / 7) < 1e-6
+
+
+def test_family_from_dir_name():
+    assert cli.model_family("rife-v2.3") == (True, False)
+    assert cli.model_family("models/rife-v3.1") == (True, False)
+    assert cli.model_family("/x/rife-v4.6") == (False, True)
+    assert cli.model_family("rife-anime") == (False, False)
+    assert cli.model_family("other") is None
+
+
+def test_validation_errors(tmp_path, capsys):
+    assert cli.main([]) == -1
+    assert cli.main(["-0", "a.png", "-1", "b.png", "-o", "o.png", "-s", "1.5", "-m", "rife-v4.6"]) == -1      # timestep range
+    assert cli.main(["-0", "a.png", "-1", "b.png", "-o", "o.bmp", "-m", "rife-v4.6"]) == -1                   # extension
+    assert cli.main(["-0", "a.png", "-1", "b.png", "-o", "o.png", "-s", "0.3", "-m", "rife-v2.3"]) == -1      # only v4 takes -s
+    assert cli.main(["-0", "a.png", "-1", "b.png", "-o", "o.png", "-m", "nonsense"]) == -1                    # unknown family
+    assert cli.main(["-0", "a.png", "-1", "b.png", "-o", "o.png", "-j", "1:2,2:2", "-m", "rife-v4.6"]) == -1  # -j / -g mismatch
+
+
+@pytest.mark.gpu
+def test_cli_directory_mode_end_to_end(modeldirs, tmp_path):
+    from PIL import Image
+    from tools import gen_frames
+    amd = importlib.import_module("rife-ncnn-vulkan_amd")
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir(); outd.mkdir()
+    a, b = gen_frames.smooth_pair(96, 64, 5)
+    c, _ = gen_frames.smooth_pair(96, 64, 6)
+    frames = [a, b, c]
+    for i, f in enumerate(frames):
+        Image.fromarray(f).save(ind / ("%03d.png" % i))
+    rc = cli.main(["-i", str(ind), "-o", str(outd), "-m", modeldirs["rife-v4.6"], "-n", "5", "-j", "1:2:2", "-g", "0"])
+    assert rc == 0
+    outs = sorted(os.listdir(outd))
+    assert outs == ["%08d.png" % i for i in range(1, 6)]
+    g = amd.RIFE(0, rife_v4=True); g.load(modeldirs["rife-v4.6"])
+    for i, (sx, fx) in enumerate(cli.build_schedule(3, 5)):
+        got = np.asarray(Image.open(outd / ("%08d.png" % (i + 1))).convert("RGB"))
+        assert np.array_equal(got, g.process(frames[sx], frames[sx + 1], fx)), i
+
+
+@pytest.mark.gpu
+def test_cli_file_mode(modeldirs, tmp_path):
+    from PIL import Image
+    from tools import gen_frames
+    amd = importlib.import_module("rife-ncnn-vulkan_amd")
+    a, b = gen_frames.smooth_pair(64, 48, 9)
+    Image.fromarray(a).save(tmp_path / "a.png"); Image.fromarray(b).save(tmp_path / "b.png")
+    assert cli.main(["-0", str(tmp_path / "a.png"), "-1", str(tmp_path / "b.png"), "-o", str(tmp_path / "o.png"), "-m", modeldirs["rife-v2.3"]]) == 0
+    g = amd.RIFE(0, rife_v2=True); g.load(modeldirs["rife-v2.3"])
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "o.png").convert("RGB")), g.process(a, b, 0.5))
