@@ -92,9 +92,11 @@ def main():
     amd = importlib.import_module("rife-ncnn-vulkan_amd")
     from tools import gen_frames, gen_models
     family, w, h, gflop_pair, roofline_ms, tta, tta_temporal = WORKLOADS[args.workload]
-    modeldir = gen_models.ensure(None, family)
+    if rank == 0:
+        modeldir = gen_models.ensure(None, family)       # one writer; the other ranks wait, then find it complete
     if dist is not None:
         dist.barrier()
+    modeldir = gen_models.ensure(None, family)
     eng = amd.RIFE(local, tta_mode=tta, tta_temporal_mode=tta_temporal, rife_v2=family.startswith("rife-v2"), rife_v4=family.startswith("rife-v4"))
     eng.load(modeldir)
 

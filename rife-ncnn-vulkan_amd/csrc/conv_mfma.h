@@ -666,14 +666,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         unsigned char* cur = ldsb + (ch & 1) * INB;
         unsigned char* oth = ldsb + ((ch & 1) ^ 1) * INB;
         H2B_TAPS(cur, 0, NTAPS / 2)
-        if (ch + 1 < nch) { H2B_WRITE_IN(oth) }                 // input of chunk ch+1 (issued half a chunk + ago)
-        if (ch + 2 < nch) { H2B_ISSUE_IN(ch + 2) }
+        if (!(TAG & 2048) && ch + 1 < nch) { H2B_WRITE_IN(oth) }   // input of chunk ch+1 (issued half a chunk + ago)
+        if (!(TAG & 512) && ch + 2 < nch) { H2B_ISSUE_IN(ch + 2) }
         H2B_TAPS(cur, NTAPS / 2, NTAPS)
         if (ch + 1 < nch) {
-            __syncthreads();                                    // everyone is done with the weight slab of chunk ch
-            H2B_WRITE_W()
-            if (ch + 2 < nch) { H2B_ISSUE_W(ch + 2) }
-            __syncthreads();
+            if (!(TAG & 1024)) __syncthreads();                 // everyone is done with the weight slab of chunk ch
+            if (!(TAG & 2048)) { H2B_WRITE_W() }
+            if (!(TAG & 512) && ch + 2 < nch) { H2B_ISSUE_W(ch + 2) }
+            if (!(TAG & 1024)) __syncthreads();
         }
     }
 #undef H2B_ISSUE_IN
@@ -697,7 +697,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int k = 0; k < 4; k++) v[k] = acc[n][4 * q + k] + b4[k];
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k];
-            if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
+            if (TAG & 256) { if (v[0] == 123.456f) a.out[0] = v[1]; }   // ablation: keep alive, (almost) never store
+            else if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
         }
     }
 }

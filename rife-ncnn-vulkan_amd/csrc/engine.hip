@@ -1425,6 +1425,50 @@ int rife_hip_probe_f16_denorm(int gpuid, float* out) {
     return 0;
 }
 
+// bench-only: ablations of the split-f16 trunk kernel (variant bits: 256 no stores, 512 no prefetch loads, 1024 no barriers,
+// 2048 no LDS staging writes after the first chunk; all but 0/256 compute garbage — timing only)
+int rife_hip_bench_h2b(int gpuid, int h, int w, int variant, int iters, float* ms_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    const int c = 64;
+    std::vector<float> wts((size_t)c * c * 9, 0.0078125f), bias(c, 0.f);
+    ConvLayer L; L.cin = c; L.cout = c; L.stride = 1; L.epi = EPI_STORE; L.skip = true;
+    if ((rc = upload_layer(L, wts.data(), bias.data(), nullptr, 0.2f))) return rc;
+    float *x = nullptr, *y = nullptr;
+    HIPCHK(hipMalloc(&x, (size_t)h * w * c * 4)); HIPCHK(hipMalloc(&y, (size_t)h * w * c * 4));
+    HIPCHK(hipMemset(x, 0, (size_t)h * w * c * 4));
+    ConvArgs a;
+    a.in = x; a.in_ld = c; a.in_coff = 0; a.H = h; a.W = w; a.out = y; a.out_ld = c; a.out_coff = 0;
+    a.wpk = reinterpret_cast<const float*>(L.d_wh); a.bias = L.d_bias; a.slope = L.d_slope; a.res = nullptr; a.res_ld = 0; a.res_coff = 0;
+    a.Ho = h; a.Wo = w; a.Cout = c; a.nchunks = L.nchunksh; a.nz = 1; a.tiles_x = (w + 31) / 32; a.ntiles_xy = a.tiles_x * ((h + 7) / 8);
+    constexpr int lds = convh2b_lds_bytes<2, 10>();
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](auto kfn) -> int {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(a.ntiles_xy), dim3(512), lds, 0, a);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kfn, dim3(a.ntiles_xy), dim3(512), lds, 0, a);
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    switch (variant) {
+        case 0: rc = run(conv_h2b_kernel<2, 10, 4096>); break;
+        case 256: rc = run(conv_h2b_kernel<2, 10, 4096 + 256>); break;
+        case 512: rc = run(conv_h2b_kernel<2, 10, 4096 + 512>); break;
+        case 1024: rc = run(conv_h2b_kernel<2, 10, 4096 + 1024>); break;
+        case 2048: rc = run(conv_h2b_kernel<2, 10, 4096 + 2048>); break;
+        case 2560: rc = run(conv_h2b_kernel<2, 10, 4096 + 2560>); break;
+        case 2816: rc = run(conv_h2b_kernel<2, 10, 4096 + 2816>); break;
+        case 3840: rc = run(conv_h2b_kernel<2, 10, 4096 + 3840>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    (void)hipFree(x); (void)hipFree(y); free_layer(L);
+    return rc;
+}
+
 // tooling: structural hash of a named blob of a .param file (used to derive / test the compiled-in constants)
 int rife_hip_param_hash(const char* param_path, const char* blob, uint64_t* out) {
     NcnnModel m;

@@ -153,3 +153,14 @@ def test_tta_differs_from_plain(engines, modeldirs):
     gt.load(modeldirs["rife-v4.6"])
     a, b = gen_frames.smooth_pair(96, 64, 5)
     assert not np.array_equal(g.process(a, b, 0.5), gt.process(a, b, 0.5))
+
+
+def test_4k_within_1_lsb(engines):
+    """BASELINE config 4 size (3840x2160 -> padded 3840x2176), the size of the north-star target."""
+    g, o = engines
+    a, b = gen_frames.smooth_pair(960, 540, 3000)
+    a = np.ascontiguousarray(np.kron(a, np.ones((4, 4, 1), np.uint8)))       # cheap 4x upsample keeps the test fast to set up
+    b = np.ascontiguousarray(np.kron(np.roll(b, 2, axis=1), np.ones((4, 4, 1), np.uint8)))
+    mx, f0, f1, psnr = lsb_report(g.process(a, b, 0.5), o.process(a, b, 0.5))
+    assert mx <= 1, (mx, f0, f1, psnr)
+    assert f0 > 0.97
