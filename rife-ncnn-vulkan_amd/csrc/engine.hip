@@ -162,25 +162,26 @@ static bool head_uses_h(int t, int par) {
     return (dy == 0 || dy == (py ? 1 : -1)) && (dx == 0 || dx == (px ? 1 : -1));
 }
 
-// v4 head (Deconvolution C -> 24, k4 s2 p1) for head_h2_kernel: fp16 [chunk][(tap, parity) pair 16][half][n 32][8].
+// Deconvolution (k4 s2 p1) for head_h2_kernel: fp16 [ntile of 32 channels][chunk][(tap, parity) pair 16][half][n 32][8].
 // Kernel row for (parity p, offset d): p=0: d=0 -> k=1, d=-1 -> k=3;  p=1: d=0 -> k=2, d=+1 -> k=0.
 static std::vector<uint16_t> pack_weights_head_h2(const ConvLayer& L, const float* w) {
-    const int nch = L.cin / 16;
-    std::vector<uint16_t> out((size_t)nch * 16 * 2 * 32 * 8, 0);
+    const int nch = L.cin / 16, nt32 = (L.cout + 31) / 32;
+    std::vector<uint16_t> out((size_t)nt32 * nch * 16 * 2 * 32 * 8, 0);
     size_t o = 0;
-    for (int ch = 0; ch < nch; ch++)
-        for (int t = 0; t < 9; t++)
-            for (int par = 0; par < 4; par++) {
-                if (!head_uses_h(t, par)) continue;
-                const int dy = t / 3 - 1, dx = t % 3 - 1, py = par >> 1, px = par & 1;
-                const int ky = dy == 0 ? (py ? 2 : 1) : (py ? 0 : 3), kx = dx == 0 ? (px ? 2 : 1) : (px ? 0 : 3);
-                for (int half = 0; half < 2; half++)
-                    for (int n = 0; n < 32; n++)
-                        for (int e = 0; e < 8; e++, o++) {
-                            const int c = ch * 16 + half * 8 + e;
-                            if (n < L.cout) out[o] = f2h(w[(((size_t)n * L.cin + c) * 4 + ky) * 4 + kx]);
-                        }
-            }
+    for (int nt = 0; nt < nt32; nt++)
+        for (int ch = 0; ch < nch; ch++)
+            for (int t = 0; t < 9; t++)
+                for (int par = 0; par < 4; par++) {
+                    if (!head_uses_h(t, par)) continue;
+                    const int dy = t / 3 - 1, dx = t % 3 - 1, py = par >> 1, px = par & 1;
+                    const int ky = dy == 0 ? (py ? 2 : 1) : (py ? 0 : 3), kx = dx == 0 ? (px ? 2 : 1) : (px ? 0 : 3);
+                    for (int half = 0; half < 2; half++)
+                        for (int n = 0; n < 32; n++)
+                            for (int e = 0; e < 8; e++, o++) {
+                                const int c = ch * 16 + half * 8 + e, oc = nt * 32 + n;
+                                if (oc < L.cout) out[o] = f2h(w[(((size_t)oc * L.cin + c) * 4 + ky) * 4 + kx]);
+                            }
+                }
     return out;
 }
 
@@ -218,7 +219,7 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             L.nchunks8 = T.nchunks;
         }
     }
-    if (L.deconv && L.epi == EPI_DECONV_PS && L.cout == 24 && L.cin % 16 == 0) {   // v4 heads: split-f16 kernel, 4 parities per workgroup
+    if (L.deconv && L.cin % 16 == 0 && L.cout % 4 == 0) {   // transposed convs: split-f16 kernel, 4 parities per workgroup, 32-channel N-tiles
         bool exact = true;
         for (size_t i = 0; i < (size_t)L.cin * L.cout * 16 && exact; i++) exact = (float)(_Float16)w_orig[i] == w_orig[i];
         if (exact) {
@@ -248,7 +249,7 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             L.nchunksh = L.cin / 16;
         }
     }
-    if (!L.deconv && L.stride == 1 && L.epi == EPI_STORE && L.NS >= 2 && L.cin % 16 == 0) {
+    if (!L.deconv && L.stride == 1 && L.epi == EPI_STORE && L.cin % 16 == 0) {
         bool exact = true;   // the split-f16 path needs weights that are exactly fp16 (true for ncnn fp16-stored models)
         for (size_t i = 0; i < (size_t)L.cin * L.cout * 9 && exact; i++) {
             const uint16_t h = f2h(w_orig[i]);
@@ -337,17 +338,23 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
     if (L.nchunksh > 0 && L.deconv && g_trunk_h2 && g_head_h2) {
         a.ntiles_xy = a.tiles_x * ((a.Ho + 7) / 8);
         a.nchunks = L.nchunksh;
+        a.nz = (L.cout + 31) / 32;
         a.wpk = reinterpret_cast<const float*>(L.d_wh);
         {
             static std::mutex hmu; static std::map<int, bool> hdone;
             int dev = 0; (void)hipGetDevice(&dev);
             std::lock_guard<std::mutex> g(hmu);
             if (!hdone[dev]) {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_DECONV_PS>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_DECONV>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_DECONV_SIG>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
                 hdone[dev] = true;
             }
         }
-        hipLaunchKernelGGL(head_h2_kernel<0>, dim3(a.ntiles_xy), dim3(512), headh2_lds_bytes(), st, a);
+        const int nb = a.ntiles_xy * a.nz;
+        if (L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_PS>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a);
+        else if (L.epi == EPI_DECONV) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a);
+        else hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_SIG>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a);
         hipError_t eh = hipGetLastError();
         if (eh != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("head_h2 launch: ") + hipGetErrorString(eh));
         return 0;
@@ -379,12 +386,15 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
             std::lock_guard<std::mutex> g(bmu);
             if (!bdone[dev]) {
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 9, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb9));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<1, 9, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, convh2b_lds_bytes<1, 9>()));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb10));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lb10));
                 bdone[dev] = true;
             }
         }
-        if (g_h2b && L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 3>), dim3(nb), dim3(512), lb10, st, a);
+        constexpr int lb19 = convh2b_lds_bytes<1, 9>();
+        if (L.NS == 1) hipLaunchKernelGGL((conv_h2b_kernel<1, 9, 0>), dim3(nb), dim3(512), lb19, st, a);
+        else if (g_h2b && L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 3>), dim3(nb), dim3(512), lb10, st, a);
         else if (g_h2b && L.NS == 2 && L.skip) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 0>), dim3(nb), dim3(512), lb10, st, a);
         else if (g_h2b && L.NS == 2) hipLaunchKernelGGL((conv_h2b_kernel<2, 9, 0>), dim3(nb), dim3(512), lb9, st, a);
         else if (L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2_kernel<2, 10, 3>), dim3(nb), dim3(512), l210, st, a);

@@ -31,7 +31,9 @@ __device__ __forceinline__ constexpr int head_pair_index(int t, int par) {   // 
 
 constexpr int headh2_lds_bytes() { return 2 * 10 * 34 * 80 + 16 * 2 * 32 * 16; }
 
-template <int TAG>
+// EPI: EPI_DECONV_PS (v4 heads: + PixelShuffle scatter, 24 channels), EPI_DECONV (+ per-channel slope, NHWC store at
+// (2y+py, 2x+px)), EPI_DECONV_SIG (sigmoid).  Output channels are tiled by 32 over the grid (a.nz N-tiles per pixel tile).
+template <int EPI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void head_h2_kernel(ConvArgs a) {
     constexpr int IH = 10, IW = 34, CC = 16, NT = 32;
     constexpr int PIXB = 80;
@@ -51,7 +53,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int q = n >> 3, r = n & 7, xcd = b & 7;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
-    const int ty = L / a.tiles_x, tx = L - ty * a.tiles_x;
+    const int tile = L / a.nz, ntile = L - tile * a.nz;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int oy0 = ty * 8, ox0 = tx * 32;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
 
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         goff[k] = ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff;
         inside |= ok ? (1u << k) : 0u;
     }
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk);
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk) + (size_t)ntile * a.nchunks * W_16;
 
     f32x4 rin[NIN], rw[NW];
 #define HD_ISSUE_IN(CH)                                                                                     \
@@ -141,22 +144,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef HD_WRITE_W
 #undef HD_TAPS
 
-    // epilogue: deconv pixel (2oy+py, 2ox+px), channels c0..c0+3 (one PixelShuffle group c = c0>>2) -> 2x2 block of the flow tensor
+    // epilogue: deconv pixel (2oy+py, 2ox+px), channels c0..c0+3 of this 32-wide N-tile
     const int oy = oy0 + wv, ox = ox0 + li;
     const bool pok = oy < a.Ho && ox < a.Wo;
 #pragma unroll
     for (int par = 0; par < 4; par++) {
         const int py = par >> 1, px = par & 1;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {                      // 24 real channels: q = 3 would be channels 24..31 (padding)
-            const int c0 = 8 * q + 4 * half;
+        for (int q = 0; q < 4; q++) {
+            const int c0 = ntile * 32 + 8 * q + 4 * half;
+            const bool ok = pok && c0 < a.Cout;
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
-            const int c = c0 >> 2;
-            const int fy = 2 * (2 * oy + py), fx = 2 * (2 * ox + px);
-            if (pok) {
+            f32x4 v;
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    a.out[((size_t)(fy + (k >> 1)) * (4 * a.Wo) + fx + (k & 1)) * a.out_ld + a.out_coff + c] = acc[par][4 * q + k] + b4[k];
+            for (int k = 0; k < 4; k++) v[k] = acc[par][4 * q + k] + b4[k];
+            if (EPI == EPI_DECONV_PS) {          // one PixelShuffle group c = c0>>2 -> a 2x2 block of the flow tensor [4H][4W][8]
+                const int c = c0 >> 2;
+                const int fy = 2 * (2 * oy + py), fx = 2 * (2 * ox + px);
+                if (ok) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) a.out[((size_t)(fy + (k >> 1)) * (4 * a.Wo) + fx + (k & 1)) * a.out_ld + a.out_coff + c] = v[k];
+                }
+            } else {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = EPI == EPI_DECONV_SIG ? 1.f / (1.f + expf(-v[k])) : (v[k] < 0.f ? v[k] * s4[k] : v[k]);
+                if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)(2 * oy + py) * (2 * a.Wo) + 2 * ox + px) * a.out_ld + a.out_coff + c0) = v;
             }
         }
     }

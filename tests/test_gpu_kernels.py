@@ -127,3 +127,32 @@ def test_conv3x3_stride2_split_f16_path_matches_oracle(cin, cout, h, w):
     got = amd.op_conv3x3(x, wt, b, stride=2, slope=np.full(cout, 0.2, np.float32))
     assert got.shape == want.shape
     assert np.abs(got - want).max() <= 4e-6 * np.abs(want).max() + 1e-6
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 24, 16, 40), (1024, 256, 5, 9), (128, 32, 20, 33), (32, 4, 12, 20), (256, 64, 9, 17)])
+def test_deconv4x4_split_f16_path_matches_oracle(cin, cout, h, w):
+    """fp16-exact weights route transposed convs to head_h2_kernel (4 parities per workgroup, 32-channel N-tiles),
+    with per-channel PReLU slopes (v2.3 FusionNet up path)."""
+    rng = np.random.default_rng(cin * 3 + cout)
+    x = (rng.standard_normal((cin, h, w)) * 2).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 4, 4)) / np.sqrt(cin * 4)).astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    slope = rng.uniform(-0.5, 1.0, cout).astype(np.float32)
+    want = pyoracle.deconv2d(x, wt, b)
+    want = np.where(want < 0, want * slope[:, None, None], want)
+    got = amd.op_deconv4x4(x, wt, b, slope=slope)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 4e-6 * np.abs(want).max() + 1e-6
+
+
+def test_conv3x3_32ch_split_f16_path():
+    """32 -> 32 stride-1 (v2.3 ContextNet / FusionNet) now also takes the split-f16 kernel (NS = 1)."""
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((32, 30, 50)).astype(np.float32)
+    wt = (rng.standard_normal((32, 32, 3, 3)) / 17).astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    slope = rng.uniform(0, 0.5, 32).astype(np.float32)
+    want = pyoracle.conv2d(x, wt, b, stride=1, pad=1)
+    want = np.where(want < 0, want * slope[:, None, None], want)
+    got = amd.op_conv3x3(x, wt, b, stride=1, slope=slope)
+    assert np.abs(got - want).max() <= 4e-6 * np.abs(want).max() + 1e-6
