@@ -573,11 +573,17 @@ struct rife_hip {
     mutable std::map<void*, std::unique_ptr<Ctx>> stream_ctx;            // one workspace per caller stream
     mutable std::mutex tta_mu;                                           // TTA passes share one set of workspaces
     mutable std::unique_ptr<Ctx> tta_ctx[2][8];                          // [direction][orientation]
+    static constexpr int NLANE = 4;                                      // spatial TTA: orientations run on 4 worker streams
+    mutable hipStream_t tta_lane[NLANE] = {nullptr, nullptr, nullptr, nullptr};
+    mutable hipEvent_t tta_fork[6] = {}, tta_join[6][NLANE] = {};
 
     ~rife_hip() {
         (void)hipSetDevice(gpuid);
         free_ctx.clear(); stream_ctx.clear();
         for (auto& d : tta_ctx) for (auto& c : d) c.reset();
+        for (auto& l : tta_lane) if (l) (void)hipStreamDestroy(l);
+        for (auto& e : tta_fork) if (e) (void)hipEventDestroy(e);
+        for (auto& r : tta_join) for (auto& e : r) if (e) (void)hipEventDestroy(e);
         for (auto& b : blk) { free_layer(b.stem0); free_layer(b.stem1); for (auto& r : b.res) free_layer(r); free_layer(b.head); }
         for (auto& b : fblk) { free_layer(b.stem0); free_layer(b.stem1); for (auto& r : b.conv) free_layer(r); free_layer(b.head); }
         for (auto& l : ctxc) free_layer(l);
@@ -747,18 +753,46 @@ static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
 static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, const uint8_t* d_in1, int w, int h, float timestep, uint8_t* d_out) {
     const int nori = E.tta ? 8 : 1, ntemp = E.tta_temporal ? 2 : 1;
     const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;
+    constexpr int NL = rife_hip::NLANE;
+    const bool lanes = nori == 8;          // the 8 orientations are independent between consensus points: 4 worker streams
     int rc;
+    if (lanes && !E.tta_lane[0]) {
+        for (int l = 0; l < NL; l++) HIPCHK(hipStreamCreateWithFlags(&E.tta_lane[l], hipStreamNonBlocking));
+        for (int i = 0; i < 6; i++) {
+            HIPCHK(hipEventCreateWithFlags(&E.tta_fork[i], hipEventDisableTiming));
+            for (int l = 0; l < NL; l++) HIPCHK(hipEventCreateWithFlags(&E.tta_join[i][l], hipEventDisableTiming));
+        }
+    }
+    auto lane_of = [&](int ti) { return lanes ? E.tta_lane[ti % NL] : st; };
     for (int dir = 0; dir < ntemp; dir++)
         for (int ti = 0; ti < nori; ti++) {
             auto& up = E.tta_ctx[dir][ti];
             if (!up) up.reset(new Ctx);
             Ctx& c = *up;
-            c.stream = st;
+            c.stream = lane_of(ti);
             const bool swap = ti >= 4;
-            const Ctx* scratch = (dir == 0 && ti == 0) ? nullptr : E.tta_ctx[0][0].get();
+            // per-layer scratch is shared by the passes of one lane (they run back to back on that lane's stream)
+            const int owner = lanes ? ti % NL : 0;
+            const Ctx* scratch = (dir == 0 && ti == owner) ? nullptr : E.tta_ctx[0][owner].get();
             if ((rc = ensure_ctx_dims(c, swap ? h : w, swap ? w : h, swap ? hp : wp, swap ? wp : hp, scratch, dir == 0, true))) return rc;
             if (dir == 1) { c.img0 = E.tta_ctx[0][ti]->img1; c.img1 = E.tta_ctx[0][ti]->img0; }   // reversed pass sees the frames swapped
         }
+    int sync_id = 0;
+    auto fork = [&]() -> int {             // lanes wait for everything enqueued on the caller's stream so far
+        if (!lanes) return 0;
+        HIPCHK(hipEventRecord(E.tta_fork[sync_id], st));
+        for (int l = 0; l < NL; l++) HIPCHK(hipStreamWaitEvent(E.tta_lane[l], E.tta_fork[sync_id], 0));
+        return 0;
+    };
+    auto join = [&]() -> int {             // the caller's stream waits for all lanes
+        if (!lanes) return 0;
+        for (int l = 0; l < NL; l++) {
+            HIPCHK(hipEventRecord(E.tta_join[sync_id][l], E.tta_lane[l]));
+            HIPCHK(hipStreamWaitEvent(st, E.tta_join[sync_id][l], 0));
+        }
+        sync_id++;
+        return 0;
+    };
     {
         Timed t(E.prof, "preproc", 0, st);
         dim3 g = grid2d(wp, hp);
@@ -776,19 +810,22 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
     static const int SC[4] = {8, 4, 2, 1};
     for (int fi = 0; fi < 4; fi++) {
         const int Wf = wp / SC[fi], Hf = hp / SC[fi];
+        if ((rc = fork())) return rc;
         for (int ti = 0; ti < nori; ti++) {
+            hipStream_t ls = lane_of(ti);
             for (int dir = 0; dir < ntemp; dir++) {
                 Ctx& c = *E.tta_ctx[dir][ti];
                 if ((rc = run_block_convs(E, c, fi, dir ? 1.f - timestep : timestep))) return rc;
             }
             if (ntemp == 2) {
-                Timed t(E.prof, "tta_merge", 0, st);
+                Timed t(E.prof, "tta_merge", 0, ls);
                 const size_t npix = (size_t)Wf * Hf;
-                hipLaunchKernelGGL(k_v4_temporal_merge, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st,
+                hipLaunchKernelGGL(k_v4_temporal_merge, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ls,
                                    E.tta_ctx[0][ti]->flow[fi], E.tta_ctx[1][ti]->flow[fi], npix);
                 HIPCHK(hipGetLastError());
             }
         }
+        if ((rc = join())) return rc;
         if (nori == 8) {
             Timed t(E.prof, "tta_merge", 0, st);
             for (int dir = 0; dir < ntemp; dir++) {
@@ -798,21 +835,30 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
             }
             HIPCHK(hipGetLastError());
         }
-        if (fi < 3)
+        if (fi < 3) {
+            if (fi == 2) { /* the fork at the top of the next stage covers it */ }
+            if (lanes) {   // flow updates run on the lanes; they must see the consensus written on the caller's stream
+                HIPCHK(hipEventRecord(E.tta_fork[5], st));
+                for (int l = 0; l < NL; l++) HIPCHK(hipStreamWaitEvent(E.tta_lane[l], E.tta_fork[5], 0));
+            }
             for (int ti = 0; ti < nori; ti++)
                 for (int dir = 0; dir < ntemp; dir++)
                     if ((rc = run_flow_update(E, *E.tta_ctx[dir][ti], fi))) return rc;
+        }
     }
     Ptr16 outs;
     for (int i = 0; i < 16; i++) outs.p[i] = nullptr;
     {
-        Timed t(E.prof, "final", 0, st);
+        if ((rc = fork())) return rc;
         for (int ti = 0; ti < nori; ti++)
             for (int dir = 0; dir < ntemp; dir++) {
                 Ctx& c = *E.tta_ctx[dir][ti];
-                hipLaunchKernelGGL(k_final_float, grid2d(c.wp, c.hp), dim3(256), 0, st, c.img0, c.img1, c.F, c.M, c.flow[3], c.outf, c.wp, c.hp);
+                Timed t(E.prof, "final", 0, c.stream);
+                hipLaunchKernelGGL(k_final_float, grid2d(c.wp, c.hp), dim3(256), 0, c.stream, c.img0, c.img1, c.F, c.M, c.flow[3], c.outf, c.wp, c.hp);
                 outs.p[dir * 8 + ti] = c.outf;
             }
+        if ((rc = join())) return rc;
+        Timed t(E.prof, "final", 0, st);
         hipLaunchKernelGGL(k_postproc_tta, grid2d(w, h), dim3(256), 0, st, outs, nori, ntemp, d_out, w, h, wp, hp);
         HIPCHK(hipGetLastError());
     }
@@ -1186,8 +1232,10 @@ int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1
     if (!rc) {
         if (!E->v4) rc = run_v2(*E, *c, c->d_in0, c->d_in1, c->d_out);
         else if (E->tta || E->tta_temporal) {
+            // the TTA workspaces are shared by all callers: serialise, and drain before the next caller may reuse them
             std::lock_guard<std::mutex> g(E->tta_mu);
             rc = run_v4_tta(*E, c->stream, c->d_in0, c->d_in1, w, h, timestep, c->d_out);
+            if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "TTA stream sync failed");
         } else rc = run_v4(*E, *c, c->d_in0, c->d_in1, timestep, c->d_out);
     }
     if (!rc) {
