@@ -117,12 +117,32 @@ def main():
         a, b = frames[i % nfr], frames[(i + 1) % nfr]
         eng.process_device(a.data_ptr(), b.data_ptr(), w, h, timesteps[i % len(timesteps)], outs[s].data_ptr(), streams[s].cuda_stream)
 
+    import threading
+
+    def run_steps(first, count):
+        """`count` steps starting at index `first`; with S > 1 pairs in flight each stream is driven by its own host thread,
+        exactly like the reference's proc threads (src/main.cpp:849-866; the C-ABI call releases the GIL)."""
+        S = len(streams)
+        if S == 1:
+            for i in range(first, first + count):
+                step(i)
+            return
+
+        def worker(s):
+            torch.cuda.set_device(local)
+            for i in range(first, first + count):
+                if i % S == s:
+                    step(i)
+        th = [threading.Thread(target=worker, args=(s,)) for s in range(S)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+
     sh = importlib.import_module("rife-ncnn-vulkan_amd.sharding")
     for i in range(args.warmup):
         step(i)
     sh.barrier(dist, torch.cuda.synchronize)
-    eng.profile_enable(True)
-    elapsed = sh.timed_steps(step, args.steps, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
+    eng.profile_enable(os.environ.get("RIFE_BENCH_NOPROF", "") == "")
+    elapsed = sh.timed_steps(lambda i: run_steps(i, args.steps), 1, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
                              make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
     prof = eng.profile_read()
     eng.profile_enable(False)

@@ -56,6 +56,9 @@ struct ConvArgs {
     int nchunks;           // Cin_padded / CC
     int nz;                // n-tiles x parities
     int tiles_x, ntiles_xy;
+    int nsplit = 1;        // split-K: the K chunks are divided among nsplit workgroups per (tile, n-tile) ...
+    float* partial = nullptr;   // ... which write raw accumulators to partial[split][pixel][Cpad] (reduced by k_splitk_reduce)
+    int cpad = 0;
 };
 
 template <int STRIDE, int MS> struct ConvGeom {
@@ -583,10 +586,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int q = n >> 3, r = n & 7, xcd = b & 7;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
-    const int tile = L / a.nz, ntile = L - tile * a.nz;
+    const int split = L % a.nsplit;                    // split-K slice of this workgroup (fastest index: the slices of a tile share an XCD)
+    const int L2 = L / a.nsplit;
+    const int tile = L2 / a.nz, ntile = L2 - tile * a.nz;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int oy0 = ty * 8, ox0 = tx * 32;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int chunks_per = (a.nchunks + a.nsplit - 1) / a.nsplit;
+    const int chb = split * chunks_per;                // first chunk of this slice
+    const int nch = min(chunks_per, a.nchunks - chb);
 
     int goff[NIN];
     unsigned inside = 0;
@@ -597,10 +605,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int py = p / IW, px = p - py * IW;
         const int gy = iy0 + py, gx = ix0 + px;
         const bool ok = idx < IN_F4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        goff[k] = ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff;
+        goff[k] = (ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff) + chb * CC;
         inside |= ok ? (1u << k) : 0u;
     }
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk) + (size_t)ntile * a.nchunks * W_16;
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk) + ((size_t)ntile * a.nchunks + chb) * W_16;
 
     f32x4 rin[NIN], rw[NW];
 #define H2B_ISSUE_IN(CH)                                                                                    \
@@ -655,7 +663,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
 
-    const int nch = a.nchunks;
     H2B_ISSUE_IN(0)
     H2B_ISSUE_W(0)
     H2B_WRITE_IN(ldsb)
@@ -693,6 +700,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
             const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
             f32x4 v;
+            if (a.nsplit > 1) {                             // raw partial sums; bias / activation happen in k_splitk_reduce
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = acc[n][4 * q + k];
+                if (ok) *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.Ho * a.Wo + (size_t)oy * a.Wo + ox) * a.cpad + c0) = v;
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = acc[n][4 * q + k] + b4[k];
 #pragma unroll
@@ -832,6 +845,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
         }
     }
+}
+
+// split-K reduction: out = slope(sum over splits (fixed order) + bias), 4 channels per thread
+__global__ void k_splitk_reduce(const float* __restrict__ partial, int nsplit, size_t npix, int cpad, int cout, const float* __restrict__ bias,
+                                const float* __restrict__ slope, float* __restrict__ out, int out_ld, int out_coff) {
+    const int nq = cout / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * nq) return;
+    const size_t p = i / nq; const int c0 = (int)(i - p * nq) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(partial + p * cpad + c0);
+    for (int s = 1; s < nsplit; s++) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(partial + ((size_t)s * npix + p) * cpad + c0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] += t[k];
+    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + c0), s4 = *reinterpret_cast<const f32x4*>(slope + c0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] += b4[k]; v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k]; }
+    *reinterpret_cast<f32x4*>(out + p * out_ld + out_coff + c0) = v;
 }
 
 }  // namespace rife
