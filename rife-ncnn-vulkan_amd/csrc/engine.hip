@@ -73,7 +73,8 @@ static void free_layer(ConvLayer& L) {
 
 // Choose the kernel configuration for a layer (see conv_mfma.h for the meaning of MS / NS / CC).
 static void configure(ConvLayer& L) {
-    const int NT = L.cout <= 32 ? 32 : (L.cout % 64 == 0 ? 64 : (L.cout % 96 == 0 ? 96 : 64));
+    static const bool nt96 = []() { const char* e = getenv("RIFE_HIP_NT96"); return !(e && e[0] == '0'); }();   // A/B: 96-wide N tiles vs 3 x 32
+    const int NT = L.cout <= 32 ? 32 : (L.cout % 64 == 0 ? 64 : (L.cout % 96 == 0 ? (nt96 ? 96 : 32) : 64));
     L.NS = NT / 32;
     L.ntiles = (L.cout + NT - 1) / NT;
     if (L.stride == 2) { L.MS = 1; L.CC = 8; }
@@ -403,6 +404,7 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
             if (!bdone[dev]) {
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 9, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb9));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<1, 9, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, convh2b_lds_bytes<1, 9>()));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<1, 10, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, convh2b_lds_bytes<1, 10>()));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb10));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lb10));
                 bdone[dev] = true;
@@ -422,7 +424,9 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         }
         const int nb_saved = nb; (void)nb_saved;
 #define nb nbl
-        if (L.NS == 1) hipLaunchKernelGGL((conv_h2b_kernel<1, 9, 0>), dim3(nb), dim3(512), lb19, st, a);
+        constexpr int lb110 = convh2b_lds_bytes<1, 10>();
+        if (L.NS == 1 && L.skip) hipLaunchKernelGGL((conv_h2b_kernel<1, 10, 0>), dim3(nb), dim3(512), lb110, st, a);
+        else if (L.NS == 1) hipLaunchKernelGGL((conv_h2b_kernel<1, 9, 0>), dim3(nb), dim3(512), lb19, st, a);
         else if (g_h2b && L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 3>), dim3(nb), dim3(512), lb10, st, a);
         else if (g_h2b && L.NS == 2 && L.skip) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 0>), dim3(nb), dim3(512), lb10, st, a);
         else if (g_h2b && L.NS == 2) hipLaunchKernelGGL((conv_h2b_kernel<2, 9, 0>), dim3(nb), dim3(512), lb9, st, a);
