@@ -305,12 +305,13 @@ static const bool g_fuse_stem = []() { const char* e = getenv("RIFE_HIP_FUSE_STE
 static const bool g_head_h2 = []() { const char* e = getenv("RIFE_HIP_HEAD_H2"); return !(e && e[0] == '0'); }();
 static const bool g_s2_h2 = []() { const char* e = getenv("RIFE_HIP_S2_H2"); return !(e && e[0] == '0'); }();
 static const bool g_splitk = []() { const char* e = getenv("RIFE_HIP_SPLITK"); return !(e && e[0] == '0'); }();
+static const bool g_fuse_tail = []() { const char* e = getenv("RIFE_HIP_FUSE_TAIL"); return !(e && e[0] == '0'); }();
 static const bool g_h2b = []() { const char* e = getenv("RIFE_HIP_H2B"); return !(e && e[0] == '0'); }();   // A/B: 2-workgroup variant
 // RIFE_HIP_CONV8=0 disables the 8-wave trunk kernel (A/B measurements)
 static const bool g_use_conv8 = []() { const char* e = getenv("RIFE_HIP_CONV8"); return !(e && e[0] == '0'); }();
 
 // x: NHWC input (H x W), y: output; for deconv layers y has 2H x 2W pixels (or the 4H x 4W flow tensor with EPI_DECONV_PS).
-static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorView y, const TensorView* res, hipStream_t st) {
+static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorView y, const TensorView* res, hipStream_t st, const FinalArgs* fin = nullptr) {
     ConvArgs a;
     a.in = x.p; a.in_ld = x.ld; a.in_coff = x.coff; a.H = H; a.W = W;
     a.out = y.p; a.out_ld = y.ld; a.out_coff = y.coff;
@@ -352,6 +353,7 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         if (eh != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_h2s2 launch: ") + hipGetErrorString(eh));
         return 0;
     }
+    if (fin && !(L.nchunksh > 0 && L.deconv && g_trunk_h2 && g_head_h2)) return fail(RIFE_HIP_EINVAL, "fused tail needs the split-f16 head kernel");
     if (L.nchunksh > 0 && L.deconv && g_trunk_h2 && g_head_h2) {
         a.ntiles_xy = a.tiles_x * ((a.Ho + 7) / 8);
         a.nchunks = L.nchunksh;
@@ -365,13 +367,15 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_DECONV_PS>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_DECONV>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_DECONV_SIG>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_FINAL>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
                 hdone[dev] = true;
             }
         }
         const int nb = a.ntiles_xy * a.nz;
-        if (L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_PS>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a);
-        else if (L.epi == EPI_DECONV) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a);
-        else hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_SIG>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a);
+        if (fin && L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_FINAL>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, *fin);
+        else if (L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_PS>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
+        else if (L.epi == EPI_DECONV) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
+        else hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_SIG>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
         hipError_t eh = hipGetLastError();
         if (eh != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("head_h2 launch: ") + hipGetErrorString(eh));
         return 0;
@@ -704,7 +708,7 @@ static int run_assemble(const rife_hip& E, Ctx& c, int b, float timestep) {
 }
 
 // One IFBlock: stems, 8 residual convs, head -> flow[b]   (flownet.param:11-46, 63-98, 116-151, 166-201)
-static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep) {
+static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, const FinalArgs* fin = nullptr) {
     const rife_hip::Block& B = E.blk[b];
     hipStream_t st = c.stream;
     const int s = B.scale, Hb = c.hp / s, Wb = c.wp / s;
@@ -751,7 +755,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep) {
     }
     {
         Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);
-        if ((rc = launch_conv(B.head, {cur, B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st))) return rc;
+        if ((rc = launch_conv(B.head, {cur, B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st, fin))) return rc;
     }
     return 0;
 }
@@ -778,11 +782,13 @@ static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
         hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.img1, c.wp, c.hp);
         HIPCHK(hipGetLastError());
     }
+    const bool fuse_tail = g_trunk_h2 && g_head_h2 && g_fuse_tail && E.blk[3].head.d_wh != nullptr;
+    FinalArgs fin{c.img0, c.img1, c.F, c.M, d_out, c.w, c.h, c.wp, c.hp};
     for (int b = 0; b < 4; b++) {
-        if ((rc = run_block_convs(E, c, b, timestep))) return rc;
+        if ((rc = run_block_convs(E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr))) return rc;
         if (b < 3 && (rc = run_flow_update(E, c, b))) return rc;
     }
-    {
+    if (!fuse_tail) {
         Timed t(E.prof, "final", 0, st);
         hipLaunchKernelGGL(k_final, grid2d(c.w, c.h), dim3(256), 0, st, c.img0, c.img1, c.F, c.M, c.flow[3], d_out, c.w, c.h, c.wp, c.hp);
         HIPCHK(hipGetLastError());

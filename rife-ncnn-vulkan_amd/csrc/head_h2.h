@@ -8,6 +8,7 @@
 //   Epilogue: + bias, PixelShuffle scatter into the flow tensor [4H][4W][8].
 #pragma once
 #include "conv_mfma.h"
+#include "elementwise.h"
 
 namespace rife {
 
@@ -29,12 +30,21 @@ __device__ __forceinline__ constexpr int head_pair_index(int t, int par) {   // 
     return -1;
 }
 
+// extra inputs of the fused tail (EPI_FINAL): everything k_final needs besides flow3
+struct FinalArgs {
+    const uint32_t *img0, *img1;
+    const float4* F; const float* M;
+    uint8_t* out;           // u8 HWC RGB, w x h
+    int w, h, wp, hp;
+};
+enum { EPI_FINAL = 7 };      // head of block 3 + flownet.param:202-217 + postproc, no flow3 in HBM
+
 constexpr int headh2_lds_bytes() { return 2 * 10 * 34 * 80 + 16 * 2 * 32 * 16; }
 
 // EPI: EPI_DECONV_PS (v4 heads: + PixelShuffle scatter, 24 channels), EPI_DECONV (+ per-channel slope, NHWC store at
 // (2y+py, 2x+px)), EPI_DECONV_SIG (sigmoid).  Output channels are tiled by 32 over the grid (a.nz N-tiles per pixel tile).
 template <int EPI>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void head_h2_kernel(ConvArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void head_h2_kernel(ConvArgs a, FinalArgs fa) {
     constexpr int IH = 10, IW = 34, CC = 16, NT = 32;
     constexpr int PIXB = 80;
     constexpr int IN_F4 = IH * IW * 4;
@@ -144,6 +154,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef HD_WRITE_W
 #undef HD_TAPS
 
+    if (EPI == EPI_FINAL) {
+        // The lane holds, per parity, channels {4q + 2... : c = 2q + half} x 4 sub-positions k of one trunk pixel: flow channels
+        // (x, z, mask) in lanes 0-31 and (y, w, -) in lanes 32-63.  The halves swap what the other needs (lane ^ 32) and each
+        // finishes two of the four flow pixels: F += d, M += dm, sigmoid, 2x warp, blend, postproc  (the body of k_final).
+        const int oy = oy0 + wv, ox = ox0 + li;
+#pragma unroll
+        for (int par = 0; par < 4; par++) {
+            const int py = par >> 1, px = par & 1;
+            float mine[3][4], theirs[3][4];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 8 * q + 4 * half);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    mine[q][k] = acc[par][4 * q + k] + b4[k];
+                    theirs[q][k] = __shfl_xor(mine[q][k], 32);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                const int k = 2 * half + kk;                 // this lane's two sub-positions
+                float dx, dy, dz, dw, dm;
+                if (half == 0) { dx = mine[0][k]; dz = mine[1][k]; dm = mine[2][k]; dy = theirs[0][k]; dw = theirs[1][k]; }
+                else { dy = mine[0][k]; dw = mine[1][k]; dx = theirs[0][k]; dz = theirs[1][k]; dm = theirs[2][k]; }
+                const int fy = 2 * (2 * oy + py) + (k >> 1), fx = 2 * (2 * ox + px) + (k & 1);
+                if (fy < fa.h && fx < fa.w) {
+                    const size_t i = (size_t)fy * fa.wp + fx;
+                    float4 f = fa.F[i];
+                    f.x = f.x + dx; f.y = f.y + dy; f.z = f.z + dz; f.w = f.w + dw;
+                    const float mm = fa.M[i] + dm;
+                    const float m = 1.f / (1.f + expf(-mm));
+                    const float rm = 1.0f - m;
+                    const float3 w1 = warp_rgbx(fa.img1, fx, fy, f.z, f.w, fa.wp, fa.hp);
+                    const float3 w0 = warp_rgbx(fa.img0, fx, fy, f.x, f.y, fa.wp, fa.hp);
+                    const float r = w0.x * m + w1.x * rm, g = w0.y * m + w1.y * rm, b = w0.z * m + w1.z * rm;
+                    uint8_t* o = fa.out + ((size_t)fy * fa.w + fx) * 3;
+                    o[0] = (uint8_t)min(max((int)(r * 255.f + 0.5f), 0), 255);
+                    o[1] = (uint8_t)min(max((int)(g * 255.f + 0.5f), 0), 255);
+                    o[2] = (uint8_t)min(max((int)(b * 255.f + 0.5f), 0), 255);
+                }
+            }
+        }
+        return;
+    }
     // epilogue: deconv pixel (2oy+py, 2ox+px), channels c0..c0+3 of this 32-wide N-tile
     const int oy = oy0 + wv, ox = ox0 + li;
     const bool pok = oy < a.Ho && ox < a.Wo;
