@@ -689,8 +689,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef H2B_WRITE_W
 #undef H2B_TAPS
 
+    // ---- epilogue.  Direct path (split-K partials, ablations, ragged channel counts): one 16-byte store per register quad,
+    // i.e. 32 B per pixel per instruction.  Normal path: each wave transposes its 32 x NT tile through LDS (the staging buffers
+    // are free by now) so that consecutive lanes store consecutive 16-byte chunks: 1 KB of contiguous memory per instruction.
     const int oy = oy0 + wv, ox = ox0 + li;
     const bool pok = oy < a.Ho && ox < a.Wo;
+    constexpr int ROWF = NT + 4;                               // floats per pixel row of the transpose tile (odd number of 16-B slots)
+    const bool via_lds = a.nsplit == 1 && !(TAG & 256) && a.out_ld == NT && a.Cout == NT && a.nz == 1;
+    if (via_lds) __syncthreads();                              // every wave is done reading the staging buffers
+    float* const tl = reinterpret_cast<float*>(ldsb) + wv * 32 * ROWF;
 #pragma unroll
     for (int n = 0; n < NS; n++) {
 #pragma unroll
@@ -710,8 +717,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int k = 0; k < 4; k++) v[k] = acc[n][4 * q + k] + b4[k];
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k];
-            if (TAG & 256) { if (v[0] == 123.456f) a.out[0] = v[1]; }   // ablation: keep alive, (almost) never store
+            if (via_lds) *reinterpret_cast<f32x4*>(tl + li * ROWF + n * 32 + 8 * q + 4 * half) = v;
+            else if (TAG & 256) { if (v[0] == 123.456f) a.out[0] = v[1]; }   // ablation: keep alive, (almost) never store
             else if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
+        }
+    }
+    if (via_lds) {
+        constexpr int LPP = NT / 4;                            // lanes (16-byte chunks) per pixel
+        constexpr int PPI = 64 / LPP;                          // pixels per store instruction
+        const int pl = lane / LPP, chunk = lane - pl * LPP;
+        float* const orow = a.out + ((size_t)oy * a.Wo + ox0) * a.out_ld + a.out_coff + chunk * 4;
+#pragma unroll
+        for (int j = 0; j < 32 / PPI; j++) {
+            const int px = j * PPI + pl;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tl + px * ROWF + chunk * 4);
+            if (oy < a.Ho && ox0 + px < a.Wo) *reinterpret_cast<f32x4*>(orow + (size_t)px * a.out_ld) = v;
         }
     }
 }

@@ -1576,6 +1576,51 @@ int rife_hip_bench_h2b(int gpuid, int h, int w, int variant, int iters, float* m
     return rc;
 }
 
+// bench-only: ablations of stem0_fused_kernel<1,1> on a wp x hp frame (variant = ABL bits, see stem_fused.h)
+int rife_hip_bench_stemf(int gpuid, int wp, int hp, int variant, int iters, float* ms_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    const size_t P = (size_t)wp * hp;
+    uint32_t *i0 = nullptr, *i1 = nullptr; float4* F = nullptr; float *M = nullptr, *out = nullptr, *bias = nullptr; void* wh = nullptr;
+    HIPCHK(hipMalloc(&i0, P * 4)); HIPCHK(hipMalloc(&i1, P * 4)); HIPCHK(hipMalloc(&F, P * 16)); HIPCHK(hipMalloc(&M, P * 4));
+    HIPCHK(hipMalloc(&out, P / 4 * 32 * 4)); HIPCHK(hipMalloc(&bias, 64 * 4)); HIPCHK(hipMalloc(&wh, 9 * 2 * 32 * 16));
+    HIPCHK(hipMemset(i0, 0x40, P * 4)); HIPCHK(hipMemset(i1, 0x60, P * 4)); HIPCHK(hipMemset(F, 0, P * 16)); HIPCHK(hipMemset(M, 0, P * 4));
+    HIPCHK(hipMemset(bias, 0, 256)); HIPCHK(hipMemset(wh, 0, 9 * 2 * 32 * 16));
+    StemFusedArgs fa;
+    fa.img0 = i0; fa.img1 = i1; fa.F = F; fa.M = M; fa.wpk = wh; fa.bias = bias; fa.slope = bias; fa.out = out; fa.timestep = 0.5f;
+    fa.wp = wp; fa.hp = hp; fa.Ho = hp / 2; fa.Wo = wp / 2; fa.out_ld = 32; fa.Cout = 32; fa.tiles_x = (fa.Wo + 31) / 32;
+    const int nb = fa.tiles_x * ((fa.Ho + 3) / 4);
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](auto kfn) -> int {
+        for (int i = 0; i < 2; i++) hipLaunchKernelGGL(kfn, dim3(nb), dim3(512), stemf_lds_bytes<1>(), 0, fa);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kfn, dim3(nb), dim3(512), stemf_lds_bytes<1>(), 0, fa);
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    switch (variant) {
+        case 0: rc = run(stem0_fused_kernel<1, 1, 0>); break;
+        case 1: rc = run(stem0_fused_kernel<1, 1, 1>); break;
+        case 2: rc = run(stem0_fused_kernel<1, 1, 2>); break;
+        case 3: rc = run(stem0_fused_kernel<1, 1, 3>); break;
+        case 6: rc = run(stem0_fused_kernel<1, 1, 6>); break;
+        case 7: rc = run(stem0_fused_kernel<1, 1, 7>); break;
+        case 9: rc = run(stem0_fused_kernel<1, 1, 9>); break;
+        case 15: rc = run(stem0_fused_kernel<1, 1, 15>); break;
+        case 16: rc = run(stem0_fused_kernel<1, 1, 16>); break;
+        case 32: rc = run(stem0_fused_kernel<1, 1, 32>); break;
+        case 48: rc = run(stem0_fused_kernel<1, 1, 48>); break;
+        case 22: rc = run(stem0_fused_kernel<1, 1, 22>); break;
+        case 38: rc = run(stem0_fused_kernel<1, 1, 38>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    (void)hipFree(i0); (void)hipFree(i1); (void)hipFree(F); (void)hipFree(M); (void)hipFree(out); (void)hipFree(bias); (void)hipFree(wh);
+    return rc;
+}
+
 // tooling: structural hash of a named blob of a .param file (used to derive / test the compiled-in constants)
 int rife_hip_param_hash(const char* param_path, const char* blob, uint64_t* out) {
     NcnnModel m;

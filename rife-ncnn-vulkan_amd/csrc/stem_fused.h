@@ -23,12 +23,14 @@ struct StemFusedArgs {
     int Ho, Wo, out_ld, Cout, tiles_x;
 };
 
+constexpr int STEMF_PIXB = 64;     // no pad: the tiny MFMA phase tolerates 8-way conflicts, the gather phase wants 3 workgroups per CU
 template <int NS>
-constexpr int stemf_lds_bytes() { return 9 * 65 * 80 + 9 * 2 * NS * 32 * 16; }
+constexpr int stemf_lds_bytes() { return 9 * 65 * STEMF_PIXB + 9 * 2 * NS * 32 * 16; }
 
-template <int S, int NS>
+// ABL (bench only): 1 = skip MFMA + epilogue, 2 = skip the image gathers, 4 = skip F/M loads too, 8 = skip LDS staging, 16 = skip stores, 32 = skip MFMAs
+template <int S, int NS, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem0_fused_kernel(StemFusedArgs a) {
-    constexpr int IH = 9, IW = 65, PIXB = 80, NT = NS * 32;
+    constexpr int IH = 9, IW = 65, PIXB = STEMF_PIXB, NT = NS * 32;
     constexpr int NPIX = IH * IW;
     constexpr int W_16 = 9 * 2 * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -57,6 +59,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int py = p / IW, px = p - py * IW;
         const int by = iy0 + py, bx = ix0 + px;
         float o[12];
+        if (ABL & 2) {
+            if (by >= 0 && by < Hb && bx >= 0 && bx < Wb) {
+                const size_t i = (size_t)by * a.wp + bx;
+                float4 f = make_float4(1.f, 2.f, 3.f, 4.f); float m = 0.5f;
+                if (!(ABL & 4)) { f = a.F[i]; m = a.M[i]; }
+#pragma unroll
+                for (int c = 0; c < 12; c++) o[c] = f.x * (float)c + f.y + f.z + f.w + m;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 12; c++) o[c] = 0.f;
+            }
+        } else
         if (by >= 0 && by < Hb && bx >= 0 && bx < Wb) assemble_pixel<S>(a.img0, a.img1, a.timestep, a.F, a.M, a.wp, a.hp, bx, by, o);
         else {
 #pragma unroll
@@ -72,11 +86,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             h1[c] = hb; l1[c] = (_Float16)(vb - (float)hb);
         }
         unsigned char* dst = ldsb + p * PIXB;
+        if (ABL & 8) { if (h0[0] == (_Float16)123.f) *reinterpret_cast<f16x8*>(dst) = h0; continue; }
         *reinterpret_cast<f16x8*>(dst) = h0; *reinterpret_cast<f16x8*>(dst + 16) = h1;
         *reinterpret_cast<f16x8*>(dst + 32) = l0; *reinterpret_cast<f16x8*>(dst + 48) = l1;
     }
     __syncthreads();
 
+    if (ABL & 1) return;
     if (nsel >= NS) return;                                // NS = 1: waves 4-7 only helped with the gather
     f32x16 acc;
 #pragma unroll
@@ -89,22 +105,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const f16x8 ah = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB);
         const f16x8 al = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB + 32);
         const f16x8 bw = *reinterpret_cast<const f16x8*>(bb + (t * 2 * NT) * 16);
+        if (ABL & 32) { acc[0] += (float)ah[0] + (float)al[1] + (float)bw[2]; continue; }     // ablation: LDS reads without the matrix pipe
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, ah, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, al, acc, 0, 0, 0);
     }
 
-    const int oy = oy0 + wv, ox = ox0 + li;
-    const bool pok = oy < a.Ho && ox < a.Wo;
+    // epilogue: bias + leaky, then transpose the wave's 32 x 32 tile through LDS (the halo tile is dead by now) so that
+    // 8 consecutive lanes store one pixel's 128 contiguous bytes (a full line per pixel, 1 KB per instruction if out_ld = 32)
+    __syncthreads();                                       // waves 4-7 (NS = 1) have exited; exited waves do not count
+    constexpr int ROWF = 36;
+    float* const tl = reinterpret_cast<float*>(ldsb) + wv8 * 32 * ROWF;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int c0 = nsel * 32 + 8 * q + 4 * half;
-        const bool ok = pok && c0 < a.Cout;
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
         const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
         f32x4 v;
 #pragma unroll
         for (int k = 0; k < 4; k++) { v[k] = acc[4 * q + k] + b4[k]; v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k]; }
-        if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + c0) = v;
+        *reinterpret_cast<f32x4*>(tl + li * ROWF + 8 * q + 4 * half) = v;
+    }
+    const int oy = oy0 + wv;
+    const int pl = lane >> 3, chunk = lane & 7;
+    const int c0 = nsel * 32 + chunk * 4;
+    float* const orow = a.out + ((size_t)oy * a.Wo + ox0) * a.out_ld + c0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int px = j * 8 + pl;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tl + px * ROWF + chunk * 4);
+        if (ABL & 16) { if (v[0] == 123.456f) a.out[0] = v[1]; }                               // ablation: no stores
+        else if (oy < a.Ho && ox0 + px < a.Wo && c0 < a.Cout) *reinterpret_cast<f32x4*>(orow + (size_t)px * a.out_ld) = v;
     }
 }
 
