@@ -100,9 +100,11 @@ void v4_temporal_merge(Mat& f, Mat& r) {
     }
 }
 
-// v4 8-orientation flow/mask consensus, in place (rife.cpp:3515-3665; signs per SURVEY App. G)
+// 8-orientation flow(/mask) consensus, in place: v4 (5 channels, rife.cpp:3515-3665) and v2 (4 channels, no mask,
+// rife.cpp:1543-1667); signs per SURVEY App. G
 void v4_spatial_avg(Mat fl[8]) {
     const int W = fl[0].w, H = fl[0].h;
+    const bool has_mask = fl[0].c > 4;
     for (int i = 0; i < H; i++)
         for (int j = 0; j < W; j++) {
             size_t id[8];
@@ -111,17 +113,17 @@ void v4_spatial_avg(Mat fl[8]) {
             auto Y = [&](int ti) -> float& { return fl[ti].channel(1)[id[ti]]; };
             auto Z = [&](int ti) -> float& { return fl[ti].channel(2)[id[ti]]; };
             auto Wc = [&](int ti) -> float& { return fl[ti].channel(3)[id[ti]]; };
-            auto M = [&](int ti) -> float& { return fl[ti].channel(4)[id[ti]]; };
+            auto M = [&](int ti) -> float& { return fl[ti].channel(has_mask ? 4 : 0)[id[ti]]; };
             float x = (X(0) + -X(1) + -X(2) + X(3) + Y(4) + Y(5) + -Y(6) + -Y(7)) * 0.125f;
             float y = (Y(0) + Y(1) + -Y(2) + -Y(3) + X(4) + -X(5) + -X(6) + X(7)) * 0.125f;
             float z = (Z(0) + -Z(1) + -Z(2) + Z(3) + Wc(4) + Wc(5) + -Wc(6) + -Wc(7)) * 0.125f;
             float w = (Wc(0) + Wc(1) + -Wc(2) + -Wc(3) + Z(4) + -Z(5) + -Z(6) + Z(7)) * 0.125f;
-            float m = (M(0) + M(1) + M(2) + M(3) + M(4) + M(5) + M(6) + M(7)) * 0.125f;
+            float m = has_mask ? (M(0) + M(1) + M(2) + M(3) + M(4) + M(5) + M(6) + M(7)) * 0.125f : 0.f;
             X(0) = x; X(1) = -x; X(2) = -x; X(3) = x; X(4) = y; X(5) = -y; X(6) = -y; X(7) = y;
             Y(0) = y; Y(1) = y; Y(2) = -y; Y(3) = -y; Y(4) = x; Y(5) = x; Y(6) = -x; Y(7) = -x;
             Z(0) = z; Z(1) = -z; Z(2) = -z; Z(3) = z; Z(4) = w; Z(5) = -w; Z(6) = -w; Z(7) = w;
             Wc(0) = w; Wc(1) = w; Wc(2) = -w; Wc(3) = -w; Wc(4) = z; Wc(5) = z; Wc(6) = -z; Wc(7) = -z;
-            for (int ti = 0; ti < 8; ti++) M(ti) = m;
+            if (has_mask) for (int ti = 0; ti < 8; ti++) M(ti) = m;
         }
 }
 
@@ -271,11 +273,68 @@ int v2_flow(const RifeOracle& R, const Mat& a, const Mat& b, Mat& flow) {
 int process_cpu_v2(const RifeOracle& R, const uint8_t* p0, const uint8_t* p1, int w, int h, float timestep, uint8_t* outpx) {
     if (timestep == 0.f) { std::memcpy(outpx, p0, (size_t)w * h * 3); return 0; }   // rife.cpp:1216-1226
     if (timestep == 1.f) { std::memcpy(outpx, p1, (size_t)w * h * 3); return 0; }
-    if (R.tta_mode) return -20;   // v2 spatial TTA: not restated (outside BASELINE configs)
     const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;
     Mat in0 = preproc_pad(p0, w, h, wp, hp), in1 = preproc_pad(p1, w, h, wp, hp);
     Mat flow, flowr;
     int rc;
+    auto synth = [&](const Mat& a, const Mat& b, const Mat& fl, Mat& o) -> int {   // slice -> contextnet x2 -> fusionnet
+        int r;
+        Mat f0 = fl.channel_range(0, 2).clone(), f1 = fl.channel_range(2, 2).clone();
+        Mat c0[4], c1[4];
+        static const char* fnames[4] = {"f1", "f2", "f3", "f4"};
+        { Extractor ex(R.contextnet); ex.light = false; ex.input("input.1", a); ex.input("flow.0", f0);
+          for (int k = 0; k < 4; k++) if ((r = ex.extract(fnames[k], c0[k]))) return r; }
+        { Extractor ex(R.contextnet); ex.light = false; ex.input("input.1", b); ex.input("flow.0", f1);
+          for (int k = 0; k < 4; k++) if ((r = ex.extract(fnames[k], c1[k]))) return r; }
+        Extractor ex(R.fusionnet);
+        ex.input("img0", a); ex.input("img1", b); ex.input("flow", fl);
+        static const char* n0[4] = {"3", "4", "5", "6"};
+        static const char* n1[4] = {"7", "8", "9", "10"};
+        for (int k = 0; k < 4; k++) { ex.input(n0[k], c0[k]); ex.input(n1[k], c1[k]); }
+        if ((r = ex.extract("output", o))) return r;
+        o = o.clone();
+        return 0;
+    };
+    if (R.tta_mode) {
+        // rife.cpp:1256-2138 (rife_v2 branches).  The reversed FusionNet pass of the reference re-uses the forward
+        // contexts swapped (rife.cpp:2026-2047); after the final merge flow_reversed = (z, w, x, y) of flow, so
+        // ContextNet(in1, flow_reversed[0:2]) is the same computation and synth() may simply recompute it.
+        Mat a[8], b[8], fl[8], flr[8], o[8], orv[8];
+        make_orientations(in0, a); make_orientations(in1, b);
+        for (int ti = 0; ti < 8; ti++) if ((rc = v2_flow(R, a[ti], b[ti], fl[ti]))) return rc;             // 1420-1450
+        if (R.tta_temporal_mode)
+            for (int ti = 0; ti < 8; ti++) {                                                                // 1452-1540
+                if ((rc = v2_flow(R, b[ti], a[ti], flr[ti]))) return rc;
+                v2_temporal_merge(fl[ti], flr[ti]);
+            }
+        v4_spatial_avg(fl);                                                                                 // 1543-1667
+        if (R.tta_temporal_mode) {
+            v4_spatial_avg(flr);                                                                            // 1721-1896
+            for (int ti = 0; ti < 8; ti++) v2_temporal_merge(fl[ti], flr[ti]);                              // 1898-1948
+        }
+        for (int ti = 0; ti < 8; ti++) {                                                                    // 1964-2048
+            if ((rc = synth(a[ti], b[ti], fl[ti], o[ti]))) return rc;
+            if (R.tta_temporal_mode && (rc = synth(b[ti], a[ti], flr[ti], orv[ti]))) return rc;
+        }
+        for (int i = 0; i < h; i++)                                                                         // 2050-2137
+            for (int j = 0; j < w; j++)
+                for (int q = 0; q < 3; q++) {
+                    float sv[8], sr[8];
+                    for (int ti = 0; ti < 8; ti++) {
+                        size_t id = tta_index(ti, i, j, wp, hp);
+                        sv[ti] = o[ti].channel(q)[id];
+                        if (R.tta_temporal_mode) sr[ti] = orv[ti].channel(q)[id];
+                    }
+                    float v = (sv[0] + sv[1] + sv[2] + sv[3] + sv[4] + sv[5] + sv[6] + sv[7]) / 8;
+                    float res;
+                    if (R.tta_temporal_mode) {
+                        float vr = (sr[0] + sr[1] + sr[2] + sr[3] + sr[4] + sr[5] + sr[6] + sr[7]) / 8;
+                        res = (v + vr) * 0.5f * 255.f + 0.5f;
+                    } else res = v * 255.f + 0.5f;
+                    outpx[((size_t)i * w + j) * 3 + q] = sat_u8(res);
+                }
+        return 0;
+    }
     if ((rc = v2_flow(R, in0, in1, flow))) return rc;
     if (R.tta_temporal_mode) {
         if ((rc = v2_flow(R, in1, in0, flowr))) return rc;

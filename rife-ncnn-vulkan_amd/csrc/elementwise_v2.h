@@ -205,6 +205,60 @@ __global__ void k2_final(const uint32_t* __restrict__ img0, const uint32_t* __re
     }
 }
 
+// tail of the v2 graph without postproc: the clipped output (fusionnet.param:63-74) kept as float4 per padded pixel, for the
+// TTA averaging (rife.cpp:804-876 GPU, 2050-2137 CPU)
+__global__ void k2_final_float(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, const float4* __restrict__ flow,
+                               const float4* __restrict__ head, float4* __restrict__ out, int wp, int hp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wp) return;
+    const float4 f = flow_up2x2(flow, x, y, wp / 2, hp / 2);
+    const float3 w0 = warp_rgbx(img0, x, y, f.x, f.y, wp, hp);
+    const float3 w1 = warp_rgbx(img1, x, y, f.z, f.w, wp, hp);
+    const float4 o = head[(size_t)y * wp + x];
+    const float m = o.w, rm = 1.0f - m;
+    float v[3];
+    v[0] = (w0.x * m + w1.x * rm) + (o.x * 2.0f - 1.0f);
+    v[1] = (w0.y * m + w1.y * rm) + (o.y * 2.0f - 1.0f);
+    v[2] = (w0.z * m + w1.z * rm) + (o.z * 2.0f - 1.0f);
+#pragma unroll
+    for (int c = 0; c < 3; c++) v[c] = fminf(fmaxf(v[c], 0.f), 1.f);
+    out[(size_t)y * wp + x] = make_float4(v[0], v[1], v[2], 0.f);
+}
+
+// v2 forward / reversed flow consensus, in place on both float4 fields (rife.cpp:1484-1540 and 1898-1948;
+// GPU twin rife_v2_flow_tta_temporal_avg.comp)
+__global__ void k2_temporal_merge(float4* __restrict__ f, float4* __restrict__ r, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float4 a = f[i], b = r[i];
+    const float x = (a.x + b.z) * 0.5f, y = (a.y + b.w) * 0.5f, z = (a.z + b.x) * 0.5f, w = (a.w + b.y) * 0.5f;
+    f[i] = make_float4(x, y, z, w);
+    r[i] = make_float4(z, w, x, y);
+}
+
+// v2 8-orientation flow consensus, in place on eight float4 fields; W x H = size of orientation 0 (rife.cpp:1543-1667;
+// GPU twin rife_v2_flow_tta_avg.comp)
+__global__ void k2_spatial_avg(Ptr8 fl, int W, int H) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= W) return;
+    float4* q[8];
+    float4 v[8];
+#pragma unroll
+    for (int ti = 0; ti < 8; ti++) { q[ti] = reinterpret_cast<float4*>(fl.p[ti]) + tta_index(ti, i, j, W, H); v[ti] = *q[ti]; }
+    const float x = (v[0].x + -v[1].x + -v[2].x + v[3].x + v[4].y + v[5].y + -v[6].y + -v[7].y) * 0.125f;
+    const float y = (v[0].y + v[1].y + -v[2].y + -v[3].y + v[4].x + -v[5].x + -v[6].x + v[7].x) * 0.125f;
+    const float z = (v[0].z + -v[1].z + -v[2].z + v[3].z + v[4].w + v[5].w + -v[6].w + -v[7].w) * 0.125f;
+    const float w = (v[0].w + v[1].w + -v[2].w + -v[3].w + v[4].z + -v[5].z + -v[6].z + v[7].z) * 0.125f;
+    *q[0] = make_float4(x, y, z, w);
+    *q[1] = make_float4(-x, y, -z, w);
+    *q[2] = make_float4(-x, -y, -z, -w);
+    *q[3] = make_float4(x, -y, z, -w);
+    *q[4] = make_float4(y, x, w, z);
+    *q[5] = make_float4(-y, x, -w, z);
+    *q[6] = make_float4(-y, -x, -w, -z);
+    *q[7] = make_float4(y, -x, w, -z);
+}
+
 __global__ void k2_flow_up2_double(const float4* __restrict__ in, float4* __restrict__ out, int wo, int ho) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= wo) return;

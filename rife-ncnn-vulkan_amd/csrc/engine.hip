@@ -580,6 +580,9 @@ struct Ctx {
     float2* fl[4] = {nullptr, nullptr, nullptr, nullptr};           // ContextNet flow pyramid
     float *e0a = nullptr, *e0b = nullptr, *e0c = nullptr, *B1 = nullptr, *e1a = nullptr, *B2 = nullptr, *e2a = nullptr, *B3 = nullptr, *e3a = nullptr, *B4 = nullptr;
     float *U0 = nullptr, *U1 = nullptr, *U2 = nullptr, *U3 = nullptr;
+    // rife-v2.x TTA: per orientation RGBX frames, half-res flows [direction][orientation], float outputs [direction][orientation]
+    uint32_t *timg0[8] = {}, *timg1[8] = {};
+    float4 *tflow[2][8] = {}, *toutf[2][8] = {};
     std::vector<void*> allocs;
     ~Ctx() {
         for (void* p : allocs) (void)hipFree(p);
@@ -917,10 +920,12 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
 // ------------------------------------------------------------------------------------------------
 // rife-v2.x: RIFE::process, non-TTA branch (rife.cpp:878-1183) = flownet -> slice -> contextnet x2 -> fusionnet
 // ------------------------------------------------------------------------------------------------
-static int ensure_ctx_v2(Ctx& c, int w, int h, bool uhd) {
+static int ensure_ctx_v2(Ctx& c, int w, int h, bool uhd, int nori = 1, int ntemp = 1) {
     const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;     // rife.cpp:417-418
-    if (c.v2 && c.wp == wp && c.hp == hp && c.w == w && c.h == h && (!uhd || c.h0)) return 0;
+    const bool ens = nori * ntemp > 1;
+    if (c.v2 && c.wp == wp && c.hp == hp && c.w == w && c.h == h && (!uhd || c.h0) && (!ens || (c.toutf[0][0] && c.toutf[ntemp - 1][nori - 1]))) return 0;
     c.h0 = c.h1 = c.acc_s = nullptr;
+    for (int d = 0; d < 2; d++) for (int t = 0; t < 8; t++) { c.tflow[d][t] = c.toutf[d][t] = nullptr; if (!d) c.timg0[t] = c.timg1[t] = nullptr; }
     for (void* p : c.allocs) (void)hipFree(p);
     c.allocs.clear();
     c.v2 = true; c.w = w; c.h = h; c.wp = wp; c.hp = hp;
@@ -939,6 +944,11 @@ static int ensure_ctx_v2(Ctx& c, int w, int h, bool uhd) {
     A_(c.e2a, P / 256 * 256) A_(c.B3, P / 256 * 512) A_(c.e3a, P / 1024 * 512) A_(c.B4, P / 1024 * 1024)
     A_(c.U0, P / 256 * 512) A_(c.U1, P / 64 * 256) A_(c.U2, P / 16 * 128) A_(c.U3, P / 4 * 32)
     if (uhd) { A_(c.h0, P / 4) A_(c.h1, P / 4) A_(c.acc_s, P / 16) }
+    if (ens) {
+        c.timg0[0] = c.img0; c.timg1[0] = c.img1;
+        for (int t = 1; t < nori; t++) { A_(c.timg0[t], P) A_(c.timg1[t], P) }
+        for (int d = 0; d < ntemp; d++) for (int t = 0; t < nori; t++) { A_(c.tflow[d][t], P / 4) A_(c.toutf[d][t], P) }
+    }
 #undef A_
     return 0;
 }
@@ -990,33 +1000,36 @@ static int run_v2_ifnet(const rife_hip& E, Ctx& c, IMG img0, IMG img1, int wp, i
     return 0;
 }
 
-static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t* d_in1, uint8_t* d_out) {
+// flow estimate of one (img0, img1) pair of padded RGBX frames of wp x hp -> acc (float4 field of wp/2 x hp/2).
+// IFNet (flownet.param); UHD mode estimates the flow on half-resolution frames (rife.cpp:928-945)
+static int run_v2_flow(const rife_hip& E, Ctx& c, const uint32_t* img0, const uint32_t* img1, int wp, int hp, float4* acc) {
     hipStream_t st = c.stream;
-    const int wp = c.wp, hp = c.hp;
     int rc;
-    {
-        Timed t(E.prof, "preproc", 0, st);
-        dim3 g = grid2d(wp, hp);
-        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.img0, wp, hp);
-        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.img1, wp, hp);
-        HIPCHK(hipGetLastError());
-    }
-    // ---- IFNet (flownet.param); UHD mode estimates the flow on half-resolution frames (rife.cpp:928-945) ----
     const int wh = wp / 2, hh = hp / 2;
     if (E.uhd) {
         {
             Timed t(E.prof, "v2_uhd_resample", 0, st);
-            hipLaunchKernelGGL(k2_image_half, grid2d(wh, hh), dim3(256), 0, st, c.img0, c.h0, wp, hp);
-            hipLaunchKernelGGL(k2_image_half, grid2d(wh, hh), dim3(256), 0, st, c.img1, c.h1, wp, hp);
+            hipLaunchKernelGGL(k2_image_half, grid2d(wh, hh), dim3(256), 0, st, img0, c.h0, wp, hp);
+            hipLaunchKernelGGL(k2_image_half, grid2d(wh, hh), dim3(256), 0, st, img1, c.h1, wp, hp);
             HIPCHK(hipGetLastError());
         }
         if ((rc = run_v2_ifnet(E, c, ImgF4{c.h0}, ImgF4{c.h1}, wh, hh, c.acc_s))) return rc;
         {
             Timed t(E.prof, "v2_uhd_resample", 0, st);
-            hipLaunchKernelGGL(k2_flow_up2_double, grid2d(wh, hh), dim3(256), 0, st, c.acc_s, c.acc, wh, hh);
+            hipLaunchKernelGGL(k2_flow_up2_double, grid2d(wh, hh), dim3(256), 0, st, c.acc_s, acc, wh, hh);
             HIPCHK(hipGetLastError());
         }
-    } else if ((rc = run_v2_ifnet(E, c, ImgU8{c.img0}, ImgU8{c.img1}, wp, hp, c.acc))) return rc;
+    } else if ((rc = run_v2_ifnet(E, c, ImgU8{img0}, ImgU8{img1}, wp, hp, acc))) return rc;
+    return 0;
+}
+
+// (img0, img1, flow) -> interpolated frame: slice -> ContextNet x2 -> FusionNet -> blend (rife.cpp:1008-1183).
+// Writes the u8 w x h frame to d_out, or (outf != null) the clipped float frame of wp x hp for the TTA averaging.
+static int run_v2_synth(const rife_hip& E, Ctx& c, const uint32_t* img0, const uint32_t* img1, const float4* acc, int wp, int hp,
+                        uint8_t* d_out, float4* outf) {
+    hipStream_t st = c.stream;
+    int rc;
+    const int wh = wp / 2, hh = hp / 2;
     // ---- ContextNet twice (contextnet.param): (img0, flow[0:2]) -> "3".."6", (img1, flow[2:4]) -> "7".."10",
     //      each warped level written straight into its slice of the FusionNet concat buffers ----
     float* cat_buf[4] = {c.B1, c.B2, c.B3, c.B4};
@@ -1025,8 +1038,8 @@ static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
         {
             Timed t(E.prof, "v2_ctx_misc", 0, st);
             const size_t P = (size_t)wp * hp;
-            hipLaunchKernelGGL(k2_image_nhwc8, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, im ? c.img1 : c.img0, c.I8, P);
-            hipLaunchKernelGGL(k2_flow_half<true>, grid2d(wh / 2, hh / 2), dim3(256), 0, st, reinterpret_cast<const float*>(c.acc), im * 2, c.fl[0], wh, hh);
+            hipLaunchKernelGGL(k2_image_nhwc8, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, im ? img1 : img0, c.I8, P);
+            hipLaunchKernelGGL(k2_flow_half<true>, grid2d(wh / 2, hh / 2), dim3(256), 0, st, reinterpret_cast<const float*>(acc), im * 2, c.fl[0], wh, hh);
             for (int l = 1; l < 4; l++)
                 hipLaunchKernelGGL(k2_flow_half<false>, grid2d((wh >> l) / 2, (hh >> l) / 2), dim3(256), 0, st, reinterpret_cast<const float*>(c.fl[l - 1]), 0, c.fl[l],
                                    wh >> l, hh >> l);
@@ -1054,7 +1067,7 @@ static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     // ---- FusionNet (fusionnet.param) ----
     {
         Timed t(E.prof, "v2_assemble", 0, st);
-        hipLaunchKernelGGL((k2_assemble<1, ImgU8>), grid2d(wp, hp), dim3(256), 0, st, ImgU8{c.img0}, ImgU8{c.img1}, c.acc, c.X, wp, hp);
+        hipLaunchKernelGGL((k2_assemble<1, ImgU8>), grid2d(wp, hp), dim3(256), 0, st, ImgU8{img0}, ImgU8{img1}, acc, c.X, wp, hp);
         HIPCHK(hipGetLastError());
     }
     auto copy_view = [&](const float* src, int sld, int soff, float* dst, int dld, int doff, int C, size_t npix) {
@@ -1086,7 +1099,80 @@ static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     if ((rc = conv_t(E, F[14], {c.U3, 32, 0}, hp / 2, wp / 2, {reinterpret_cast<float*>(c.head), 4, 0}, st))) return rc;
     {
         Timed t(E.prof, "final", 0, st);
-        hipLaunchKernelGGL(k2_final, grid2d(c.w, c.h), dim3(256), 0, st, c.img0, c.img1, c.acc, c.head, d_out, c.w, c.h, wp, hp);
+        if (outf) hipLaunchKernelGGL(k2_final_float, grid2d(wp, hp), dim3(256), 0, st, img0, img1, acc, c.head, outf, wp, hp);
+        else hipLaunchKernelGGL(k2_final, grid2d(c.w, c.h), dim3(256), 0, st, img0, img1, acc, c.head, d_out, c.w, c.h, wp, hp);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+// RIFE::process for the v2 family: plain branch rife.cpp:878-1183; TTA branches 459-877 (CPU twin 1256-2138) with
+// nori = 8 orientations (-x) and / or ntemp = 2 time directions (-z); SURVEY App. G.
+static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t* d_in1, uint8_t* d_out) {
+    hipStream_t st = c.stream;
+    const int wp = c.wp, hp = c.hp;
+    const int nori = E.tta ? 8 : 1, ntemp = E.tta_temporal ? 2 : 1;
+    int rc;
+    if (nori * ntemp == 1) {
+        {
+            Timed t(E.prof, "preproc", 0, st);
+            dim3 g = grid2d(wp, hp);
+            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.img0, wp, hp);
+            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.img1, wp, hp);
+            HIPCHK(hipGetLastError());
+        }
+        if ((rc = run_v2_flow(E, c, c.img0, c.img1, wp, hp, c.acc))) return rc;
+        return run_v2_synth(E, c, c.img0, c.img1, c.acc, wp, hp, d_out, nullptr);
+    }
+    {
+        Timed t(E.prof, "preproc", 0, st);
+        dim3 g = grid2d(wp, hp);
+        if (nori == 8) {
+            Ptr8 a, b;
+            for (int ti = 0; ti < 8; ti++) { a.p[ti] = c.timg0[ti]; b.p[ti] = c.timg1[ti]; }
+            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in0, c.w, c.h, a, wp, hp);
+            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in1, c.w, c.h, b, wp, hp);
+        } else {
+            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.timg0[0], wp, hp);
+            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.timg1[0], wp, hp);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    const size_t nflow = (size_t)(wp / 2) * (hp / 2);
+    const unsigned gflow = (unsigned)((nflow + 255) / 256);
+    auto ow = [&](int ti) { return ti < 4 ? wp : hp; };
+    auto oh = [&](int ti) { return ti < 4 ? hp : wp; };
+    for (int ti = 0; ti < nori; ti++) {
+        if ((rc = run_v2_flow(E, c, c.timg0[ti], c.timg1[ti], ow(ti), oh(ti), c.tflow[0][ti]))) return rc;
+        if (ntemp == 2) {
+            if ((rc = run_v2_flow(E, c, c.timg1[ti], c.timg0[ti], ow(ti), oh(ti), c.tflow[1][ti]))) return rc;
+            Timed t(E.prof, "tta_merge", 0, st);
+            hipLaunchKernelGGL(k2_temporal_merge, dim3(gflow), dim3(256), 0, st, c.tflow[0][ti], c.tflow[1][ti], nflow);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    if (nori == 8) {
+        Timed t(E.prof, "tta_merge", 0, st);
+        for (int d = 0; d < ntemp; d++) {
+            Ptr8 f;
+            for (int ti = 0; ti < 8; ti++) f.p[ti] = c.tflow[d][ti];
+            hipLaunchKernelGGL(k2_spatial_avg, grid2d(wp / 2, hp / 2), dim3(256), 0, st, f, wp / 2, hp / 2);
+        }
+        if (ntemp == 2)
+            for (int ti = 0; ti < 8; ti++) hipLaunchKernelGGL(k2_temporal_merge, dim3(gflow), dim3(256), 0, st, c.tflow[0][ti], c.tflow[1][ti], nflow);
+        HIPCHK(hipGetLastError());
+    }
+    // the reference's reversed FusionNet pass re-uses the forward contexts swapped (rife.cpp:2026-2047); flow_reversed is
+    // (z, w, x, y) of flow after the merge, so recomputing ContextNet(img1, flow_reversed[0:2]) is the identical computation
+    for (int ti = 0; ti < nori; ti++) {
+        if ((rc = run_v2_synth(E, c, c.timg0[ti], c.timg1[ti], c.tflow[0][ti], ow(ti), oh(ti), nullptr, c.toutf[0][ti]))) return rc;
+        if (ntemp == 2 && (rc = run_v2_synth(E, c, c.timg1[ti], c.timg0[ti], c.tflow[1][ti], ow(ti), oh(ti), nullptr, c.toutf[1][ti]))) return rc;
+    }
+    {
+        Timed t(E.prof, "final", 0, st);
+        Ptr16 outs;
+        for (int d = 0; d < 2; d++) for (int ti = 0; ti < 8; ti++) outs.p[d * 8 + ti] = c.toutf[d][ti];
+        hipLaunchKernelGGL(k_postproc_tta, grid2d(c.w, c.h), dim3(256), 0, st, outs, nori, ntemp, d_out, c.w, c.h, wp, hp);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1197,7 +1283,6 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {
     int rc;
     if ((rc = check_device(E->gpuid))) return rc;
     if (E->v2 && !E->v4) {
-        if (E->tta || E->tta_temporal) return fail(RIFE_HIP_ENOSYS, "TTA is implemented for the rife-v4 family only");
         if ((rc = load_v2(E, modeldir))) return rc;
         E->loaded = true;
         return 0;
@@ -1272,7 +1357,7 @@ int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
         c->own_stream = true;
     }
-    rc = E->v4 ? ensure_ctx(*c, w, h) : ensure_ctx_v2(*c, w, h, E->uhd);
+    rc = E->v4 ? ensure_ctx(*c, w, h) : ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(c->d_in0, in0, nbytes, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->d_in1, in1, nbytes, hipMemcpyHostToDevice, c->stream);
@@ -1323,7 +1408,7 @@ int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* 
         HIPCHK(hipMemcpyAsync(d_out, timestep == 0.f ? d_in0 : d_in1, nbytes, hipMemcpyDeviceToDevice, c->stream));
     } else {
         if (!E->v4) {
-            if ((rc = ensure_ctx_v2(*c, w, h, E->uhd))) return rc;
+            if ((rc = ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1))) return rc;
             if ((rc = run_v2(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, (uint8_t*)d_out))) return rc;
         } else if (E->tta || E->tta_temporal) {
             // the TTA workspaces are shared: serialise, and drain before another stream may reuse them

@@ -78,3 +78,34 @@ def test_v23_uhd_rejects_unsupported_size(modeldirs):
     a, b = gen_frames.smooth_pair(96, 64, 1)        # padded 96 -> half 48, not a multiple of 32
     with pytest.raises(amd.RifeError):
         g.process(a, b, 0.5)
+
+
+@pytest.mark.parametrize("tta,temporal,uhd,w,h", [(True, False, False, 100, 60), (False, True, False, 160, 96), (True, True, False, 96, 64),
+                                                  (True, True, True, 128, 64), (True, False, False, 640, 360)])
+def test_v23_tta_within_1_lsb(modeldirs, tta, temporal, uhd, w, h):
+    """-x / -z for the v2 family: 8 orientations, forward/backward consensus (rife.cpp:459-877, CPU twin 1256-2138)."""
+    d = modeldirs["rife-v2.3"]
+    g = amd.RIFE(0, tta_mode=tta, tta_temporal_mode=temporal, uhd_mode=uhd, rife_v2=True); g.load(d)
+    o = pyoracle.OracleRIFE(tta_mode=tta, tta_temporal_mode=temporal, uhd_mode=uhd, rife_v2=True); o.set_gpu_crop(1); o.load(d)
+    a, b = gen_frames.smooth_pair(w, h, 500 + w)
+    got, want = g.process(a, b, 0.5), o.process(a, b, 0.5)
+    mx, f0 = report(got, want)
+    assert mx <= 1, (mx, f0)
+    assert f0 > 0.97
+    plain = amd.RIFE(0, uhd_mode=uhd, rife_v2=True); plain.load(d)
+    assert not np.array_equal(got, plain.process(a, b, 0.5))
+
+
+def test_v23_tta_is_equivariant_under_the_dihedral_group(modeldirs):
+    """Size-independent property of the -x ensemble: flipping / transposing the inputs flips / transposes the output
+    (frames are multiples of 32, so the zero padding does not break the symmetry)."""
+    g = amd.RIFE(0, tta_mode=True, tta_temporal_mode=True, rife_v2=True); g.load(modeldirs["rife-v2.3"])
+    a, b = gen_frames.smooth_pair(192, 128, 31)
+    base = g.process(a, b, 0.5)
+    for name, f in [("hflip", lambda x: x[:, ::-1]), ("vflip", lambda x: x[::-1]), ("transpose", lambda x: x.transpose(1, 0, 2))]:
+        got = g.process(np.ascontiguousarray(f(a)), np.ascontiguousarray(f(b)), 0.5)
+        mx, f0 = report(got, f(base))
+        assert mx <= 1 and f0 > 0.99, (name, mx, f0)
+    # -z: swapping the two frames gives the same middle frame
+    mx, f0 = report(g.process(b, a, 0.5), base)
+    assert mx <= 1 and f0 > 0.99, (mx, f0)
