@@ -69,6 +69,9 @@ int rife_hip_profile_read(rife_hip_t* r, char* names, size_t names_cap, double* 
  * src/rife.cpp:2653-2669; these do the same for the v4 schedule).  Planar CHW fp32 host arrays. ------------- */
 int rife_hip_v4_extract_flow(const rife_hip_t* r, const uint8_t* in0_rgb, const uint8_t* in1_rgb, int w, int h,
                              float timestep, int fi, const float* const* inject, int n_inject, float* out6chw);
+/* shape of blob flow{fi} for frames of w x h: rife-v4.6 6 x hp/s x wp/s (PixelShuffle output, models/rife-v4.6/flownet.param:46),
+ * rife-v4 5 x hp/2s x wp/2s (Deconvolution output, models/rife-v4/flownet.param:33); s = 8, 4, 2, 1. */
+int rife_hip_v4_flow_dims(const rife_hip_t* r, int w, int h, int fi, int* channels, int* fh, int* fw);
 
 /* ---- single-kernel entry points for per-kernel parity tests (host arrays, planar CHW fp32 like ncnn::Mat) --- */
 /* 3x3 conv, pad 1, stride 1|2, + bias, optional residual add (same shape as output), per-channel negative slope

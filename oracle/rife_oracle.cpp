@@ -430,8 +430,12 @@ int oracle_v4_extract(void* h, const uint8_t* in0, const uint8_t* in1, int w, in
     ex.input("in0", a); ex.input("in1", b); ex.input("in2", t);
     static const char* names[4] = {"flow0", "flow1", "flow2", "flow3"};
     static const int scale[4] = {8, 4, 2, 1};
+    // blob flow{k}: PixelShuffle output (6 ch at 1/s, rife-v4.6) or Deconvolution output (5 ch at 1/2s, rife-v4)
+    const int fb = R->flownet.find_blob("flow0");
+    const bool deconv_flow = fb >= 0 && R->flownet.layers[R->flownet.producer[fb]].type == "Deconvolution";
     for (int k = 0; k < n_inject; k++) {
-        Mat f(wp / scale[k], hp / scale[k], 6);
+        const int div = deconv_flow ? 2 * scale[k] : scale[k];
+        Mat f(wp / div, hp / div, deconv_flow ? 5 : 6);
         std::memcpy(f.data, flows_in[k], f.total() * sizeof(float));
         ex.input(names[k], f);
     }

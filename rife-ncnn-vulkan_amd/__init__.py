@@ -23,7 +23,7 @@ _lib = None
 C_ABI_SYMBOLS = [
     "rife_hip_device_count", "rife_hip_create", "rife_hip_destroy", "rife_hip_load", "rife_hip_process",
     "rife_hip_process_device", "rife_hip_last_error", "rife_hip_profile_enable", "rife_hip_profile_read",
-    "rife_hip_v4_extract_flow", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
+    "rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
 ]
 
 
@@ -64,6 +64,7 @@ def lib():
     L.rife_hip_profile_enable.argtypes = [vp, ci]
     L.rife_hip_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, vp, vp, vp, ci]
     L.rife_hip_v4_extract_flow.argtypes = [vp, vp, vp, ci, ci, cf, ci, vp, ci, vp]
+    L.rife_hip_v4_flow_dims.argtypes = [vp, ci, ci, ci, vp, vp, vp]
     L.rife_hip_op_conv3x3.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, ci, vp, vp, vp]
     L.rife_hip_op_deconv4x4.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, vp, vp]
     L.rife_hip_op_warp.argtypes = [ci, vp, vp, ci, ci, ci, vp]
@@ -135,9 +136,9 @@ class RIFE:
     def v4_extract_flow(self, in0image, in1image, timestep, fi, inject=()):
         a = np.ascontiguousarray(in0image, dtype=np.uint8); b = np.ascontiguousarray(in1image, dtype=np.uint8)
         h, w, _ = a.shape
-        wp, hp = (w + 31) // 32 * 32, (h + 31) // 32 * 32
-        s = (8, 4, 2, 1)[fi]
-        out = np.empty((6, hp // s, wp // s), np.float32)
+        nc, fh, fw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(lib().rife_hip_v4_flow_dims(self._h, w, h, fi, ctypes.byref(nc), ctypes.byref(fh), ctypes.byref(fw)), "v4_flow_dims")
+        out = np.empty((nc.value, fh.value, fw.value), np.float32)
         inj = [np.ascontiguousarray(f, dtype=np.float32) for f in inject]
         arr = (ctypes.c_void_p * max(1, len(inj)))(*[f.ctypes.data for f in inj])
         _check(lib().rife_hip_v4_extract_flow(self._h, _p(a), _p(b), w, h, float(timestep), fi, arr, len(inj), _p(out)), "v4_extract_flow")

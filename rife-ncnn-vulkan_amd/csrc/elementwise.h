@@ -226,6 +226,49 @@ __global__ void k_final(const uint32_t* __restrict__ img0, const uint32_t* __res
     o[2] = (uint8_t)min(max((int)(b * 255.f + 0.5f), 0), 255);
 }
 
+// rife-v4 (4.0) tail (models/rife-v4/flownet.param:154-168): F and M are final after the block-3 flow update;
+//   m = sigmoid(M); out = warp(in0,F.xy)*m + warp(in1,F.zw)*(1-m); then the same postproc as k_final.
+__global__ void k_blend_final(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, const float4* __restrict__ F,
+                              const float* __restrict__ M, uint8_t* __restrict__ out, int w, int h, int wp, int hp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t i = (size_t)y * wp + x;
+    const float4 f = F[i];
+    const float m = 1.f / (1.f + expf(-M[i]));
+    const float rm = 1.0f - m;
+    const float3 w1 = warp_rgbx(img1, x, y, f.z, f.w, wp, hp);
+    const float3 w0 = warp_rgbx(img0, x, y, f.x, f.y, wp, hp);
+    const float r = w0.x * m + w1.x * rm, g = w0.y * m + w1.y * rm, b = w0.z * m + w1.z * rm;
+    uint8_t* o = out + ((size_t)y * w + x) * 3;
+    o[0] = (uint8_t)min(max((int)(r * 255.f + 0.5f), 0), 255);
+    o[1] = (uint8_t)min(max((int)(g * 255.f + 0.5f), 0), 255);
+    o[2] = (uint8_t)min(max((int)(b * 255.f + 0.5f), 0), 255);
+}
+
+// the same without postproc: out0 as float4 per padded pixel (TTA averaging)
+__global__ void k_blend_final_float(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, const float4* __restrict__ F,
+                                    const float* __restrict__ M, float4* __restrict__ out, int wp, int hp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wp) return;
+    const size_t i = (size_t)y * wp + x;
+    const float4 f = F[i];
+    const float m = 1.f / (1.f + expf(-M[i]));
+    const float rm = 1.0f - m;
+    const float3 w1 = warp_rgbx(img1, x, y, f.z, f.w, wp, hp);
+    const float3 w0 = warp_rgbx(img0, x, y, f.x, f.y, wp, hp);
+    out[i] = make_float4(w0.x * m + w1.x * rm, w0.y * m + w1.y * rm, w0.z * m + w1.z * rm, 0.f);
+}
+
+// a += b (BinaryOp add closing a rife-v4 (4.0) IFBlock trunk)
+__global__ void k_add_inplace(float4* __restrict__ a, const float4* __restrict__ b, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 x = a[i];
+    const float4 y = b[i];
+    x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+    a[i] = x;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // TTA (-x spatial, -z temporal), rife-v4:  rife_preproc_tta.comp:40-93, rife_v4_flow_tta_avg.comp:25-129,
 // rife_v4_flow_tta_temporal_avg.comp:19-59, rife_postproc_tta.comp:40-81, rife_out_tta_temporal_avg.comp:19-36

@@ -569,6 +569,7 @@ struct Ctx {
     uint8_t *d_in0 = nullptr, *d_in1 = nullptr, *d_out = nullptr;   // staging for the host-buffer entry point
     uint32_t *img0 = nullptr, *img1 = nullptr;                       // padded RGBX u8
     float *X = nullptr, *S1 = nullptr, *T0 = nullptr, *T1 = nullptr; // block input, stem-1 output, trunk ping/pong
+    float *T2 = nullptr;                                             // rife-v4 (4.0): stem-1 output kept for the block's residual add
     float* flow[4] = {nullptr, nullptr, nullptr, nullptr};           // [hp/s][wp/s][8]
     float4* F = nullptr; float* M = nullptr;                         // full-resolution flow (4ch) and mask logit
     float4* outf = nullptr;                                          // TTA only: out0 as float, padded
@@ -611,8 +612,12 @@ struct rife_hip {
     bool tta = false, tta_temporal = false, uhd = false, v2 = false, v4 = false;
     int num_threads = 1;
     bool loaded = false;
-    // v4.6 schedule: per block {stem0, stem1, res x8, head}
+    // v4.x schedule: per block {stem0, stem1, res x8, head}
     struct Block { ConvLayer stem0, stem1, res[8], head; int c = 0, scale = 1; } blk[4];
+    // rife-v4 (4.0) variant of the schedule: PReLU, plain trunk + one residual add, 5-channel deconv head at half the block
+    // resolution (flow{b} is [hp/2s][wp/2s][8] instead of [hp/s][wp/s][8])
+    bool v40 = false;
+    int flow_div(int b) const { return v40 ? 2 * blk[b].scale : blk[b].scale; }
     // rife-v2.x schedule (IFNet + ContextNet + FusionNet)
     struct V2Block { ConvLayer stem0, stem1, conv[6], head; int c = 0, scale = 1; } fblk[4];
     ConvLayer ctxc[10];          // ContextNet convs in graph order
@@ -663,7 +668,7 @@ static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scra
         if ((rc = dalloc(c, c.img0, P))) return rc;
         if ((rc = dalloc(c, c.img1, P))) return rc;
     }
-    if (scratch) { c.X = scratch->X; c.S1 = scratch->S1; c.T0 = scratch->T0; c.T1 = scratch->T1; }
+    if (scratch) { c.X = scratch->X; c.S1 = scratch->S1; c.T0 = scratch->T0; c.T1 = scratch->T1; c.T2 = scratch->T2; }
     else {
         if ((rc = dalloc(c, c.d_in0, (size_t)w * h * 3))) return rc;
         if ((rc = dalloc(c, c.d_in1, (size_t)w * h * 3))) return rc;
@@ -672,6 +677,7 @@ static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scra
         if ((rc = dalloc(c, c.S1, P / 4 * 32))) return rc;             // block 3 stem-0 output: (hp/2 x wp/2) x 32
         if ((rc = dalloc(c, c.T0, P / 16 * 64))) return rc;            // block 3 trunk: (hp/4 x wp/4) x 64 (the largest trunk)
         if ((rc = dalloc(c, c.T1, P / 16 * 64))) return rc;
+        if ((rc = dalloc(c, c.T2, P / 16 * 64))) return rc;
     }
     static const int sc[4] = {8, 4, 2, 1};
     for (int b = 0; b < 4; b++) {
@@ -745,16 +751,24 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         Timed t(E.prof, B.stem0.cls, B.stem0.flops_per_pixel * (Hb / 2) * (Wb / 2), st);
         if ((rc = launch_conv(B.stem0, {c.X, xin_ld, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, nullptr, st))) return rc;
     }
+    float* const stem_out = E.v40 ? c.T2 : c.T0;
     {
         Timed t(E.prof, B.stem1.cls, B.stem1.flops_per_pixel * (Hb / 4) * (Wb / 4), st);
-        if ((rc = launch_conv(B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {c.T0, B.c, 0}, nullptr, st))) return rc;
+        if ((rc = launch_conv(B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {stem_out, B.c, 0}, nullptr, st))) return rc;
     }
-    float* cur = c.T0; float* nxt = c.T1;
+    float* cur = stem_out; float* nxt = E.v40 ? c.T0 : c.T1;
     const int Ht = Hb / 4, Wt = Wb / 4;
     for (int i = 0; i < 8; i++) {
         Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
-        if ((rc = launch_conv(B.res[i], {cur, B.c, 0}, Ht, Wt, {nxt, B.c, 0}, nullptr, st))) return rc;   // skip folded into the weights
-        std::swap(cur, nxt);
+        if ((rc = launch_conv(B.res[i], {cur, B.c, 0}, Ht, Wt, {nxt, B.c, 0}, nullptr, st))) return rc;   // v4.6: skip folded into the weights
+        if (E.v40 && i == 0) { cur = c.T0; nxt = c.T1; }
+        else std::swap(cur, nxt);
+    }
+    if (E.v40) {   // add_0 / add_3 / add_8 / add_12 (models/rife-v4/flownet.param): trunk output + stem output, no activation
+        Timed t(E.prof, "v40_block_add", 0, st);
+        const size_t n4 = (size_t)Ht * Wt * B.c / 4;
+        hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<float4*>(cur), reinterpret_cast<const float4*>(c.T2), n4);
+        HIPCHK(hipGetLastError());
     }
     {
         Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);
@@ -767,6 +781,14 @@ static int run_flow_update(const rife_hip& E, Ctx& c, int b) {
     hipStream_t st = c.stream;
     Timed t(E.prof, "flow_update", 0, st);
     dim3 g = grid2d(c.wp, c.hp);
+    if (E.v40) {   // Interp x(2 x scale) of the 5-channel head output, then F (+)= u[0:4] * (2 x scale), M (+)= u[4]
+        if (b == 0) hipLaunchKernelGGL((k_flow_update<16, true>), g, dim3(256), 0, st, c.flow[0], c.F, c.M, c.wp, c.hp);
+        else if (b == 1) hipLaunchKernelGGL((k_flow_update<8, false>), g, dim3(256), 0, st, c.flow[1], c.F, c.M, c.wp, c.hp);
+        else if (b == 2) hipLaunchKernelGGL((k_flow_update<4, false>), g, dim3(256), 0, st, c.flow[2], c.F, c.M, c.wp, c.hp);
+        else hipLaunchKernelGGL((k_flow_update<2, false>), g, dim3(256), 0, st, c.flow[3], c.F, c.M, c.wp, c.hp);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (b == 0) hipLaunchKernelGGL((k_flow_update<8, true>), g, dim3(256), 0, st, c.flow[0], c.F, c.M, c.wp, c.hp);
     else if (b == 1) hipLaunchKernelGGL((k_flow_update<4, false>), g, dim3(256), 0, st, c.flow[1], c.F, c.M, c.wp, c.hp);
     else hipLaunchKernelGGL((k_flow_update<2, false>), g, dim3(256), 0, st, c.flow[2], c.F, c.M, c.wp, c.hp);
@@ -785,13 +807,17 @@ static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
         hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.img1, c.wp, c.hp);
         HIPCHK(hipGetLastError());
     }
-    const bool fuse_tail = g_trunk_h2 && g_head_h2 && g_fuse_tail && E.blk[3].head.d_wh != nullptr;
+    const bool fuse_tail = !E.v40 && g_trunk_h2 && g_head_h2 && g_fuse_tail && E.blk[3].head.d_wh != nullptr;
     FinalArgs fin{c.img0, c.img1, c.F, c.M, d_out, c.w, c.h, c.wp, c.hp};
     for (int b = 0; b < 4; b++) {
         if ((rc = run_block_convs(E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr))) return rc;
-        if (b < 3 && (rc = run_flow_update(E, c, b))) return rc;
+        if ((b < 3 || E.v40) && (rc = run_flow_update(E, c, b))) return rc;
     }
-    if (!fuse_tail) {
+    if (E.v40) {
+        Timed t(E.prof, "final", 0, st);
+        hipLaunchKernelGGL(k_blend_final, grid2d(c.w, c.h), dim3(256), 0, st, c.img0, c.img1, c.F, c.M, d_out, c.w, c.h, c.wp, c.hp);
+        HIPCHK(hipGetLastError());
+    } else if (!fuse_tail) {
         Timed t(E.prof, "final", 0, st);
         hipLaunchKernelGGL(k_final, grid2d(c.w, c.h), dim3(256), 0, st, c.img0, c.img1, c.F, c.M, c.flow[3], d_out, c.w, c.h, c.wp, c.hp);
         HIPCHK(hipGetLastError());
@@ -859,9 +885,8 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
         }
         HIPCHK(hipGetLastError());
     }
-    static const int SC[4] = {8, 4, 2, 1};
     for (int fi = 0; fi < 4; fi++) {
-        const int Wf = wp / SC[fi], Hf = hp / SC[fi];
+        const int Wf = wp / E.flow_div(fi), Hf = hp / E.flow_div(fi);
         if ((rc = fork())) return rc;
         for (int ti = 0; ti < nori; ti++) {
             hipStream_t ls = lane_of(ti);
@@ -887,8 +912,7 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
             }
             HIPCHK(hipGetLastError());
         }
-        if (fi < 3) {
-            if (fi == 2) { /* the fork at the top of the next stage covers it */ }
+        if (fi < 3 || E.v40) {
             if (lanes) {   // flow updates run on the lanes; they must see the consensus written on the caller's stream
                 HIPCHK(hipEventRecord(E.tta_fork[5], st));
                 for (int l = 0; l < NL; l++) HIPCHK(hipStreamWaitEvent(E.tta_lane[l], E.tta_fork[5], 0));
@@ -906,7 +930,8 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
             for (int dir = 0; dir < ntemp; dir++) {
                 Ctx& c = *E.tta_ctx[dir][ti];
                 Timed t(E.prof, "final", 0, c.stream);
-                hipLaunchKernelGGL(k_final_float, grid2d(c.wp, c.hp), dim3(256), 0, c.stream, c.img0, c.img1, c.F, c.M, c.flow[3], c.outf, c.wp, c.hp);
+                if (E.v40) hipLaunchKernelGGL(k_blend_final_float, grid2d(c.wp, c.hp), dim3(256), 0, c.stream, c.img0, c.img1, c.F, c.M, c.outf, c.wp, c.hp);
+                else hipLaunchKernelGGL(k_final_float, grid2d(c.wp, c.hp), dim3(256), 0, c.stream, c.img0, c.img1, c.F, c.M, c.flow[3], c.outf, c.wp, c.hp);
                 outs.p[dir * 8 + ti] = c.outf;
             }
         if ((rc = join())) return rc;
@@ -1291,10 +1316,53 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {
     NcnnModel m;
     const std::string base = std::string(modeldir) + "/flownet";
     if (!m.load_param(base + ".param")) return fail(RIFE_HIP_EIO, m.error);
-    if (m.structural_hash("out0") != V46_HASH_OUT0)
-        return fail(RIFE_HIP_EMODEL, base + ".param is not the rife-v4.6 IFNet graph this engine schedules");
+    const uint64_t gh = m.structural_hash("out0");
+    if (gh != V46_HASH_OUT0 && gh != RIFE_V40_HASH_OUT0)
+        return fail(RIFE_HIP_EMODEL, base + ".param is neither the rife-v4.6 nor the rife-v4 IFNet graph this engine schedules");
     if (!m.load_bin(base + ".bin")) return fail(RIFE_HIP_EIO, m.error);
     std::vector<const NcnnLayer*> wl = m.weighted();
+    E->v40 = gh == RIFE_V40_HASH_OUT0;
+    if (E->v40) {
+        // rife-v4 (4.0): every conv is followed by its PReLU in the weight stream; the 5-channel head is padded to 8 output channels
+        // (zero weights / bias) so that flow{b} keeps the [.][.][8] = {x, y, z, w, mask, 0, 0, 0} layout of the v4.6 schedule
+        static const int C[4] = {192, 128, 96, 64}, SC[4] = {8, 4, 2, 1};
+        size_t k = 0;
+        for (int b = 0; b < 4; b++) {
+            rife_hip::Block& B = E->blk[b];
+            B.c = C[b]; B.scale = SC[b];
+            static const char* const SN0[4] = {"stem0_b0", "stem0_b1", "stem0_b2", "stem0_b3"};
+            static const char* const SN1[4] = {"stem1_b0", "stem1_b1", "stem1_b2", "stem1_b3"};
+            static const char* const TN[4] = {"trunk_b0", "trunk_b1", "trunk_b2", "trunk_b3"};
+            static const char* const HN[4] = {"head_b0", "head_b1", "head_b2", "head_b3"};
+            auto take = [&](ConvLayer& L, int cin, int cout, int stride, bool deconv, const char* cls) -> int {
+                if (k >= wl.size()) return fail(RIFE_HIP_EMODEL, "weight stream ended early");
+                const NcnnLayer* nl = wl[k++];
+                const int kk = deconv ? 16 : 9;
+                if (nl->type != (deconv ? "Deconvolution" : "Convolution") || nl->geti(0, 0) != cout || (int)nl->weight.size() != cin * cout * kk ||
+                    nl->geti(3, 1) != stride)
+                    return fail(RIFE_HIP_EMODEL, "weighted layer " + nl->name + " does not match the rife-v4 schedule");
+                free_layer(L);
+                L.cin = cin; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = deconv ? EPI_DECONV : EPI_STORE; L.cls = cls; L.tag = 0; L.skip = false;
+                if (deconv) {
+                    L.cout = 8;
+                    std::vector<float> w((size_t)8 * cin * 16, 0.f), bias(8, 0.f);
+                    std::copy(nl->weight.begin(), nl->weight.end(), w.begin());              // ncnn deconv weights are [oc][ic][ky][kx]
+                    std::copy(nl->bias.begin(), nl->bias.end(), bias.begin());
+                    return upload_layer(L, w.data(), bias.data(), nullptr, 1.0f);
+                }
+                L.cout = cout;
+                if (k >= wl.size() || wl[k]->type != "PReLU" || (int)wl[k]->slope.size() != cout) return fail(RIFE_HIP_EMODEL, "PReLU expected after " + nl->name);
+                return upload_layer(L, nl->weight.data(), nl->bias.data(), wl[k++]->slope.data(), 1.0f);
+            };
+            if ((rc = take(B.stem0, b == 0 ? 7 : 12, C[b] / 2, 2, false, SN0[b]))) return rc;
+            if ((rc = take(B.stem1, C[b] / 2, C[b], 2, false, SN1[b]))) return rc;
+            for (int i = 0; i < 8; i++) if ((rc = take(B.res[i], C[b], C[b], 1, false, TN[b]))) return rc;
+            if ((rc = take(B.head, C[b], 5, 2, true, HN[b]))) return rc;
+        }
+        if (k != wl.size()) return fail(RIFE_HIP_EMODEL, "flownet.bin has extra weighted layers");
+        E->loaded = true;
+        return 0;
+    }
     if (wl.size() != 44) return fail(RIFE_HIP_EMODEL, "unexpected number of weighted layers");
     static const int C[4] = {192, 128, 96, 64}, SC[4] = {8, 4, 2, 1};
     size_t k = 0;
@@ -1471,20 +1539,29 @@ int rife_hip_v4_extract_flow(const rife_hip_t* E, const uint8_t* in0, const uint
     hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, c.stream, c.d_in1, c.w, c.h, c.img1, c.wp, c.hp);
     float* tmp = nullptr;
     if ((rc = dalloc(c, tmp, (size_t)c.wp * c.hp * 6))) return rc;
+    const int nc = E->v40 ? 5 : 6;      // channels of blob flow{b}: rife-v4.6 PixelShuffle output 6, rife-v4 deconv output 5
     for (int b = 0; b <= fi; b++) {
-        const int s = E->blk[b].scale, Hb = c.hp / s, Wb = c.wp / s;
+        const int s = E->flow_div(b), Hb = c.hp / s, Wb = c.wp / s;
         if (b < n_inject) {
-            HIPCHK(hipMemcpyAsync(tmp, inject[b], (size_t)Hb * Wb * 6 * 4, hipMemcpyHostToDevice, c.stream));
-            hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(Wb, Hb), dim3(256), 0, c.stream, tmp, c.flow[b], 6, Hb, Wb, 8);
+            HIPCHK(hipMemcpyAsync(tmp, inject[b], (size_t)Hb * Wb * nc * 4, hipMemcpyHostToDevice, c.stream));
+            hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(Wb, Hb), dim3(256), 0, c.stream, tmp, c.flow[b], nc, Hb, Wb, 8);
         } else {
             if ((rc = run_block_convs(*E, c, b, timestep))) return rc;
         }
         if (b < fi && (rc = run_flow_update(*E, c, b))) return rc;
     }
-    const int s = E->blk[fi].scale, Hb = c.hp / s, Wb = c.wp / s;
-    hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(Wb, Hb), dim3(256), 0, c.stream, c.flow[fi], tmp, 6, Hb, Wb, 8);
-    HIPCHK(hipMemcpyAsync(out6chw, tmp, (size_t)Hb * Wb * 6 * 4, hipMemcpyDeviceToHost, c.stream));
+    const int s = E->flow_div(fi), Hb = c.hp / s, Wb = c.wp / s;
+    hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(Wb, Hb), dim3(256), 0, c.stream, c.flow[fi], tmp, nc, Hb, Wb, 8);
+    HIPCHK(hipMemcpyAsync(out6chw, tmp, (size_t)Hb * Wb * nc * 4, hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+int rife_hip_v4_flow_dims(const rife_hip_t* E, int w, int h, int fi, int* channels, int* fh, int* fw) {
+    if (!E || !E->loaded || !E->v4) return fail(RIFE_HIP_EINVAL, "flow blobs exist for a loaded rife-v4 family engine only");
+    if (fi < 0 || fi > 3 || w <= 0 || h <= 0 || !channels || !fh || !fw) return fail(RIFE_HIP_EINVAL, "bad argument");
+    const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;
+    *channels = E->v40 ? 5 : 6; *fh = hp / E->flow_div(fi); *fw = wp / E->flow_div(fi);
     return 0;
 }
 

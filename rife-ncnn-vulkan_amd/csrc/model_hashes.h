@@ -2,6 +2,7 @@
 // schedules were written for.  Regenerate with tools/param_hash.py after changing the hash function.
 #pragma once
 #define RIFE_V46_HASH_OUT0 0xee408936024d43cfull   /* models/rife-v4.6/flownet.param, blob "out0" */
+#define RIFE_V40_HASH_OUT0 0xc679a7939b863e18ull   /* models/rife-v4/flownet.param, blob "out0" */
 /* models/rife-v2.3 (== rife-v2, rife-v2.4): flownet "flow", contextnet "f1".."f4", fusionnet "output" */
 #define RIFE_V23_HASH_FLOW 0xaf09294daee7aff7ull
 #define RIFE_V23_HASH_F1 0x91ca51f8d25c3b93ull

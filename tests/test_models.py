@@ -9,6 +9,7 @@ from tools import gen_models, ncnn_param
 
 NAMED_OUTPUTS = {
     ("rife-v4.6", "flownet"): ["flow0", "flow1", "flow2", "flow3", "out0"],     # rife.cpp:3142-3145, 2653-2669
+    ("rife-v4", "flownet"): ["flow0", "flow1", "flow2", "flow3", "out0"],       # same blob contract, models/rife-v4/flownet.param
     ("rife-v2.3", "flownet"): ["flow"],                                          # rife.cpp:948-950
     ("rife-v2.3", "contextnet"): ["f1", "f2", "f3", "f4"],                       # rife.cpp:1027-1039
     ("rife-v2.3", "fusionnet"): ["output"],                                      # rife.cpp:1070-1098
@@ -37,7 +38,7 @@ def test_v2_family_graphs_identical(alias):
         assert a == b
 
 
-@pytest.mark.parametrize("fam", ["rife-v4.6", "rife-v2.3"])
+@pytest.mark.parametrize("fam", ["rife-v4.6", "rife-v2.3", "rife-v4"])
 def test_weight_count_identity(modeldirs, fam):
     """param[6] == oc*ic*k*k for every conv/deconv once channels are propagated."""
     for net in gen_models.FAMILIES[fam]:

@@ -180,6 +180,49 @@ def ifnet_v46():
     return g
 
 
+def ifnet_v40():
+    """rife-v4 (4.0) IFNet (models/rife-v4/flownet.param): the v4.6 skeleton with PReLU activations, a plain 8-conv trunk closed
+    by ONE residual add (no activation after it), and a 5-channel deconv head at half the block resolution that is
+    bilinearly upsampled by 2 x scale (no PixelShuffle)."""
+    g = Graph()
+    in0, in1, in2 = g.input("in0"), g.input("in1"), g.input("in2")
+    F = M = None
+    for b, (c, s) in enumerate(zip((192, 128, 96, 64), (8, 4, 2, 1))):
+        if b == 0:
+            x = g.interp(g.concat([in0, in1, in2]), 1.0 / s)
+            cin = 7
+        else:
+            Fd = g.scalar(g.interp(F, 1.0 / s), 2, 1.0 / s) if s > 1 else g.add("Interp", [F], ["0=2"])
+            w1 = g.warp(in1, g.crop(F, 2, 4))
+            w0 = g.warp(in0, g.crop(F, 0, 2))
+            x = g.concat([w0, w1, in2, M])
+            x = g.interp(x, 1.0 / s) if s > 1 else g.add("Interp", [x], ["0=2"])
+            x = g.concat([x, Fd])
+            cin = 12
+        x = g.prelu(g.conv(x, cin, c // 2, 2, kind="stem"), c // 2)
+        x = g.prelu(g.conv(x, c // 2, c, 2, kind="stem"), c)
+        t = x
+        for _ in range(8):
+            t = g.prelu(g.conv(t, c, c, kind="res"), c)
+        x = g.binary(t, x, 0)
+        flow = g.add("Deconvolution", [x], ["0=5", "1=4", "3=2", "4=1", "5=1", "6=%d" % (c * 5 * 16)], top_names=["flow%d" % b],
+                     meta=dict(w=(5, c, 4, 4), kind="head"))
+        u = g.interp(flow, 2.0 * s)
+        d4 = g.crop(u, 0, 4)
+        if b == 0:
+            F = g.scalar(d4, 2, 2.0 * s)
+            M = g.crop(u, 4, 5)
+        else:
+            F = g.wsum(F, d4, 1.0, 2.0 * s)
+            M = g.binary(M, g.crop(u, 4, 5), 0)
+    m = g.sigmoid(M)
+    rm = g.scalar(m, 7, 1.0)
+    a = g.binary(g.warp(in1, g.crop(F, 2, 4)), rm, 2)
+    bb = g.binary(g.warp(in0, g.crop(F, 0, 2)), m, 2)
+    g.binary(bb, a, 0, "out0")
+    return g
+
+
 def ifnet_v23():
     """rife-v2.3 IFNet: 4 blocks, trunks 384/256/192/96, 6 conv+PReLU each, deconv(4) heads,
     flow kept at half resolution, output = dF0+dF1+dF2+dF3."""
@@ -268,6 +311,7 @@ def fusionnet_v23():
 
 FAMILIES = {
     "rife-v4.6": {"flownet": ifnet_v46},
+    "rife-v4": {"flownet": ifnet_v40},
     "rife-v2.3": {"flownet": ifnet_v23, "contextnet": contextnet_v23, "fusionnet": fusionnet_v23},
 }
 
@@ -328,6 +372,8 @@ def generate(outdir, family="rife-v4.6", seed=0x51FE, real_contextnet=None):
             continue
         if family == "rife-v4.6":
             w = synth_weights(g, rng, head_gain=0.25, res_gain=0.5)
+        elif family == "rife-v4":
+            w = synth_weights(g, rng, head_gain=0.25)
         else:
             w = synth_weights(g, rng, head_gain=0.25 if net == "flownet" else 1.0)
         write_bin(os.path.join(outdir, net + ".bin"), w)
