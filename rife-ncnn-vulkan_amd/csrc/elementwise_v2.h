@@ -51,13 +51,14 @@ __device__ __forceinline__ float4 flow_up2x2(const float4* __restrict__ flow, in
     return u;
 }
 
-// IFNet block 0 input: Interp(1/8)(Concat(input0, input1)) -> NHWC8 {rgb0, rgb1, 0, 0}   (flownet.param:5-7)
-template <typename IMG>
+// IFNet block 0 input: Interp(1/S)(Concat(input0, input1)) -> NHWC8 {rgb0, rgb1, 0, 0}   (S = 8: rife-v2.3 flownet.param:5-7;
+// S = 4: rife-v3.x flownet.param:6-8)
+template <int S, typename IMG>
 __global__ void k2_assemble0(IMG img0, IMG img1, float* __restrict__ X, int wp, int hp) {
-    const int Wb = wp / 8, Hb = hp / 8;
+    const int Wb = wp / S, Hb = hp / S;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= Wb || y >= Hb) return;
-    const size_t i00 = (size_t)(8 * y + 3) * wp + 8 * x + 3, i10 = i00 + wp;
+    const size_t i00 = (size_t)(S * y + S / 2 - 1) * wp + S * x + S / 2 - 1, i10 = i00 + wp;
     const float3 a0 = img0.at(i00), a1 = img0.at(i00 + 1), a2 = img0.at(i10), a3 = img0.at(i10 + 1);
     const float3 b0 = img1.at(i00), b1 = img1.at(i00 + 1), b2 = img1.at(i10), b3 = img1.at(i10 + 1);
     float4* dst = reinterpret_cast<float4*>(X + ((size_t)y * Wb + x) * 8);
@@ -67,7 +68,8 @@ __global__ void k2_assemble0(IMG img0, IMG img1, float* __restrict__ X, int wp, 
 
 // IFNet blocks 1..3 and FusionNet input (flownet.param:27-37, 58-68, 90-99; fusionnet.param:14-23):
 //   Ff = 2*Interp(x2)(acc);  x = Interp(1/S)(Concat(warp(img0, Ff.xy), warp(img1, Ff.zw), Ff))  -> NHWC16 (10 + 6 zero)
-template <int S, typename IMG>
+// FSCALE (rife-v3.x, flownet.param:44-46, 83-85): the flow channels are additionally multiplied by 1/S after the resize
+template <int S, typename IMG, bool FSCALE = false>
 __global__ void k2_assemble(IMG img0, IMG img1, const float4* __restrict__ acc, float* __restrict__ X, int wp, int hp) {
     const int Wb = wp / S, Hb = hp / S;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -92,6 +94,10 @@ __global__ void k2_assemble(IMG img0, IMG img1, const float4* __restrict__ acc, 
         }
 #pragma unroll
         for (int c = 0; c < 10; c++) o[c] = down4(v[0][c], v[1][c], v[2][c], v[3][c]);
+        if (FSCALE) {
+#pragma unroll
+            for (int c = 6; c < 10; c++) o[c] = o[c] * (1.0f / (float)S);
+        }
     }
     float4* dst = reinterpret_cast<float4*>(X + ((size_t)y * Wb + x) * 16);
     dst[0] = make_float4(o[0], o[1], o[2], o[3]);
@@ -102,7 +108,8 @@ __global__ void k2_assemble(IMG img0, IMG img1, const float4* __restrict__ acc, 
 
 // running flow sum at half resolution: acc = (FIRST ? 0 : acc) + Interp(xS)(D)   (flownet.param:25, 56, 87, 117-119)
 // D = deconv output, float4 per pixel at (hh/S x wh/S); acc float4 at (hh x wh)
-template <int S, bool FIRST>
+// MUL (rife-v3.x, flownet.param:31-32, 71-72): the upsampled head output is multiplied by S before the sum
+template <int S, bool FIRST, bool MUL = false>
 __global__ void k2_flow_accum(const float4* __restrict__ D, float4* __restrict__ acc, int wh, int hh) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= wh) return;
@@ -119,6 +126,7 @@ __global__ void k2_flow_accum(const float4* __restrict__ D, float4* __restrict__
         u.y = (q00.y * a0 + q01.y * a1) * b0 + (q10.y * a0 + q11.y * a1) * b1;
         u.z = (q00.z * a0 + q01.z * a1) * b0 + (q10.z * a0 + q11.z * a1) * b1;
         u.w = (q00.w * a0 + q01.w * a1) * b0 + (q10.w * a0 + q11.w * a1) * b1;
+        if (MUL) { const float sc = (float)S; u.x = u.x * sc; u.y = u.y * sc; u.z = u.z * sc; u.w = u.w * sc; }
     }
     const size_t i = (size_t)y * wh + x;
     if (FIRST) acc[i] = u;

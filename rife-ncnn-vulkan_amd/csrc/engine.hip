@@ -620,6 +620,9 @@ struct rife_hip {
     int flow_div(int b) const { return v40 ? 2 * blk[b].scale : blk[b].scale; }
     // rife-v2.x schedule (IFNet + ContextNet + FusionNet)
     struct V2Block { ConvLayer stem0, stem1, conv[6], head; int c = 0, scale = 1; } fblk[4];
+    // rife-v3.x: same ContextNet / FusionNet, IFNet of 3 blocks (scales 4, 2, 1; 160 channels; trunk = 3 x [conv, conv, + skip])
+    bool v3 = false;
+    int n_fblk = 4;
     ConvLayer ctxc[10];          // ContextNet convs in graph order
     ConvLayer fus[15];           // FusionNet: 10 down convs, 4 up deconvs, sigmoid head
     mutable Profiler prof;
@@ -945,11 +948,11 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
 // ------------------------------------------------------------------------------------------------
 // rife-v2.x: RIFE::process, non-TTA branch (rife.cpp:878-1183) = flownet -> slice -> contextnet x2 -> fusionnet
 // ------------------------------------------------------------------------------------------------
-static int ensure_ctx_v2(Ctx& c, int w, int h, bool uhd, int nori = 1, int ntemp = 1) {
+static int ensure_ctx_v2(Ctx& c, int w, int h, bool uhd, int nori = 1, int ntemp = 1, bool v3 = false) {
     const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;     // rife.cpp:417-418
     const bool ens = nori * ntemp > 1;
-    if (c.v2 && c.wp == wp && c.hp == hp && c.w == w && c.h == h && (!uhd || c.h0) && (!ens || (c.toutf[0][0] && c.toutf[ntemp - 1][nori - 1]))) return 0;
-    c.h0 = c.h1 = c.acc_s = nullptr;
+    if (c.v2 && c.wp == wp && c.hp == hp && c.w == w && c.h == h && (!uhd || c.h0) && (!ens || (c.toutf[0][0] && c.toutf[ntemp - 1][nori - 1])) && (!v3 || c.T2)) return 0;
+    c.h0 = c.h1 = c.acc_s = nullptr; c.T2 = nullptr;
     for (int d = 0; d < 2; d++) for (int t = 0; t < 8; t++) { c.tflow[d][t] = c.toutf[d][t] = nullptr; if (!d) c.timg0[t] = c.timg1[t] = nullptr; }
     for (void* p : c.allocs) (void)hipFree(p);
     c.allocs.clear();
@@ -959,7 +962,8 @@ static int ensure_ctx_v2(Ctx& c, int w, int h, bool uhd, int nori = 1, int ntemp
 #define A_(ptr, n) if ((rc = dalloc(c, ptr, (size_t)(n)))) return rc;
     A_(c.d_in0, (size_t)w * h * 3) A_(c.d_in1, (size_t)w * h * 3) A_(c.d_out, (size_t)w * h * 3)
     A_(c.img0, P) A_(c.img1, P)
-    A_(c.X, P * 16) A_(c.S1, P / 4 * 48) A_(c.T0, P / 16 * 96) A_(c.T1, P / 16 * 96)
+    if (v3) { A_(c.X, P * 16) A_(c.S1, P / 4 * 80) A_(c.T0, P / 16 * 160) A_(c.T1, P / 16 * 160) A_(c.T2, P / 16 * 160) }   // rife-v3.x block 2: 80 / 160 ch at 1/2, 1/4 res
+    else { A_(c.X, P * 16) A_(c.S1, P / 4 * 48) A_(c.T0, P / 16 * 96) A_(c.T1, P / 16 * 96) }
     A_(c.acc, P / 4) A_(c.D, P / 4) A_(c.head, P)
     A_(c.I8, P * 8) A_(c.ca, P / 4 * 32) A_(c.cb, P / 4 * 32) A_(c.cc, P / 16 * 32)
     A_(c.feat[0], P / 16 * 32) A_(c.feat[1], P / 64 * 64) A_(c.feat[2], P / 256 * 128) A_(c.feat[3], P / 1024 * 256)
@@ -991,31 +995,54 @@ static int run_v2_ifnet(const rife_hip& E, Ctx& c, IMG img0, IMG img1, int wp, i
     hipStream_t st = c.stream;
     const int wh = wp / 2, hh = hp / 2;
     int rc;
-    for (int b = 0; b < 4; b++) {
+    for (int b = 0; b < E.n_fblk; b++) {
         const rife_hip::V2Block& B = E.fblk[b];
         const int s = B.scale, Hb = hp / s, Wb = wp / s;
         {
             Timed t(E.prof, "v2_assemble", 0, st);
             dim3 g = grid2d(Wb, Hb);
-            if (b == 0) hipLaunchKernelGGL(k2_assemble0<IMG>, g, dim3(256), 0, st, img0, img1, c.X, wp, hp);
+            if (b == 0 && s == 8) hipLaunchKernelGGL((k2_assemble0<8, IMG>), g, dim3(256), 0, st, img0, img1, c.X, wp, hp);
+            else if (b == 0) hipLaunchKernelGGL((k2_assemble0<4, IMG>), g, dim3(256), 0, st, img0, img1, c.X, wp, hp);
+            else if (E.v3 && s == 2) hipLaunchKernelGGL((k2_assemble<2, IMG, true>), g, dim3(256), 0, st, img0, img1, acc, c.X, wp, hp);
             else if (s == 4) hipLaunchKernelGGL((k2_assemble<4, IMG>), g, dim3(256), 0, st, img0, img1, acc, c.X, wp, hp);
             else if (s == 2) hipLaunchKernelGGL((k2_assemble<2, IMG>), g, dim3(256), 0, st, img0, img1, acc, c.X, wp, hp);
-            else hipLaunchKernelGGL((k2_assemble<1, IMG>), g, dim3(256), 0, st, img0, img1, acc, c.X, wp, hp);
+            else hipLaunchKernelGGL((k2_assemble<1, IMG>), g, dim3(256), 0, st, img0, img1, acc, c.X, wp, hp);   // v3: x 1.0 (Mul_139) is the identity
             HIPCHK(hipGetLastError());
         }
         if ((rc = conv_t(E, B.stem0, {c.X, b == 0 ? 8 : 16, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, st))) return rc;
         if ((rc = conv_t(E, B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {c.T0, B.c, 0}, st))) return rc;
-        float* cur = c.T0; float* nxt = c.T1;
+        float* cur = c.T0;
         const int Ht = Hb / 4, Wt = Wb / 4;
-        for (int i = 0; i < 6; i++) {
-            if ((rc = conv_t(E, B.conv[i], {cur, B.c, 0}, Ht, Wt, {nxt, B.c, 0}, st))) return rc;
-            std::swap(cur, nxt);
+        if (E.v3) {
+            // 3 x [conv + PReLU, conv + PReLU, BinaryOp add with the block input] (rife-v3.1 flownet.param:12-29)
+            float* tmp = c.T1; float* nxt = c.T2;
+            const size_t n4 = (size_t)Ht * Wt * B.c / 4;
+            for (int i = 0; i < 3; i++) {
+                if ((rc = conv_t(E, B.conv[2 * i], {cur, B.c, 0}, Ht, Wt, {tmp, B.c, 0}, st))) return rc;
+                if ((rc = conv_t(E, B.conv[2 * i + 1], {tmp, B.c, 0}, Ht, Wt, {nxt, B.c, 0}, st))) return rc;
+                {
+                    Timed t(E.prof, "v3_res_add", 0, st);
+                    hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<float4*>(nxt), reinterpret_cast<const float4*>(cur), n4);
+                    HIPCHK(hipGetLastError());
+                }
+                std::swap(cur, nxt);
+            }
+        } else {
+            float* nxt = c.T1;
+            for (int i = 0; i < 6; i++) {
+                if ((rc = conv_t(E, B.conv[i], {cur, B.c, 0}, Ht, Wt, {nxt, B.c, 0}, st))) return rc;
+                std::swap(cur, nxt);
+            }
         }
         if ((rc = conv_t(E, B.head, {cur, B.c, 0}, Ht, Wt, {reinterpret_cast<float*>(c.D), 4, 0}, st))) return rc;
         {
             Timed t(E.prof, "v2_flow_accum", 0, st);
             dim3 g = grid2d(wh, hh);
-            if (b == 0) hipLaunchKernelGGL((k2_flow_accum<8, true>), g, dim3(256), 0, st, c.D, acc, wh, hh);
+            if (E.v3) {
+                if (b == 0) hipLaunchKernelGGL((k2_flow_accum<4, true, true>), g, dim3(256), 0, st, c.D, acc, wh, hh);
+                else if (b == 1) hipLaunchKernelGGL((k2_flow_accum<2, false, true>), g, dim3(256), 0, st, c.D, acc, wh, hh);
+                else hipLaunchKernelGGL((k2_flow_accum<1, false>), g, dim3(256), 0, st, c.D, acc, wh, hh);
+            } else if (b == 0) hipLaunchKernelGGL((k2_flow_accum<8, true>), g, dim3(256), 0, st, c.D, acc, wh, hh);
             else if (b == 1) hipLaunchKernelGGL((k2_flow_accum<4, false>), g, dim3(256), 0, st, c.D, acc, wh, hh);
             else if (b == 2) hipLaunchKernelGGL((k2_flow_accum<2, false>), g, dim3(256), 0, st, c.D, acc, wh, hh);
             else hipLaunchKernelGGL((k2_flow_accum<1, false>), g, dim3(256), 0, st, c.D, acc, wh, hh);
@@ -1209,10 +1236,13 @@ static int load_v2(rife_hip* E, const std::string& dir) {
     if (!mf.load_param(dir + "/flownet.param")) return fail(RIFE_HIP_EIO, mf.error);
     if (!mc.load_param(dir + "/contextnet.param")) return fail(RIFE_HIP_EIO, mc.error);
     if (!mu.load_param(dir + "/fusionnet.param")) return fail(RIFE_HIP_EIO, mu.error);
-    if (mf.structural_hash("flow") != RIFE_V23_HASH_FLOW || mc.structural_hash("f1") != RIFE_V23_HASH_F1 ||
+    const uint64_t fh = mf.structural_hash("flow");
+    E->v3 = fh == RIFE_V3_HASH_FLOW;
+    E->n_fblk = E->v3 ? 3 : 4;
+    if ((fh != RIFE_V23_HASH_FLOW && fh != RIFE_V3_HASH_FLOW) || mc.structural_hash("f1") != RIFE_V23_HASH_F1 ||
         mc.structural_hash("f2") != RIFE_V23_HASH_F2 || mc.structural_hash("f3") != RIFE_V23_HASH_F3 ||
         mc.structural_hash("f4") != RIFE_V23_HASH_F4 || mu.structural_hash("output") != RIFE_V23_HASH_OUTPUT)
-        return fail(RIFE_HIP_EMODEL, dir + " does not hold the rife-v2.x IFNet/ContextNet/FusionNet graphs this engine schedules");
+        return fail(RIFE_HIP_EMODEL, dir + " does not hold the rife-v2.x / rife-v3.x IFNet/ContextNet/FusionNet graphs this engine schedules");
     if (!mf.load_bin(dir + "/flownet.bin")) return fail(RIFE_HIP_EIO, mf.error);
     if (!mc.load_bin(dir + "/contextnet.bin")) return fail(RIFE_HIP_EIO, mc.error);
     if (!mu.load_bin(dir + "/fusionnet.bin")) return fail(RIFE_HIP_EIO, mu.error);
@@ -1235,8 +1265,9 @@ static int load_v2(rife_hip* E, const std::string& dir) {
     };
     {
         std::vector<const NcnnLayer*> wl = mf.weighted(); size_t k = 0;
-        static const int C[4] = {384, 256, 192, 96}, SC[4] = {8, 4, 2, 1};
-        for (int b = 0; b < 4; b++) {
+        static const int C2[4] = {384, 256, 192, 96}, SC2[4] = {8, 4, 2, 1}, C3[4] = {160, 160, 160, 0}, SC3[4] = {4, 2, 1, 1};
+        const int* C = E->v3 ? C3 : C2; const int* SC = E->v3 ? SC3 : SC2;
+        for (int b = 0; b < E->n_fblk; b++) {
             rife_hip::V2Block& B = E->fblk[b];
             B.c = C[b]; B.scale = SC[b];
             if ((rc = take(wl, k, B.stem0, b == 0 ? 6 : 10, C[b] / 2, 2, false, EPI_STORE, "v2_flow_stem"))) return rc;
@@ -1425,7 +1456,7 @@ int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
         c->own_stream = true;
     }
-    rc = E->v4 ? ensure_ctx(*c, w, h) : ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1);
+    rc = E->v4 ? ensure_ctx(*c, w, h) : ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1, E->v3);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(c->d_in0, in0, nbytes, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->d_in1, in1, nbytes, hipMemcpyHostToDevice, c->stream);
@@ -1476,7 +1507,7 @@ int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* 
         HIPCHK(hipMemcpyAsync(d_out, timestep == 0.f ? d_in0 : d_in1, nbytes, hipMemcpyDeviceToDevice, c->stream));
     } else {
         if (!E->v4) {
-            if ((rc = ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1))) return rc;
+            if ((rc = ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1, E->v3))) return rc;
             if ((rc = run_v2(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, (uint8_t*)d_out))) return rc;
         } else if (E->tta || E->tta_temporal) {
             // the TTA workspaces are shared: serialise, and drain before another stream may reuse them

@@ -13,6 +13,9 @@ NAMED_OUTPUTS = {
     ("rife-v2.3", "flownet"): ["flow"],                                          # rife.cpp:948-950
     ("rife-v2.3", "contextnet"): ["f1", "f2", "f3", "f4"],                       # rife.cpp:1027-1039
     ("rife-v2.3", "fusionnet"): ["output"],                                      # rife.cpp:1070-1098
+    ("rife-v3.1", "flownet"): ["flow"],
+    ("rife-v3.1", "contextnet"): ["f1", "f2", "f3", "f4"],
+    ("rife-v3.1", "fusionnet"): ["output"],
 }
 needs_ref = pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree only exists in the build container")
 
@@ -38,7 +41,16 @@ def test_v2_family_graphs_identical(alias):
         assert a == b
 
 
-@pytest.mark.parametrize("fam", ["rife-v4.6", "rife-v2.3", "rife-v4"])
+@needs_ref
+def test_v3_family_graphs_identical():
+    """rife-v3.0 ships the same three graphs as v3.1."""
+    for net in ("flownet", "contextnet", "fusionnet"):
+        a = open(os.path.join(REFERENCE, "models", "rife-v3.0", net + ".param")).read()
+        b = open(os.path.join(REFERENCE, "models", "rife-v3.1", net + ".param")).read()
+        assert a == b
+
+
+@pytest.mark.parametrize("fam", ["rife-v4.6", "rife-v2.3", "rife-v4", "rife-v3.1"])
 def test_weight_count_identity(modeldirs, fam):
     """param[6] == oc*ic*k*k for every conv/deconv once channels are propagated."""
     for net in gen_models.FAMILIES[fam]:

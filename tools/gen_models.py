@@ -258,6 +258,41 @@ def ifnet_v23():
     return g
 
 
+def ifnet_v3():
+    """rife-v3.0 / v3.1 IFNet (models/rife-v3.1/flownet.param): 3 blocks at scales 4, 2, 1, all 160 channels wide
+    (stems 6|10 -> 80 -> 160), trunk = 3 x [conv+PReLU, conv+PReLU, + skip], deconv(4) heads; the flow is kept at half
+    resolution and - unlike v2.3 - rescaled with every resize (x 1/s going in, x s coming out)."""
+    g = Graph()
+    x01 = g.add("Interp", [g.concat([g.input("input0"), g.input("input1")])], ["0=2"])
+    deltas = []
+    for b, s in enumerate((4, 2, 1)):
+        if b == 0:
+            x = g.interp(x01, 1.0 / s)
+            cin = 6
+        else:
+            acc = deltas[0] if b == 1 else g.binary(deltas[0], deltas[1], 0)
+            Ff = g.scalar(g.interp(acc, 2.0), 2, 2.0)
+            w0 = g.warp(g.crop(x01, 0, 3), g.crop(Ff, 0, 2))
+            w1 = g.warp(g.crop(x01, 3, 2147483647), g.crop(Ff, 2, 4))
+            xw = g.concat([w0, w1])
+            xw = g.interp(xw, 1.0 / s) if s > 1 else g.add("Interp", [xw], ["0=2"])
+            fd = g.interp(Ff, 1.0 / s) if s > 1 else g.add("Interp", [Ff], ["0=2"])
+            x = g.concat([xw, g.scalar(fd, 2, 1.0 / s)])
+            cin = 10
+        x = g.prelu(g.conv(x, cin, 80, 2, kind="stem"), 80)
+        x = g.prelu(g.conv(x, 80, 160, 2, kind="stem"), 160)
+        for _ in range(3):
+            y = g.prelu(g.conv(x, 160, 160, kind="res"), 160)
+            y = g.prelu(g.conv(y, 160, 160, kind="res"), 160)
+            x = g.binary(y, x, 0)
+        d = g.deconv(x, 160, 4)
+        if s > 1:
+            d = g.scalar(g.interp(d, float(s)), 2, float(s))
+        deltas.append(d)
+    g.binary(g.binary(deltas[0], deltas[1], 0), deltas[2], 0, "flow")
+    return g
+
+
 def contextnet_v23():
     g = Graph()
     x, f = g.input("input.1"), g.input("flow.0")
@@ -313,6 +348,7 @@ FAMILIES = {
     "rife-v4.6": {"flownet": ifnet_v46},
     "rife-v4": {"flownet": ifnet_v40},
     "rife-v2.3": {"flownet": ifnet_v23, "contextnet": contextnet_v23, "fusionnet": fusionnet_v23},
+    "rife-v3.1": {"flownet": ifnet_v3, "contextnet": contextnet_v23, "fusionnet": fusionnet_v23},
 }
 
 
@@ -374,6 +410,8 @@ def generate(outdir, family="rife-v4.6", seed=0x51FE, real_contextnet=None):
             w = synth_weights(g, rng, head_gain=0.25, res_gain=0.5)
         elif family == "rife-v4":
             w = synth_weights(g, rng, head_gain=0.25)
+        elif family == "rife-v3.1":      # small fusion residual: keeps the synthetic output away from the 0 / 255 clip
+            w = synth_weights(g, rng, head_gain=0.25 if net == "flownet" else 0.15)
         else:
             w = synth_weights(g, rng, head_gain=0.25 if net == "flownet" else 1.0)
         write_bin(os.path.join(outdir, net + ".bin"), w)
