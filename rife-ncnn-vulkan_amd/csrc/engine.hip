@@ -372,6 +372,8 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
             }
         }
         const int nb = a.ntiles_xy * a.nz;
+        if (L.epi == EPI_DECONV_PS && (L.cout != 24 || y.ld != 8 || y.coff != 0))
+            return fail(RIFE_HIP_EINVAL, "the PixelShuffle head kernel writes the 6-channel flow tensor [4H][4W][8] only");
         if (fin && L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_FINAL>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, *fin);
         else if (L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_PS>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
         else if (L.epi == EPI_DECONV) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});

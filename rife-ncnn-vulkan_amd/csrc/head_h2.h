@@ -154,47 +154,92 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef HD_WRITE_W
 #undef HD_TAPS
 
-    if (EPI == EPI_FINAL) {
-        // The lane holds, per parity, channels {4q + 2... : c = 2q + half} x 4 sub-positions k of one trunk pixel: flow channels
-        // (x, z, mask) in lanes 0-31 and (y, w, -) in lanes 32-63.  The halves swap what the other needs (lane ^ 32) and each
-        // finishes two of the four flow pixels: F += d, M += dm, sigmoid, 2x warp, blend, postproc  (the body of k_final).
-        const int oy = oy0 + wv, ox = ox0 + li;
+#ifndef HEAD_ABL
+#define HEAD_ABL 0
+#endif
+    if (EPI == EPI_FINAL || EPI == EPI_DECONV_PS) {
+        if (EPI == EPI_FINAL && (HEAD_ABL & 1)) {     // ablation: no tail at all (keep the accumulators alive)
+            float sacc = 0.f;
 #pragma unroll
-        for (int par = 0; par < 4; par++) {
-            const int py = par >> 1, px = par & 1;
-            float mine[3][4], theirs[3][4];
+            for (int par = 0; par < 4; par++)
 #pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 8 * q + 4 * half);
+                for (int r = 0; r < 16; r++) sacc += acc[par][r];
+            if (sacc == 123.456f) fa.out[0] = 1;
+            return;
+        }
+        // Per parity the lane holds deconv channels 8q + 4 half + k = PixelShuffle channel 2q + half at sub-position k of one trunk
+        // pixel, i.e. a 4 x 4 block of full-resolution flow deltas spread over a lane pair.  Finishing the pixels in that layout
+        // means 64-byte-strided F reads, scattered image taps and byte stores, so the wave first transposes its 4 rows x 128
+        // columns of (dx, dy, dz, dw, dm) through LDS (two rows at a time; the staging buffers are free now) and then runs the
+        // body of k_final with one lane per pixel along a row: F / M reads and the warp taps are row-contiguous and the u8
+        // output leaves as whole dwords.
+        __syncthreads();
+        constexpr int NPL = EPI == EPI_FINAL ? 5 : 6;      // flow3 channel 5 is never used by the graph tail; the flow{b} blobs keep it
+        float* const reg = reinterpret_cast<float*>(ldsb) + wv * (NPL * 2 * 128);
+        const int oy = oy0 + wv;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    mine[q][k] = acc[par][4 * q + k] + b4[k];
-                    theirs[q][k] = __shfl_xor(mine[q][k], 32);
+        for (int py = 0; py < 2; py++) {
+#pragma unroll
+            for (int px = 0; px < 2; px++) {
+                const int par = 2 * py + px;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 8 * q + 4 * half);
+                    if (EPI == EPI_FINAL && q == 2 && half == 1) continue;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) reg[((2 * q + half) * 2 + (k >> 1)) * 128 + 4 * li + 2 * px + (k & 1)] = acc[par][4 * q + k] + b4[k];
                 }
             }
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                const int k = 2 * half + kk;                 // this lane's two sub-positions
-                float dx, dy, dz, dw, dm;
-                if (half == 0) { dx = mine[0][k]; dz = mine[1][k]; dm = mine[2][k]; dy = theirs[0][k]; dw = theirs[1][k]; }
-                else { dy = mine[0][k]; dw = mine[1][k]; dx = theirs[0][k]; dz = theirs[1][k]; dm = theirs[2][k]; }
-                const int fy = 2 * (2 * oy + py) + (k >> 1), fx = 2 * (2 * ox + px) + (k & 1);
-                if (fy < fa.h && fx < fa.w) {
-                    const size_t i = (size_t)fy * fa.wp + fx;
-                    float4 f = fa.F[i];
-                    f.x = f.x + dx; f.y = f.y + dy; f.z = f.z + dz; f.w = f.w + dw;
-                    const float mm = fa.M[i] + dm;
-                    const float m = 1.f / (1.f + expf(-mm));
-                    const float rm = 1.0f - m;
-                    const float3 w1 = warp_rgbx(fa.img1, fx, fy, f.z, f.w, fa.wp, fa.hp);
-                    const float3 w0 = warp_rgbx(fa.img0, fx, fy, f.x, f.y, fa.wp, fa.hp);
-                    const float r = w0.x * m + w1.x * rm, g = w0.y * m + w1.y * rm, b = w0.z * m + w1.z * rm;
-                    uint8_t* o = fa.out + ((size_t)fy * fa.w + fx) * 3;
-                    o[0] = (uint8_t)min(max((int)(r * 255.f + 0.5f), 0), 255);
-                    o[1] = (uint8_t)min(max((int)(g * 255.f + 0.5f), 0), 255);
-                    o[2] = (uint8_t)min(max((int)(b * 255.f + 0.5f), 0), 255);
+            for (int ky = 0; ky < 2; ky++) {
+                const int fy = 4 * oy + 2 * py + ky;
+#pragma unroll
+                for (int cb = 0; cb < 2; cb++) {
+                    const int col = 64 * cb + lane;
+                    const int fxb = 4 * ox0 + 64 * cb, fx = fxb + lane;
+                    const float dx = reg[(0 * 2 + ky) * 128 + col], dy = reg[(1 * 2 + ky) * 128 + col], dz = reg[(2 * 2 + ky) * 128 + col];
+                    const float dw = reg[(3 * 2 + ky) * 128 + col], dm = reg[(4 * 2 + ky) * 128 + col];
+                    if (EPI == EPI_DECONV_PS) {                  // flow{b} tensor [4 Ho][4 Wo][8]: 32 contiguous bytes per lane, 2 KB per wave
+                        const float d5 = reg[(5 * 2 + ky) * 128 + col];
+                        if (oy < a.Ho && fx < 4 * a.Wo) {
+                            float* o = a.out + ((size_t)fy * (4 * a.Wo) + fx) * a.out_ld + a.out_coff;
+                            *reinterpret_cast<f32x4*>(o) = f32x4{dx, dy, dz, dw};
+                            *reinterpret_cast<float2*>(o + 4) = make_float2(dm, d5);
+                        }
+                        continue;
+                    }
+                    if (fy >= fa.h || fxb >= fa.w) continue;     // wave-uniform
+                    const bool valid = fx < fa.w;
+                    uint32_t pk = 0;
+                    if (valid) {
+                        const size_t i = (size_t)fy * fa.wp + fx;
+                        float4 f = (HEAD_ABL & 2) ? make_float4(0.1f, 0.2f, 0.3f, 0.4f) : fa.F[i];
+                        f.x = f.x + dx; f.y = f.y + dy; f.z = f.z + dz; f.w = f.w + dw;
+                        const float mm = ((HEAD_ABL & 2) ? 0.5f : fa.M[i]) + dm;
+                        const float m = (HEAD_ABL & 8) ? mm * 0.01f : 1.f / (1.f + expf(-mm));
+                        const float rm = 1.0f - m;
+                        const float3 w1 = (HEAD_ABL & 4) ? make_float3(f.z, f.w, f.z) : warp_rgbx(fa.img1, fx, fy, f.z, f.w, fa.wp, fa.hp);
+                        const float3 w0 = (HEAD_ABL & 4) ? make_float3(f.x, f.y, f.x) : warp_rgbx(fa.img0, fx, fy, f.x, f.y, fa.wp, fa.hp);
+                        const float r = w0.x * m + w1.x * rm, g = w0.y * m + w1.y * rm, b = w0.z * m + w1.z * rm;
+                        pk = (uint32_t)min(max((int)(r * 255.f + 0.5f), 0), 255) | ((uint32_t)min(max((int)(g * 255.f + 0.5f), 0), 255) << 8) |
+                             ((uint32_t)min(max((int)(b * 255.f + 0.5f), 0), 255) << 16);
+                    }
+                    uint8_t* const orow = fa.out + ((size_t)fy * fa.w + fxb) * 3;
+                    if ((fa.w & 3) == 0 && fxb + 64 <= fa.w) {
+                        // 64 pixels = 192 bytes = 48 dwords: dword d takes bytes from pixels 4d/3 and 4d/3 + 1
+                        const int d = lane < 48 ? lane : 0;
+                        const int pa = (4 * d) / 3, sh = 8 * (4 * d - 3 * pa);
+                        const uint32_t va = (uint32_t)__shfl((int)pk, pa), vb = (uint32_t)__shfl((int)pk, pa + 1);
+                        const uint32_t word = sh == 0 ? (va | (vb << 24)) : ((va >> sh) | (vb << (24 - sh)));
+                        if (lane < 48) reinterpret_cast<uint32_t*>(orow)[lane] = word;
+                    } else if (valid) {
+                        uint8_t* o = orow + lane * 3;
+                        o[0] = (uint8_t)(pk & 255u); o[1] = (uint8_t)((pk >> 8) & 255u); o[2] = (uint8_t)(pk >> 16);
+                    }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
         return;
     }
