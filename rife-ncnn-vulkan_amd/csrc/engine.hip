@@ -1801,15 +1801,10 @@ int rife_hip_bench_stemf(int gpuid, int wp, int hp, int variant, int iters, floa
         case 1: rc = run(stem0_fused_kernel<1, 1, 1>); break;
         case 2: rc = run(stem0_fused_kernel<1, 1, 2>); break;
         case 3: rc = run(stem0_fused_kernel<1, 1, 3>); break;
-        case 6: rc = run(stem0_fused_kernel<1, 1, 6>); break;
-        case 7: rc = run(stem0_fused_kernel<1, 1, 7>); break;
-        case 9: rc = run(stem0_fused_kernel<1, 1, 9>); break;
-        case 15: rc = run(stem0_fused_kernel<1, 1, 15>); break;
         case 16: rc = run(stem0_fused_kernel<1, 1, 16>); break;
         case 32: rc = run(stem0_fused_kernel<1, 1, 32>); break;
-        case 48: rc = run(stem0_fused_kernel<1, 1, 48>); break;
-        case 22: rc = run(stem0_fused_kernel<1, 1, 22>); break;
-        case 38: rc = run(stem0_fused_kernel<1, 1, 38>); break;
+        case 64: rc = run(stem0_fused_kernel<1, 1, 64>); break;
+        case 128: rc = run(stem0_fused_kernel<1, 1, 128>); break;
         default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
     }
     (void)hipFree(i0); (void)hipFree(i1); (void)hipFree(F); (void)hipFree(M); (void)hipFree(out); (void)hipFree(bias); (void)hipFree(wh);

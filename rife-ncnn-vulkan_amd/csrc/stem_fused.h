@@ -23,14 +23,16 @@ struct StemFusedArgs {
     int Ho, Wo, out_ld, Cout, tiles_x;
 };
 
-constexpr int STEMF_PIXB = 64;     // no pad: the tiny MFMA phase tolerates 8-way conflicts, the gather phase wants 3 workgroups per CU
-template <int NS>
-constexpr int stemf_lds_bytes() { return 9 * 65 * STEMF_PIXB + 9 * 2 * NS * 32 * 16; }
+// LDS pixel record: 32 B hi + 32 B lo (+ 16 B pad: 80-byte records are conflict-free for the 16-byte staging writes and 2-way for
+// the stride-2 operand reads; 64-byte records are 4-way / 8-way).  ABL bit 128 selects the unpadded record for A/B runs.
+template <int ABL> constexpr int stemf_pixb() { return (ABL & 128) ? 64 : 80; }
+template <int NS, int ABL = 0>
+constexpr int stemf_lds_bytes() { return 9 * 65 * stemf_pixb<ABL>() + 9 * 2 * NS * 32 * 16; }
 
-// ABL (bench only): 1 = skip MFMA + epilogue, 2 = skip the image gathers, 4 = skip F/M loads too, 8 = skip LDS staging, 16 = skip stores, 32 = skip MFMAs
+// ABL (bench only): 1 = skip MFMA + epilogue, 2 = second halo pixel in a second round, 16 = skip stores, 32 = skip MFMAs, 64 = direct-store epilogue, 128 = 64-byte LDS records
 template <int S, int NS, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem0_fused_kernel(StemFusedArgs a) {
-    constexpr int IH = 9, IW = 65, PIXB = STEMF_PIXB, NT = NS * 32;
+    constexpr int IH = 9, IW = 65, PIXB = stemf_pixb<ABL>(), NT = NS * 32;
     constexpr int NPIX = IH * IW;
     constexpr int W_16 = 9 * 2 * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -54,42 +56,49 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // weights -> LDS (one 16-channel chunk covers the 12 input channels)
     for (int idx = tid; idx < W_16; idx += 512) reinterpret_cast<f32x4*>(lw)[idx] = reinterpret_cast<const f32x4*>(a.wpk)[idx];
 
-    // block-input halo tile -> LDS as f16 hi | lo
-    for (int p = tid; p < NPIX; p += 512) {
-        const int py = p / IW, px = p - py * IW;
-        const int by = iy0 + py, bx = ix0 + px;
-        float o[12];
-        if (ABL & 2) {
-            if (by >= 0 && by < Hb && bx >= 0 && bx < Wb) {
-                const size_t i = (size_t)by * a.wp + bx;
-                float4 f = make_float4(1.f, 2.f, 3.f, 4.f); float m = 0.5f;
-                if (!(ABL & 4)) { f = a.F[i]; m = a.M[i]; }
-#pragma unroll
-                for (int c = 0; c < 12; c++) o[c] = f.x * (float)c + f.y + f.z + f.w + m;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 12; c++) o[c] = 0.f;
-            }
-        } else
-        if (by >= 0 && by < Hb && bx >= 0 && bx < Wb) assemble_pixel<S>(a.img0, a.img1, a.timestep, a.F, a.M, a.wp, a.hp, bx, by, o);
-        else {
-#pragma unroll
-            for (int c = 0; c < 12; c++) o[c] = 0.f;        // conv zero padding
-        }
-        f16x8 h0, h1, l0, l1;
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const _Float16 ha = (_Float16)o[c];
-            h0[c] = ha; l0[c] = (_Float16)(o[c] - (float)ha);
-            const float vb = c < 4 ? o[8 + c] : 0.f;
-            const _Float16 hb = (_Float16)vb;
-            h1[c] = hb; l1[c] = (_Float16)(vb - (float)hb);
-        }
-        unsigned char* dst = ldsb + p * PIXB;
-        if (ABL & 8) { if (h0[0] == (_Float16)123.f) *reinterpret_cast<f16x8*>(dst) = h0; continue; }
-        *reinterpret_cast<f16x8*>(dst) = h0; *reinterpret_cast<f16x8*>(dst + 16) = h1;
-        *reinterpret_cast<f16x8*>(dst + 32) = l0; *reinterpret_cast<f16x8*>(dst + 48) = l1;
+    // block-input halo tile -> LDS as f16 hi | lo.  585 pixels over 512 threads: every thread takes pixel `tid`, waves 0-1 also
+    // pixel 512 + tid.  The gather is straight-line code on clamped coordinates (conv zero padding = a select afterwards) so that
+    // the two pixels of waves 0-1 are in flight together instead of costing a second round of dependent F -> image-tap loads.
+#define STEM_GATHER(P, O)                                                                                         \
+    {                                                                                                             \
+        const int p_ = (P) < NPIX ? (P) : NPIX - 1;                                                               \
+        const int py_ = p_ / IW, px_ = p_ - py_ * IW;                                                             \
+        const int by_ = iy0 + py_, bx_ = ix0 + px_;                                                               \
+        const bool in_ = by_ >= 0 && by_ < Hb && bx_ >= 0 && bx_ < Wb;                                            \
+        assemble_pixel<S>(a.img0, a.img1, a.timestep, a.F, a.M, a.wp, a.hp, min(max(bx_, 0), Wb - 1), min(max(by_, 0), Hb - 1), O); \
+        _Pragma("unroll") for (int c = 0; c < 12; c++) O[c] = in_ ? O[c] : 0.f;                                   \
     }
+#define STEM_STAGE(P, O)                                                                                          \
+    {                                                                                                             \
+        f16x8 h0, h1, l0, l1;                                                                                     \
+        _Pragma("unroll") for (int c = 0; c < 8; c++) {                                                           \
+            const _Float16 ha = (_Float16)O[c];                                                                   \
+            h0[c] = ha; l0[c] = (_Float16)(O[c] - (float)ha);                                                     \
+            const float vb = c < 4 ? O[8 + c] : 0.f;                                                              \
+            const _Float16 hb = (_Float16)vb;                                                                     \
+            h1[c] = hb; l1[c] = (_Float16)(vb - (float)hb);                                                       \
+        }                                                                                                         \
+        unsigned char* dst = ldsb + (P) * PIXB;                                                                   \
+        *reinterpret_cast<f16x8*>(dst) = h0; *reinterpret_cast<f16x8*>(dst + 16) = h1;                            \
+        *reinterpret_cast<f16x8*>(dst + 32) = l0; *reinterpret_cast<f16x8*>(dst + 48) = l1;                       \
+    }
+    if (wv8 < 2 && !(ABL & 2)) {
+        float o0[12], o1[12];
+        STEM_GATHER(tid, o0)
+        STEM_GATHER(tid + 512, o1)
+        STEM_STAGE(tid, o0)
+        if (tid + 512 < NPIX) STEM_STAGE(tid + 512, o1)
+    } else {
+        float o0[12];
+        STEM_GATHER(tid, o0)
+        STEM_STAGE(tid, o0)
+        if ((ABL & 2) && tid + 512 < NPIX) {     // A/B: the second pixel as a second, dependent round
+            STEM_GATHER(tid + 512, o0)
+            STEM_STAGE(tid + 512, o0)
+        }
+    }
+#undef STEM_GATHER
+#undef STEM_STAGE
     __syncthreads();
 
     if (ABL & 1) return;
@@ -110,6 +119,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, al, acc, 0, 0, 0);
     }
 
+    if (ABL & 64) {   // A/B: direct epilogue, one 16-byte store per register quad (32 B per pixel per instruction)
+        const int oy = oy0 + wv, ox = ox0 + li;
+        const bool pok = oy < a.Ho && ox < a.Wo;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c0 = nsel * 32 + 8 * q + 4 * half;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { v[k] = acc[4 * q + k] + b4[k]; v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k]; }
+            if (pok && c0 < a.Cout) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + c0) = v;
+        }
+        return;
+    }
     // epilogue: bias + leaky, then transpose the wave's 32 x 32 tile through LDS (the halo tile is dead by now) so that
     // 8 consecutive lanes store one pixel's 128 contiguous bytes (a full line per pixel, 1 KB per instruction if out_ld = 32)
     __syncthreads();                                       // waves 4-7 (NS = 1) have exited; exited waves do not count

@@ -4,9 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
 L = amd.lib()
 L.rife_hip_bench_stemf.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float)]
-for name, v in [("full", 0), ("no mfma/epilogue", 1), ("no image gathers", 2), ("no gathers, no mfma", 3), ("no loads at all", 6), ("no loads, no mfma", 7),
-                ("no LDS staging, no mfma", 9), ("nothing but index math", 15), ("no stores", 16), ("no MFMAs (LDS reads kept)", 32), ("no stores, no MFMAs", 48),
-                ("no loads, no stores", 22), ("no loads, no MFMAs", 38)]:
+for name, v in [("full", 0), ("second halo pixel in a second round", 2), ("full", 0), ("second halo pixel in a second round", 2), ("no mfma/epilogue", 1), ("no mfma/epilogue, second round", 3),
+                ("no stores", 16), ("no MFMAs (LDS reads kept)", 32), ("direct-store epilogue", 64), ("64-byte LDS records", 128)]:
     ms = ctypes.c_float()
     rc = L.rife_hip_bench_stemf(0, 3840, 2176, v, 10, ctypes.byref(ms))
     print("%-28s rc=%d  %.4f ms" % (name, rc, ms.value))
