@@ -122,7 +122,26 @@ int Net::load_model(const std::string& path) {
             L.slope.resize(n);
             std::memcpy(L.slope.data(), &raw[pos], (size_t)n * 4); pos += (size_t)n * 4;
         } else if (L.type == "InnerProduct") {
-            return -6;   // only the out-of-scope HD/UHD/anime families use it
+            // ncnn InnerProduct: 0 = num_output, 1 = bias_term, 2 = weight_data_size; same tagged weight block as Convolution
+            // (the SE blocks of the rife / rife-HD / rife-UHD / rife-anime graphs, e.g. models/rife/flownet.param:15-16)
+            int n = L.geti(2, 0), outc = L.geti(0, 0), has_bias = L.geti(1, 0);
+            if (!need(4)) return -2;
+            uint32_t tag; std::memcpy(&tag, &raw[pos], 4); pos += 4;
+            L.weight.resize(n);
+            if (tag == 0x01306B47u) {
+                size_t bytes = ((size_t)n * 2 + 3) / 4 * 4;
+                if (!need(bytes)) return -2;
+                for (int i = 0; i < n; i++) { uint16_t h; std::memcpy(&h, &raw[pos + 2 * (size_t)i], 2); L.weight[i] = half_to_float(h); }
+                pos += bytes;
+            } else if (tag == 0) {
+                if (!need((size_t)n * 4)) return -2;
+                std::memcpy(L.weight.data(), &raw[pos], (size_t)n * 4); pos += (size_t)n * 4;
+            } else return -5;
+            L.bias.assign(outc, 0.f);
+            if (has_bias) {
+                if (!need((size_t)outc * 4)) return -2;
+                std::memcpy(L.bias.data(), &raw[pos], (size_t)outc * 4); pos += (size_t)outc * 4;
+            }
         }
     }
     bin_bytes_consumed = pos;
@@ -383,6 +402,11 @@ int Extractor::forward_layer(int li) {
             for (size_t i = 0; i < a.total(); i++) out.data[i] = binop(op, a.data[i], sb);
         } else {
             const Mat& b = blobs[L.bottoms[1]];
+            if (b.w == 1 && b.h == 1 && b.c == a.c && (a.w != 1 || a.h != 1)) {   // per-channel scalar (SE scale; ncnn broadcasts a 1-D operand of length c)
+                for (int q = 0; q < a.c; q++) { const float bv = b.channel(q)[0]; for (size_t i = 0; i < plane; i++) out.channel(q)[i] = binop(op, a.channel(q)[i], bv); }
+                blobs[L.tops[0]] = out;
+                return 0;
+            }
             if (b.w != a.w || b.h != a.h) return -8;
             if (b.c == a.c) { for (size_t i = 0; i < a.total(); i++) out.data[i] = binop(op, a.data[i], b.data[i]); }
             else if (b.c == 1) {   // 1-channel operand broadcast over channels (flownet.param:213,216)
@@ -406,6 +430,44 @@ int Extractor::forward_layer(int li) {
             for (size_t i = 0; i < n; i++) out.data[i] = a.data[i] * c0 + b.data[i] * c1;
             for (size_t bi = 2; bi < L.bottoms.size(); bi++) { const Mat& m = blobs[L.bottoms[bi]]; float ck = (float)cf->second[bi]; for (size_t i = 0; i < n; i++) out.data[i] += m.data[i] * ck; }
         }
+        blobs[L.tops[0]] = out;
+    } else if (t == "Pooling") {
+        // global average pooling only (0 = 1 avg, 4 = 1 global): sequential fp32 sum / size -> c values (ncnn Pooling::forward)
+        if (L.geti(0, 0) != 1 || L.geti(4, 0) != 1) return -11;
+        const Mat& in = blobs[L.bottoms[0]];
+        Mat out(1, 1, in.c);
+        const size_t plane = (size_t)in.w * in.h;
+        for (int q = 0; q < in.c; q++) {
+            const float* p = in.channel(q);
+            float sum = 0.f;
+            for (size_t i = 0; i < plane; i++) sum += p[i];
+            out.channel(q)[0] = sum / (float)plane;
+        }
+        blobs[L.tops[0]] = out;
+    } else if (t == "InnerProduct") {
+        const Mat& in = blobs[L.bottoms[0]];
+        const int outc = L.geti(0, 0), n = (int)in.total(), act = L.geti(9, 0);
+        if ((int)L.weight.size() != outc * n) return -12;
+        float actp[2] = {0.f, 0.f};
+        auto ap = L.pa.find(10);
+        if (ap != L.pa.end()) for (size_t i = 0; i < ap->second.size() && i < 2; i++) actp[i] = (float)ap->second[i];
+        Mat out(1, 1, outc);
+        for (int p = 0; p < outc; p++) {
+            float sum = L.bias[p];
+            const float* wv = L.weight.data() + (size_t)p * n;
+            for (int i = 0; i < n; i++) sum += in.data[i] * wv[i];
+            if (act == 1) sum = sum > 0 ? sum : 0.f;
+            else if (act == 2) sum = sum > 0 ? sum : sum * actp[0];
+            else if (act == 3) sum = std::min(std::max(sum, actp[0]), actp[1]);
+            else if (act == 4) sum = 1.f / (1.f + std::exp(-sum));
+            out.channel(p)[0] = sum;
+        }
+        blobs[L.tops[0]] = out;
+    } else if (t == "UnaryOp") {
+        if (L.geti(0, 0) != 1) return -13;   // 1 = neg (the only op the RIFE graphs use)
+        Mat out = blobs[L.bottoms[0]].clone();
+        size_t n = out.total();
+        for (size_t i = 0; i < n; i++) out.data[i] = -out.data[i];
         blobs[L.tops[0]] = out;
     } else if (t == "rife.Warp") {
         Mat out; warp(blobs[L.bottoms[0]], blobs[L.bottoms[1]], out, nt);

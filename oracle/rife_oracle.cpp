@@ -105,6 +105,20 @@ void v4_temporal_merge(Mat& f, Mat& r) {
 void v4_spatial_avg(Mat fl[8]) {
     const int W = fl[0].w, H = fl[0].h;
     const bool has_mask = fl[0].c > 4;
+    if (fl[0].c == 2) {   // v1 family: one 2-channel flow (rife.cpp:1669-1716): the x / y rows of the same algebra
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++) {
+                size_t id[8];
+                for (int ti = 0; ti < 8; ti++) id[ti] = tta_index(ti, i, j, W, H);
+                auto X = [&](int ti) -> float& { return fl[ti].channel(0)[id[ti]]; };
+                auto Y = [&](int ti) -> float& { return fl[ti].channel(1)[id[ti]]; };
+                float x = (X(0) + -X(1) + -X(2) + X(3) + Y(4) + Y(5) + -Y(6) + -Y(7)) * 0.125f;
+                float y = (Y(0) + Y(1) + -Y(2) + -Y(3) + X(4) + -X(5) + -X(6) + X(7)) * 0.125f;
+                X(0) = x; X(1) = -x; X(2) = -x; X(3) = x; X(4) = y; X(5) = -y; X(6) = -y; X(7) = y;
+                Y(0) = y; Y(1) = y; Y(2) = -y; Y(3) = -y; Y(4) = x; Y(5) = x; Y(6) = -x; Y(7) = -x;
+            }
+        return;
+    }
     for (int i = 0; i < H; i++)
         for (int j = 0; j < W; j++) {
             size_t id[8];
@@ -240,6 +254,14 @@ int process_v4_cpu(const RifeOracle& R, const uint8_t* p0, const uint8_t* p1, in
 // v2 flow / reversed-flow merge (rife.cpp:2277-2303)
 void v2_temporal_merge(Mat& f, Mat& r) {
     size_t n = (size_t)f.w * f.h;
+    if (f.c == 2) {   // v1 family (rife.cpp:2304-2316, 1525-1538): the reversed flow is the negated flow
+        float *fx = f.channel(0), *fy = f.channel(1), *rx = r.channel(0), *ry = r.channel(1);
+        for (size_t i = 0; i < n; i++) {
+            float x = (fx[i] - rx[i]) * 0.5f, y = (fy[i] - ry[i]) * 0.5f;
+            fx[i] = x; fy[i] = y; rx[i] = -x; ry[i] = -y;
+        }
+        return;
+    }
     float *fx = f.channel(0), *fy = f.channel(1), *fz = f.channel(2), *fw = f.channel(3);
     float *rx = r.channel(0), *ry = r.channel(1), *rz = r.channel(2), *rw = r.channel(3);
     for (size_t i = 0; i < n; i++) {
@@ -279,13 +301,20 @@ int process_cpu_v2(const RifeOracle& R, const uint8_t* p0, const uint8_t* p1, in
     int rc;
     auto synth = [&](const Mat& a, const Mat& b, const Mat& fl, Mat& o) -> int {   // slice -> contextnet x2 -> fusionnet
         int r;
-        Mat f0 = fl.channel_range(0, 2).clone(), f1 = fl.channel_range(2, 2).clone();
         Mat c0[4], c1[4];
         static const char* fnames[4] = {"f1", "f2", "f3", "f4"};
-        { Extractor ex(R.contextnet); ex.light = false; ex.input("input.1", a); ex.input("flow.0", f0);
-          for (int k = 0; k < 4; k++) if ((r = ex.extract(fnames[k], c0[k]))) return r; }
-        { Extractor ex(R.contextnet); ex.light = false; ex.input("input.1", b); ex.input("flow.0", f1);
-          for (int k = 0; k < 4; k++) if ((r = ex.extract(fnames[k], c1[k]))) return r; }
+        if (R.rife_v2) {   // Slice {-233,-233} (rife.cpp:2322-2330), each half bound to "flow.0"
+            Mat f0 = fl.channel_range(0, 2).clone(), f1 = fl.channel_range(2, 2).clone();
+            { Extractor ex(R.contextnet); ex.light = false; ex.input("input.1", a); ex.input("flow.0", f0);
+              for (int k = 0; k < 4; k++) if ((r = ex.extract(fnames[k], c0[k]))) return r; }
+            { Extractor ex(R.contextnet); ex.light = false; ex.input("input.1", b); ex.input("flow.0", f1);
+              for (int k = 0; k < 4; k++) if ((r = ex.extract(fnames[k], c1[k]))) return r; }
+        } else {           // v1 family: one 2-channel flow; img0 binds it to "flow.0", img1 to "flow.1" (= -flow.0 inside the graph), rife.cpp:2339-2362
+            { Extractor ex(R.contextnet); ex.light = false; ex.input("input.1", a); ex.input("flow.0", fl);
+              for (int k = 0; k < 4; k++) if ((r = ex.extract(fnames[k], c0[k]))) return r; }
+            { Extractor ex(R.contextnet); ex.light = false; ex.input("input.1", b); ex.input("flow.1", fl);
+              for (int k = 0; k < 4; k++) if ((r = ex.extract(fnames[k], c1[k]))) return r; }
+        }
         Extractor ex(R.fusionnet);
         ex.input("img0", a); ex.input("img1", b); ex.input("flow", fl);
         static const char* n0[4] = {"3", "4", "5", "6"};
@@ -340,30 +369,11 @@ int process_cpu_v2(const RifeOracle& R, const uint8_t* p0, const uint8_t* p1, in
         if ((rc = v2_flow(R, in1, in0, flowr))) return rc;
         v2_temporal_merge(flow, flowr);
     }
-    Mat flow0 = flow.channel_range(0, 2).clone(), flow1 = flow.channel_range(2, 2).clone();   // Slice {-233,-233}, rife.cpp:2322-2330
-    Mat ctx0[4], ctx1[4];
-    static const char* fn[4] = {"f1", "f2", "f3", "f4"};
-    {   // rife.cpp:2333-2368: one extractor per image, f1..f4 extracted from it (ncnn caches intermediates)
-        Extractor ex(R.contextnet); ex.light = false;
-        ex.input("input.1", in0); ex.input("flow.0", flow0);
-        for (int k = 0; k < 4; k++) if ((rc = ex.extract(fn[k], ctx0[k]))) return rc;
-    }
-    {
-        Extractor ex(R.contextnet); ex.light = false;
-        ex.input("input.1", in1); ex.input("flow.0", flow1);
-        for (int k = 0; k < 4; k++) if ((rc = ex.extract(fn[k], ctx1[k]))) return rc;
-    }
-    auto fuse = [&](const Mat& a, const Mat& b, const Mat& f, Mat* c0, Mat* c1, Mat& o) {
-        Extractor ex(R.fusionnet);
-        ex.input("img0", a); ex.input("img1", b); ex.input("flow", f);
-        static const char* n0[4] = {"3", "4", "5", "6"};
-        static const char* n1[4] = {"7", "8", "9", "10"};
-        for (int k = 0; k < 4; k++) { ex.input(n0[k], c0[k]); ex.input(n1[k], c1[k]); }
-        return ex.extract("output", o);
-    };
+    // slice -> contextnet x2 -> fusionnet (rife.cpp:2322-2388); the reversed pass of -z re-uses the contexts swapped
+    // (rife.cpp:2391-2413), which synth() recomputes to identical values
     Mat outp, outr;
-    if ((rc = fuse(in0, in1, flow, ctx0, ctx1, outp))) return rc;
-    if (R.tta_temporal_mode) if ((rc = fuse(in1, in0, flowr, ctx1, ctx0, outr))) return rc;
+    if ((rc = synth(in0, in1, flow, outp))) return rc;
+    if (R.tta_temporal_mode) if ((rc = synth(in1, in0, flowr, outr))) return rc;
     for (int i = 0; i < h; i++)
         for (int j = 0; j < w; j++)
             for (int q = 0; q < 3; q++) {
@@ -415,8 +425,7 @@ int oracle_load(void* h, const char* modeldir) {
 int oracle_process(void* h, const uint8_t* in0, const uint8_t* in1, int w, int hgt, float timestep, uint8_t* out) {
     RifeOracle* R = (RifeOracle*)h;
     if (R->rife_v4) return process_v4_cpu(*R, in0, in1, w, hgt, timestep, out);
-    if (R->rife_v2) return process_cpu_v2(*R, in0, in1, w, hgt, timestep, out);
-    return -30;   // v1 family: out of scope
+    return process_cpu_v2(*R, in0, in1, w, hgt, timestep, out);   // v2 / v3 (rife_v2) and the v1 family share RIFE::process_cpu
 }
 
 // Debug tap for stage-wise parity: run the plain v4 graph and return any named blob (planar CHW fp32).

@@ -19,7 +19,7 @@ def modeldirs(tmp_path_factory):
     """Seeded synthetic model directories in the reference's on-disk format (see tools/gen_models.py)."""
     from tools import gen_models
     out = {}
-    for fam in ("rife-v4.6", "rife-v2.3", "rife-v4", "rife-v3.1"):
+    for fam in ("rife-v4.6", "rife-v2.3", "rife-v4", "rife-v3.1", "rife", "rife-HD"):
         out[fam] = gen_models.ensure(None, fam)
     return out
 

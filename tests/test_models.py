@@ -16,6 +16,8 @@ NAMED_OUTPUTS = {
     ("rife-v3.1", "flownet"): ["flow"],
     ("rife-v3.1", "contextnet"): ["f1", "f2", "f3", "f4"],
     ("rife-v3.1", "fusionnet"): ["output"],
+    ("rife", "flownet"): ["flow"], ("rife", "contextnet"): ["f1", "f2", "f3", "f4"], ("rife", "fusionnet"): ["output"],
+    ("rife-HD", "flownet"): ["flow"], ("rife-HD", "contextnet"): ["f1", "f2", "f3", "f4"], ("rife-HD", "fusionnet"): ["output"],
 }
 needs_ref = pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree only exists in the build container")
 
@@ -27,8 +29,10 @@ def test_generated_param_is_the_reference_graph(modeldirs, fam, net):
     gen = ncnn_param.parse(os.path.join(modeldirs[fam], net + ".param"))
     assert len(ref) == len(gen)
     assert ncnn_param.weighted_layers(ref) == ncnn_param.weighted_layers(gen)   # same .bin stream order
+    # v1 family: the negative slopes of the SE bottleneck FCs are trained constants kept in the .param (i.e. weights): not structure
+    v1 = fam in ("rife", "rife-HD")
     for blob in NAMED_OUTPUTS[(fam, net)]:
-        assert ncnn_param.structural_hash(ref, blob) == ncnn_param.structural_hash(gen, blob), blob
+        assert ncnn_param.structural_hash(ref, blob, v1) == ncnn_param.structural_hash(gen, blob, v1), blob
 
 
 @needs_ref
@@ -42,6 +46,16 @@ def test_v2_family_graphs_identical(alias):
 
 
 @needs_ref
+@pytest.mark.parametrize("alias", ["rife-UHD", "rife-anime"])
+def test_hd_family_graphs_identical(alias):
+    """rife-UHD and rife-anime ship the rife-HD graphs byte for byte."""
+    for net in ("flownet", "contextnet", "fusionnet"):
+        a = open(os.path.join(REFERENCE, "models", alias, net + ".param")).read()
+        b = open(os.path.join(REFERENCE, "models", "rife-HD", net + ".param")).read()
+        assert a == b
+
+
+@needs_ref
 def test_v3_family_graphs_identical():
     """rife-v3.0 ships the same three graphs as v3.1."""
     for net in ("flownet", "contextnet", "fusionnet"):
@@ -50,7 +64,7 @@ def test_v3_family_graphs_identical():
         assert a == b
 
 
-@pytest.mark.parametrize("fam", ["rife-v4.6", "rife-v2.3", "rife-v4", "rife-v3.1"])
+@pytest.mark.parametrize("fam", ["rife-v4.6", "rife-v2.3", "rife-v4", "rife-v3.1", "rife", "rife-HD"])
 def test_weight_count_identity(modeldirs, fam):
     """param[6] == oc*ic*k*k for every conv/deconv once channels are propagated."""
     for net in gen_models.FAMILIES[fam]:
@@ -58,7 +72,8 @@ def test_weight_count_identity(modeldirs, fam):
         for l in g.weighted():
             if "w" in l["meta"]:
                 oc, ic, kh, kw = l["meta"]["w"]
-                n = [int(p.split("=")[1]) for p in l["params"] if p.startswith("6=")][0]
+                key = "2=" if l["type"] == "InnerProduct" else "6="        # weight_data_size lives at id 2 for InnerProduct
+                n = [int(p.split("=")[1]) for p in l["params"] if p.startswith(key)][0]
                 assert n == oc * ic * kh * kw
 
 

@@ -123,6 +123,36 @@ def test_v23_process_matches_torch(modeldirs):
     assert diff.max() <= 1 and (diff > 0).mean() < 0.02
 
 
+@pytest.mark.parametrize("fam", ["rife", "rife-HD"])
+def test_v1_family_process_matches_torch(modeldirs, fam):
+    """rife / rife-HD (= rife-UHD, rife-anime) graphs: SE blocks (global mean, two InnerProducts), 5x5 convs, bias-free
+    strided skip convs, UnaryOp neg; one 2-channel flow bound to "flow.0" for frame 0 and "flow.1" for frame 1 (rife.cpp:2339-2362)."""
+    d = modeldirs[fam]
+    W, H = 96, 64
+    a, b = gen_frames.smooth_pair(W, H, 13)
+    o = pyoracle.OracleRIFE()
+    o.load(d)
+    got = o.process(a, b, 0.5)
+    x0, x1 = chw(a, W, H), chw(b, W, H)
+    fnet = TorchNet(os.path.join(d, "flownet.param"), os.path.join(d, "flownet.bin"))
+    cnet = TorchNet(os.path.join(d, "contextnet.param"), os.path.join(d, "contextnet.bin"))
+    unet = TorchNet(os.path.join(d, "fusionnet.param"), os.path.join(d, "fusionnet.bin"))
+    (flow,) = fnet.run({"input0": x0, "input1": x1}, ["flow"])
+    assert flow.shape == (2, H // 2, W // 2)
+    oflow = o.net_extract(0, {"input0": x0.numpy(), "input1": x1.numpy()}, "flow", 2 * W * H)
+    assert np.abs(oflow - flow.numpy()).max() < 2e-4
+    c0 = cnet.run({"input.1": x0, "flow.0": flow}, ["f1", "f2", "f3", "f4"])
+    c1 = cnet.run({"input.1": x1, "flow.1": flow}, ["f1", "f2", "f3", "f4"])
+    ins = {"img0": x0, "img1": x1, "flow": flow}
+    for k in range(4):
+        ins[str(3 + k)] = c0[k]
+        ins[str(7 + k)] = c1[k]
+    (out,) = unet.run(ins, ["output"])
+    want = (out * 255.0 + 0.5).to(torch.int32).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02
+
+
 @pytest.mark.parametrize("stride", [1, 2])
 def test_single_ops_match_torch(stride):
     import torch.nn.functional as F

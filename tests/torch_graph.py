@@ -29,8 +29,22 @@ def load_bin(layers, path):
                 w = np.frombuffer(raw, "<f4", n, pos).copy()
                 pos += n * 4
             l["weight"] = torch.from_numpy(w.copy())
-            l["bias"] = torch.from_numpy(np.frombuffer(raw, "<f4", oc, pos).copy())
-            pos += oc * 4
+            if int(p.get(5, 0)):
+                l["bias"] = torch.from_numpy(np.frombuffer(raw, "<f4", oc, pos).copy())
+                pos += oc * 4
+            else:
+                l["bias"] = None
+        elif l["type"] == "InnerProduct":
+            n, oc = int(p[2]), int(p[0])
+            (tag,) = struct.unpack_from("<I", raw, pos)
+            pos += 4
+            assert tag == 0x01306B47
+            l["weight"] = torch.from_numpy(np.frombuffer(raw, "<f2", n, pos).astype(np.float32).copy()).reshape(oc, -1)
+            pos += (n * 2 + 3) // 4 * 4
+            l["bias"] = None
+            if int(p.get(1, 0)):
+                l["bias"] = torch.from_numpy(np.frombuffer(raw, "<f4", oc, pos).copy())
+                pos += oc * 4
         elif l["type"] == "PReLU":
             n = int(p[0])
             l["slope"] = torch.from_numpy(np.frombuffer(raw, "<f4", n, pos).copy())
@@ -113,9 +127,20 @@ class TorchNet:
                 y = torch.sigmoid(x[0])
             elif t == "Clip":
                 y = x[0].clamp(p[0], p[1])
+            elif t == "Pooling":
+                assert int(p.get(0, 0)) == 1 and int(p.get(4, 0)) == 1
+                y = x[0].mean(dim=(1, 2))                       # (C,) like ncnn's 1-D blob
+            elif t == "InnerProduct":
+                y = F.linear(x[0].reshape(-1), l["weight"], l["bias"])
+                y = self._act(y, p, a)
+            elif t == "UnaryOp":
+                assert int(p.get(0, 0)) == 1
+                y = -x[0]
             elif t == "BinaryOp":
                 op = int(p.get(0, 0))
                 b = x[1] if len(x) > 1 else torch.tensor(np.float32(p[2]))
+                if len(x) > 1 and b.dim() == 1 and x[0].dim() == 3:
+                    b = b[:, None, None]                        # per-channel operand (SE scale)
                 y = {0: lambda: x[0] + b, 1: lambda: x[0] - b, 2: lambda: x[0] * b, 3: lambda: x[0] / b, 7: lambda: b - x[0]}[op]()
             elif t == "Eltwise":
                 c = a[1]

@@ -99,6 +99,33 @@ class Graph:
     def clip(self, x, lo, hi, name=None):
         return self.add("Clip", [x], ["0=%e" % lo, "1=%e" % hi], top_names=[name] if name else None)
 
+    def convk(self, x, cin, cout, k=3, stride=1, bias=True, act=None, kind="plain"):
+        """Convolution with an explicit kernel size (pad k//2), optional bias, optional fused activation (ncnn 9=...)."""
+        p = ["0=%d" % cout, "1=%d" % k]
+        if stride != 1:
+            p.append("3=%d" % stride)
+        p.append("4=%d" % (k // 2))
+        if bias:
+            p.append("5=1")
+        p.append("6=%d" % (cin * cout * k * k))
+        if act == "sigmoid":
+            p.append("9=4")
+        return self.add("Convolution", [x], p, meta=dict(w=(cout, cin, k, k), kind=kind, bias=bias))
+
+    def pool_global_avg(self, x):
+        return self.add("Pooling", [x], ["0=1", "4=1"])
+
+    def inner(self, x, cin, cout, act, slope=None):
+        p = ["0=%d" % cout, "2=%d" % (cin * cout)]
+        if act == "leaky":
+            p += ["9=2", "-23310=1,%e" % slope]
+        elif act == "sigmoid":
+            p.append("9=4")
+        return self.add("InnerProduct", [x], p, meta=dict(w=(cout, cin, 1, 1), kind="fc", bias=False))
+
+    def neg(self, x, name=None):
+        return self.add("UnaryOp", [x], ["0=1"], top_names=[name] if name else None)
+
     # ---- emit --------------------------------------------------------------------------------
     def emit(self):
         # count consumers, insert Split after any producer whose top feeds >1 consumer
@@ -344,11 +371,159 @@ def fusionnet_v23():
     return g
 
 
+# ----------------------------------------------------------------------------------------------
+# the v1 family: models/rife (3 x 3 convs) and models/rife-HD = rife-UHD = rife-anime (5 x 5 convs, one more level).
+# Everything is built from one squeeze-and-excitation residual block:  y = conv(PReLU(conv(x)));  s = sigmoid(fc(leaky(fc(mean(y)))));
+# out = PReLU(y * s + skip).  The negative slopes of the 16-wide bottleneck are trained constants stored in the .param itself
+# (e.g. models/rife/flownet.param:15); here they come from the seeded generator like every other weight.
+# ----------------------------------------------------------------------------------------------
+def _se_tail(g, y, skip, c, rng):
+    m = g.pool_global_avg(y)
+    m = g.inner(m, c, 16, "leaky", float(rng.uniform(-0.05, 0.6)))
+    m = g.inner(m, 16, c, "sigmoid")
+    return g.prelu(g.binary(g.binary(y, m, 2), skip, 0), c)
+
+
+def _se_res(g, x, c, k, rng):
+    """same-resolution block of the IFNets (models/rife/flownet.param:10-21, models/rife-HD/flownet.param:10-21)"""
+    y = g.prelu(g.convk(x, c, c, k, kind="res"), c)
+    y = g.convk(y, c, c, 3, kind="res")
+    return _se_tail(g, y, x, c, rng)
+
+
+def _se_down(g, x, cin, c, rng):
+    """stride-2 block of the ContextNet / FusionNet: bias-free strided conv as the skip path (models/rife/contextnet.param:6-16)"""
+    skip = g.convk(x, cin, c, 3, 2, bias=False, kind="plain")
+    y = g.prelu(g.convk(x, cin, c, 3, 2, kind="plain"), c)
+    y = g.convk(y, c, c, 3, kind="res")
+    return _se_tail(g, y, skip, c, rng)
+
+
+def _ifnet_v1(widths, scales, k, rng):
+    g = Graph()
+    x01 = g.interp(g.concat([g.input("input0"), g.input("input1")]), 0.5)
+    deltas = []
+
+    def total():
+        acc = deltas[0]
+        for d in deltas[1:]:
+            acc = g.binary(acc, d, 0)
+        return acc
+    for b, (c, s) in enumerate(zip(widths, scales)):
+        if b == 0:
+            x = g.interp(x01, 1.0 / s)
+            cin = 6
+        else:
+            F = total()
+            w0 = g.warp(g.crop(x01, 0, 3), F)
+            w1 = g.warp(g.crop(x01, 3, 2147483647), g.neg(F))
+            x = g.concat([w0, w1, F])
+            if s > 1:
+                x = g.interp(x, 1.0 / s)
+            cin = 8
+        x = g.prelu(g.convk(x, cin, c, k, 2, kind="stem"), c)
+        for _ in range(6):
+            x = _se_res(g, x, c, k, rng)
+        d = g.pixelshuffle(g.convk(x, c, 8, 3, kind="head"), 2)
+        if s > 1:
+            d = g.interp(d, float(s))
+        deltas.append(d)
+    acc = deltas[0]
+    for d in deltas[1:-1]:
+        acc = g.binary(acc, d, 0)
+    g.binary(acc, deltas[-1], 0, "flow")
+    return g
+
+
+def ifnet_v1(rng=None):
+    """models/rife/flownet.param: 3 blocks (scales 4, 2, 1 of the half-resolution pair; 192 / 128 / 64 channels), 2-channel flow."""
+    return _ifnet_v1((192, 128, 64), (4, 2, 1), 3, rng or np.random.default_rng(7))
+
+
+def ifnet_hd(rng=None):
+    """models/rife-HD/flownet.param: 4 blocks (scales 8, 4, 2, 1; 192 / 128 / 96 / 48 channels), 5 x 5 convs."""
+    return _ifnet_v1((192, 128, 96, 48), (8, 4, 2, 1), 5, rng or np.random.default_rng(7))
+
+
+def _contextnet_v1(widths, stem, rng):
+    g = Graph()
+    x = g.input("input.1")
+    f = g.neg(g.input("flow.1"), "flow.0")
+    cin = 3
+    if stem:                                   # rife-HD: a plain strided conv first, so the first warp already needs flow / 2
+        x = g.prelu(g.convk(x, 3, stem, 3, 2, kind="plain"), stem)
+        cin = stem
+    for i, c in enumerate(widths):
+        x = _se_down(g, x, cin, c, rng)
+        if i > 0 or stem:
+            f = g.scalar(g.interp(f, 0.5), 2, 0.5)
+        g.warp(x, f, "f%d" % (i + 1))
+        cin = c
+    return g
+
+
+def contextnet_v1(rng=None):
+    return _contextnet_v1((16, 32, 64, 128), 0, rng or np.random.default_rng(8))
+
+
+def contextnet_hd(rng=None):
+    return _contextnet_v1((32, 64, 128, 256), 32, rng or np.random.default_rng(8))
+
+
+def _fusionnet_v1(hd, rng):
+    g = Graph()
+    img0, img1, flow = g.input("img0"), g.input("img1"), g.input("flow")
+    c0 = [g.input(str(i)) for i in (3, 4, 5, 6)]
+    c1 = [g.input(str(i)) for i in (7, 8, 9, 10)]
+    Ff = g.scalar(g.interp(flow, 2.0), 2, 2.0)
+    w0 = g.warp(img0, Ff)
+    w1 = g.warp(img1, g.neg(Ff))
+    x = g.concat([w0, w1, Ff])
+    if hd:
+        x = g.prelu(g.convk(x, 8, 32, 3, 2, kind="plain"), 32)
+        s = [x]
+        widths, cin = (64, 128, 256, 512), 32
+        s.append(_se_down(g, s[-1], cin, widths[0], rng))
+        for i in range(3):
+            s.append(_se_down(g, g.concat([s[-1], c0[i], c1[i]]), 2 * widths[i], widths[i + 1], rng))
+        x = g.prelu(g.deconv(g.concat([s[4], c0[3], c1[3]]), 1024, 256, kind="plain"), 256)
+        x = g.prelu(g.deconv(g.concat([x, s[3]]), 512, 128, kind="plain"), 128)
+        x = g.prelu(g.deconv(g.concat([x, s[2]]), 256, 64, kind="plain"), 64)
+        x = g.prelu(g.deconv(g.concat([x, s[1]]), 128, 32, kind="plain"), 32)
+        o = g.sigmoid(g.pixelshuffle(g.convk(x, 32, 16, 3, kind="head"), 2))
+    else:
+        s = [_se_down(g, x, 8, 32, rng)]
+        widths = (32, 64, 128, 256)
+        for i in range(3):
+            s.append(_se_down(g, g.concat([s[-1], c0[i], c1[i]]), 2 * widths[i], widths[i + 1], rng))
+        x = g.prelu(g.deconv(g.concat([s[3], c0[3], c1[3]]), 512, 128, kind="plain"), 128)
+        x = g.prelu(g.deconv(g.concat([x, s[2]]), 256, 64, kind="plain"), 64)
+        x = g.prelu(g.deconv(g.concat([x, s[1]]), 128, 32, kind="plain"), 32)
+        x = g.prelu(g.deconv(g.concat([x, s[0]]), 64, 16, kind="plain"), 16)
+        o = g.convk(x, 16, 4, 3, act="sigmoid", kind="head")
+    res = g.scalar(g.scalar(g.crop(o, 0, 3), 2, 2.0), 1, 1.0)
+    m = g.crop(o, 3, 4)
+    a = g.binary(w0, m, 2)
+    b = g.binary(w1, g.scalar(m, 7, 1.0), 2)
+    g.clip(g.binary(g.binary(a, b, 0), res, 0), 0.0, 1.0, "output")
+    return g
+
+
+def fusionnet_v1(rng=None):
+    return _fusionnet_v1(False, rng or np.random.default_rng(9))
+
+
+def fusionnet_hd(rng=None):
+    return _fusionnet_v1(True, rng or np.random.default_rng(9))
+
+
 FAMILIES = {
     "rife-v4.6": {"flownet": ifnet_v46},
     "rife-v4": {"flownet": ifnet_v40},
     "rife-v2.3": {"flownet": ifnet_v23, "contextnet": contextnet_v23, "fusionnet": fusionnet_v23},
     "rife-v3.1": {"flownet": ifnet_v3, "contextnet": contextnet_v23, "fusionnet": fusionnet_v23},
+    "rife": {"flownet": ifnet_v1, "contextnet": contextnet_v1, "fusionnet": fusionnet_v1},
+    "rife-HD": {"flownet": ifnet_hd, "contextnet": contextnet_hd, "fusionnet": fusionnet_hd},
 }
 
 
@@ -375,7 +550,7 @@ def synth_weights(graph, rng, head_gain, res_gain=1.0):
         elif m["kind"] == "res":
             std *= res_gain                  # residual branch: keep x + conv(x) from doubling the variance
         w = (rng.standard_normal((oc, ic, kh, kw)) * std).astype(np.float16)
-        b = (rng.standard_normal(oc) * 0.01).astype(np.float32)
+        b = (rng.standard_normal(oc) * 0.01).astype(np.float32) if m.get("bias", True) else None
         out.append((l["type"], w, b, None))
     return out
 
@@ -390,7 +565,8 @@ def write_bin(path, weights):
             raw = w.astype("<f2").tobytes()
             f.write(raw)
             f.write(b"\0" * ((-len(raw)) % 4))
-            f.write(b.astype("<f4").tobytes())
+            if b is not None:
+                f.write(b.astype("<f4").tobytes())
 
 
 def generate(outdir, family="rife-v4.6", seed=0x51FE, real_contextnet=None):
@@ -410,6 +586,8 @@ def generate(outdir, family="rife-v4.6", seed=0x51FE, real_contextnet=None):
             w = synth_weights(g, rng, head_gain=0.25, res_gain=0.5)
         elif family == "rife-v4":
             w = synth_weights(g, rng, head_gain=0.25)
+        elif family in ("rife", "rife-HD"):
+            w = synth_weights(g, rng, head_gain=0.25 if net == "flownet" else 0.15, res_gain=0.7)
         elif family == "rife-v3.1":      # small fusion residual: keeps the synthetic output away from the 0 / 255 clip
             w = synth_weights(g, rng, head_gain=0.25 if net == "flownet" else 0.15)
         else:

@@ -47,8 +47,9 @@ def weighted_layers(layers):
     return [(l["type"], tuple(sorted(l["params"].items()))) for l in layers if l["type"] in WEIGHTED]
 
 
-def structural_hash(layers, blob):
-    """Canonical hash of the computation producing `blob`."""
+def structural_hash(layers, blob, ignore_fc_slopes=False):
+    """Canonical hash of the computation producing `blob`.  `ignore_fc_slopes`: leave the fused-activation slope of
+    InnerProduct layers out (in the v1 family these are trained constants stored in the .param, i.e. weights)."""
     producer = {}
     widx = 0
     for l in layers:
@@ -71,7 +72,8 @@ def structural_hash(layers, blob):
         else:
             parts = [l["type"], str(oi), str(l.get("widx", -1))]
             parts += ["%d=%r" % (k, v) for k, v in sorted(l["params"].items())]
-            parts += ["%d=[%s]" % (k, ",".join(repr(x) for x in v)) for k, v in sorted(l["arrays"].items())]
+            if not (ignore_fc_slopes and l["type"] == "InnerProduct"):
+                parts += ["%d=[%s]" % (k, ",".join(repr(x) for x in v)) for k, v in sorted(l["arrays"].items())]
             parts += [h(x) for x in l["bottoms"]]
             r = hashlib.sha256("|".join(parts).encode()).hexdigest()
         memo[b] = r
