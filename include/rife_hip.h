@@ -73,6 +73,11 @@ int rife_hip_v4_extract_flow(const rife_hip_t* r, const uint8_t* in0_rgb, const 
  * rife-v4 5 x hp/2s x wp/2s (Deconvolution output, models/rife-v4/flownet.param:33); s = 8, 4, 2, 1. */
 int rife_hip_v4_flow_dims(const rife_hip_t* r, int w, int h, int fi, int* channels, int* fh, int* fw);
 
+/* Dry run of the generic graph executor's loader on one ncnn .param file (no GPU needed): 0 if every layer of the graph has a
+ * kernel, RIFE_HIP_EMODEL with the offending layer in rife_hip_last_error() otherwise.  The v1 family (models/rife, rife-HD,
+ * rife-UHD, rife-anime) is executed from its .param layer by layer, like ncnn::Net does for every model (src/rife.cpp:112-121). */
+int rife_hip_graph_check(const char* param_path_without_extension);
+
 /* ---- single-kernel entry points for per-kernel parity tests (host arrays, planar CHW fp32 like ncnn::Mat) --- */
 /* 3x3 conv, pad 1, stride 1|2, + bias, optional residual add (same shape as output), per-channel negative slope
  * (1.0 = none, 0.2 = LeakyReLU(0.2), PReLU slopes otherwise): ncnn Convolution (+BinaryOp add +ReLU/PReLU). */

@@ -23,7 +23,7 @@ _lib = None
 C_ABI_SYMBOLS = [
     "rife_hip_device_count", "rife_hip_create", "rife_hip_destroy", "rife_hip_load", "rife_hip_process",
     "rife_hip_process_device", "rife_hip_last_error", "rife_hip_profile_enable", "rife_hip_profile_read",
-    "rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
+    "rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_graph_check", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
 ]
 
 
@@ -65,6 +65,7 @@ def lib():
     L.rife_hip_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, vp, vp, vp, ci]
     L.rife_hip_v4_extract_flow.argtypes = [vp, vp, vp, ci, ci, cf, ci, vp, ci, vp]
     L.rife_hip_v4_flow_dims.argtypes = [vp, ci, ci, ci, vp, vp, vp]
+    L.rife_hip_graph_check.argtypes = [ctypes.c_char_p]
     L.rife_hip_op_conv3x3.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, ci, vp, vp, vp]
     L.rife_hip_op_deconv4x4.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, vp, vp]
     L.rife_hip_op_warp.argtypes = [ci, vp, vp, ci, ci, ci, vp]
@@ -83,6 +84,11 @@ def _check(rc, what):
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def graph_check(param_base):
+    """Raise RifeError if the generic graph executor has no kernel for some layer of <param_base>.param (CPU-only check)."""
+    _check(lib().rife_hip_graph_check(param_base.encode()), "graph_check")
 
 
 def device_count():

@@ -25,6 +25,7 @@
 #include "elementwise_v2.h"
 #include "stem_fused.h"
 #include "head_h2.h"
+#include "graph_kernels.h"
 #include "model_hashes.h"
 #include "ncnn_model.h"
 
@@ -517,6 +518,10 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
 // ------------------------------------------------------------------------------------------------
 // profiler (rife_hip_profile_*): HIP events on the launch stream around every kernel
 // ------------------------------------------------------------------------------------------------
+}  // namespace rife
+#include "graph_exec.h"
+namespace rife {
+
 struct Profiler {
     bool on = false;
     std::mutex mu;
@@ -586,6 +591,9 @@ struct Ctx {
     // rife-v2.x TTA: per orientation RGBX frames, half-res flows [direction][orientation], float outputs [direction][orientation]
     uint32_t *timg0[8] = {}, *timg1[8] = {};
     float4 *tflow[2][8] = {}, *toutf[2][8] = {};
+    // v1 family (generic graph executor): blob storage per net instance, one set per frame orientation (w x h / h x w for TTA);
+    // [.][0] flownet, [1] / [2] contextnet of frame 0 / 1, [3] fusionnet, [4] tensors outside the nets (frames, UHD resizes, TTA flows)
+    std::unique_ptr<GraphInst> ginst[2][5];
     std::vector<void*> allocs;
     ~Ctx() {
         for (void* p : allocs) (void)hipFree(p);
@@ -625,6 +633,9 @@ struct rife_hip {
     // rife-v3.x: same ContextNet / FusionNet, IFNet of 3 blocks (scales 4, 2, 1; 160 channels; trunk = 3 x [conv, conv, + skip])
     bool v3 = false;
     int n_fblk = 4;
+    // v1 family (rife, rife-HD, rife-UHD, rife-anime): executed layer by layer from the .param (graph_exec.h)
+    bool v1 = false;
+    std::unique_ptr<GraphNet> gflow, gctx, gfus;
     ConvLayer ctxc[10];          // ContextNet convs in graph order
     ConvLayer fus[15];           // FusionNet: 10 down convs, 4 up deconvs, sigmoid head
     mutable Profiler prof;
@@ -707,6 +718,10 @@ struct Timed {
 };
 
 static inline dim3 grid2d(int w, int h) { return dim3((w + 255) / 256, h); }
+
+}  // namespace rife
+#include "graph_run.h"
+namespace rife {
 
 static int run_assemble(const rife_hip& E, Ctx& c, int b, float timestep) {
     hipStream_t st = c.stream;
@@ -1232,6 +1247,208 @@ static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// v1 family (models/rife, rife-HD, rife-UHD, rife-anime): RIFE::process with rife_v2 = rife_v4 = false (rife.cpp:381-1212, CPU twin
+// 1214-2460) on the generic graph executor.  One 2-channel flow; frame 0's ContextNet binds it to "flow.0", frame 1's to "flow.1"
+// (the graph negates it, contextnet.param:4-5; rife.cpp:1027-1060).  -u, -x and -z like the v2 family, with the 2-channel algebra.
+// ------------------------------------------------------------------------------------------------
+static int ensure_ctx_v1(Ctx& c, int w, int h, int nori, int ntemp) {
+    const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;
+    const bool ens = nori * ntemp > 1;
+    if (c.v2 && c.wp == wp && c.hp == hp && c.w == w && c.h == h && c.img0 && (!ens || (c.toutf[0][0] && c.toutf[ntemp - 1][nori - 1]))) return 0;
+    for (int d = 0; d < 2; d++) for (int t = 0; t < 8; t++) { c.tflow[d][t] = c.toutf[d][t] = nullptr; if (!d) c.timg0[t] = c.timg1[t] = nullptr; }
+    for (void* p : c.allocs) (void)hipFree(p);
+    c.allocs.clear();
+    for (auto& o : c.ginst) for (auto& g : o) g.reset();
+    c.v2 = true; c.w = w; c.h = h; c.wp = wp; c.hp = hp;
+    c.h0 = c.h1 = c.acc_s = nullptr; c.T2 = nullptr;
+    const size_t P = (size_t)wp * hp;
+    int rc;
+    if ((rc = dalloc(c, c.d_in0, (size_t)w * h * 3))) return rc;
+    if ((rc = dalloc(c, c.d_in1, (size_t)w * h * 3))) return rc;
+    if ((rc = dalloc(c, c.d_out, (size_t)w * h * 3))) return rc;
+    if ((rc = dalloc(c, c.img0, P))) return rc;
+    if ((rc = dalloc(c, c.img1, P))) return rc;
+    c.timg0[0] = c.img0; c.timg1[0] = c.img1;
+    for (int t = 1; t < nori; t++) { if ((rc = dalloc(c, c.timg0[t], P))) return rc; if ((rc = dalloc(c, c.timg1[t], P))) return rc; }
+    if (ens) for (int d = 0; d < ntemp; d++) for (int t = 0; t < nori; t++) if ((rc = dalloc(c, c.toutf[d][t], P))) return rc;
+    return 0;
+}
+
+static int run_v1(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t* d_in1, uint8_t* d_out) {
+    hipStream_t st = c.stream;
+    const int wp = c.wp, hp = c.hp;
+    const int nori = E.tta ? 8 : 1, ntemp = E.tta_temporal ? 2 : 1;
+    int rc;
+    {
+        Timed t(E.prof, "preproc", 0, st);
+        dim3 g = grid2d(wp, hp);
+        if (nori == 8) {
+            Ptr8 a, b;
+            for (int ti = 0; ti < 8; ti++) { a.p[ti] = c.timg0[ti]; b.p[ti] = c.timg1[ti]; }
+            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in0, c.w, c.h, a, wp, hp);
+            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in1, c.w, c.h, b, wp, hp);
+        } else {
+            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.timg0[0], wp, hp);
+            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.timg1[0], wp, hp);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    // tensors outside the three nets live in the "aux" instance of their orientation; slot numbers are fixed:
+    //   0 / 1 frames as 3-channel blobs, 2 / 3 their half-size versions (-u), 4 upscaled flow, 5 doubled flow,
+    //   8 + dir * 8 + ti: the flow of pass (dir, ti)
+    auto inst = [&](int o, int k) -> GraphInst& {
+        if (!c.ginst[o][k]) c.ginst[o][k].reset(new GraphInst);
+        return *c.ginst[o][k];
+    };
+    auto aux = [&](int o) -> GraphInst& {
+        GraphInst& A = inst(o, 4);
+        if (A.v.size() != 32) { A.v.assign(32, GView{nullptr, 0, 0, 0, 0}); A.owned.assign(32, nullptr); A.cap.assign(32, 0); }
+        return A;
+    };
+    auto frames = [&](int ti, int o, int W, int H) -> int {      // RGBX -> "input0" / "input1" style blobs (slots 0, 1)
+        GraphInst& A = aux(o);
+        int r;
+        if ((r = g_alloc(A, 0, 3, H, W, false, st))) return r;
+        if ((r = g_alloc(A, 1, 3, H, W, false, st))) return r;
+        const size_t P = (size_t)W * H;
+        hipLaunchKernelGGL(kg_from_rgbx, dim3(g_blocks(P)), dim3(256), 0, st, (const uint32_t*)c.timg0[ti], A.v[0].p, A.v[0].ld, P);
+        hipLaunchKernelGGL(kg_from_rgbx, dim3(g_blocks(P)), dim3(256), 0, st, (const uint32_t*)c.timg1[ti], A.v[1].p, A.v[1].ld, P);
+        HIPCHK(hipGetLastError());
+        return 0;
+    };
+    // flow of (first, second) -> slot `dst` of the aux instance (2 channels, half resolution); rife.cpp:912-950
+    auto flow_of = [&](int o, int first, int second, int dst) -> int {
+        GraphInst& A = aux(o);
+        GraphInst& F = inst(o, 0);
+        int r;
+        GView fl;
+        if (E.uhd) {
+            const GView a = A.v[first], b = A.v[second];
+            if ((r = g_alloc(A, 2, 3, a.h / 2, a.w / 2, false, st))) return r;
+            if ((r = g_alloc(A, 3, 3, a.h / 2, a.w / 2, false, st))) return r;
+            {
+                Timed t(E.prof, "g_interp", 0, st);
+                hipLaunchKernelGGL(kg_interp, grid2d(a.w / 2, a.h / 2), dim3(256), 0, st, a, A.v[2]);     // rife_uhd_downscale_image (rife.cpp:294-305)
+                hipLaunchKernelGGL(kg_interp, grid2d(a.w / 2, a.h / 2), dim3(256), 0, st, b, A.v[3]);
+            }
+            if ((r = graph_run(E, *E.gflow, F, st, {{"input0", A.v[2]}, {"input1", A.v[3]}}, {"flow"}))) return r;
+            const GView fd = F.v[E.gflow->blob("flow")];
+            if ((r = g_alloc(A, 4, fd.c, fd.h * 2, fd.w * 2, false, st))) return r;
+            if ((r = g_alloc(A, 5, fd.c, fd.h * 2, fd.w * 2, false, st))) return r;
+            Timed t(E.prof, "g_interp", 0, st);
+            hipLaunchKernelGGL(kg_interp, grid2d(fd.w * 2, fd.h * 2), dim3(256), 0, st, fd, A.v[4]);          // rife_uhd_upscale_flow (306-318)
+            hipLaunchKernelGGL(kg_binary_scalar, dim3(g_blocks((size_t)A.v[4].h * A.v[4].w * fd.c)), dim3(256), 0, st, A.v[4], A.v[5], 2, 2.0f);   // rife_uhd_double_flow (319-332)
+            fl = A.v[5];
+        } else {
+            if ((r = graph_run(E, *E.gflow, F, st, {{"input0", A.v[first]}, {"input1", A.v[second]}}, {"flow"}))) return r;
+            fl = F.v[E.gflow->blob("flow")];
+        }
+        if (fl.c != 2) return fail(RIFE_HIP_EMODEL, "the v1-family flownet must produce a 2-channel flow");
+        if ((r = g_alloc(A, dst, 2, fl.h, fl.w, false, st))) return r;
+        hipLaunchKernelGGL(kg_copy_channels, dim3(g_blocks((size_t)fl.h * fl.w * 2)), dim3(256), 0, st, (const float*)fl.p, fl.ld, 0, A.v[dst].p, A.v[dst].ld, 0, 2, (size_t)fl.h * fl.w);
+        HIPCHK(hipGetLastError());
+        return 0;
+    };
+    // (first, second, flow) -> FusionNet "output" view
+    auto synth = [&](int o, int first, int second, int flow_slot, GView& out) -> int {
+        GraphInst& A = aux(o);
+        int r;
+        static const char* const fn[4] = {"f1", "f2", "f3", "f4"};
+        if ((r = graph_run(E, *E.gctx, inst(o, 1), st, {{"input.1", A.v[first]}, {"flow.0", A.v[flow_slot]}}, {"f1", "f2", "f3", "f4"}))) return r;
+        if ((r = graph_run(E, *E.gctx, inst(o, 2), st, {{"input.1", A.v[second]}, {"flow.1", A.v[flow_slot]}}, {"f1", "f2", "f3", "f4"}))) return r;
+        std::vector<std::pair<std::string, GView>> in = {{"img0", A.v[first]}, {"img1", A.v[second]}, {"flow", A.v[flow_slot]}};
+        static const char* const n0[4] = {"3", "4", "5", "6"};
+        static const char* const n1[4] = {"7", "8", "9", "10"};
+        for (int k = 0; k < 4; k++) {
+            in.push_back({n0[k], inst(o, 1).v[E.gctx->blob(fn[k])]});
+            in.push_back({n1[k], inst(o, 2).v[E.gctx->blob(fn[k])]});
+        }
+        if ((r = graph_run(E, *E.gfus, inst(o, 3), st, in, {"output"}))) return r;
+        out = inst(o, 3).v[E.gfus->blob("output")];
+        if (out.c != 3) return fail(RIFE_HIP_EMODEL, "the FusionNet output must have 3 channels");
+        return 0;
+    };
+    auto ow = [&](int ti) { return ti < 4 ? wp : hp; };
+    auto oh = [&](int ti) { return ti < 4 ? hp : wp; };
+    if (nori * ntemp == 1) {
+        GView out;
+        if ((rc = frames(0, 0, wp, hp))) return rc;
+        if ((rc = flow_of(0, 0, 1, 8))) return rc;
+        if ((rc = synth(0, 0, 1, 8, out))) return rc;
+        Timed t(E.prof, "final", 0, st);
+        hipLaunchKernelGGL(kg_to_u8, grid2d(c.w, c.h), dim3(256), 0, st, out, d_out, c.w, c.h);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    // ---- ensembles: all flows first (they are merged across passes), then one synthesis per pass.  The frames of an orientation are
+    // converted again for the synthesis stage because orientations of the same shape share the aux slots 0 / 1.
+    for (int ti = 0; ti < nori; ti++) {
+        const int o = ti < 4 ? 0 : 1;
+        if ((rc = frames(ti, o, ow(ti), oh(ti)))) return rc;
+        if ((rc = flow_of(o, 0, 1, 8 + ti))) return rc;
+        if (ntemp == 2) {
+            if ((rc = flow_of(o, 1, 0, 16 + ti))) return rc;
+            GraphInst& A = aux(o);
+            Timed t(E.prof, "tta_merge", 0, st);
+            hipLaunchKernelGGL(kg_v1_temporal_merge, dim3(g_blocks((size_t)A.v[8 + ti].h * A.v[8 + ti].w)), dim3(256), 0, st, A.v[8 + ti], A.v[16 + ti]);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    if (nori == 8) {
+        Timed t(E.prof, "tta_merge", 0, st);
+        for (int d = 0; d < ntemp; d++) {
+            Ptr8 f;
+            for (int ti = 0; ti < 8; ti++) f.p[ti] = aux(ti < 4 ? 0 : 1).v[8 + d * 8 + ti].p;
+            const GView f0 = aux(0).v[8 + d * 8];
+            hipLaunchKernelGGL(kg_v1_spatial_avg, grid2d(f0.w, f0.h), dim3(256), 0, st, f, f0.ld, f0.w, f0.h);
+        }
+        if (ntemp == 2)
+            for (int ti = 0; ti < 8; ti++) {
+                GraphInst& A = aux(ti < 4 ? 0 : 1);
+                hipLaunchKernelGGL(kg_v1_temporal_merge, dim3(g_blocks((size_t)A.v[8 + ti].h * A.v[8 + ti].w)), dim3(256), 0, st, A.v[8 + ti], A.v[16 + ti]);
+            }
+        HIPCHK(hipGetLastError());
+    }
+    for (int ti = 0; ti < nori; ti++) {
+        const int o = ti < 4 ? 0 : 1;
+        if ((rc = frames(ti, o, ow(ti), oh(ti)))) return rc;
+        for (int d = 0; d < ntemp; d++) {
+            GView out;
+            // reversed pass: frames swapped, flow_reversed = -flow after the merge; the contexts the reference re-uses swapped
+            // (rife.cpp:1099-1131) are the same computation
+            if ((rc = synth(o, d ? 1 : 0, d ? 0 : 1, 8 + d * 8 + ti, out))) return rc;
+            hipLaunchKernelGGL(kg_to_float4, dim3(g_blocks((size_t)out.h * out.w)), dim3(256), 0, st, out, c.toutf[d][ti]);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    {
+        Timed t(E.prof, "final", 0, st);
+        Ptr16 outs;
+        for (int d = 0; d < 2; d++) for (int ti = 0; ti < 8; ti++) outs.p[d * 8 + ti] = c.toutf[d][ti];
+        hipLaunchKernelGGL(k_postproc_tta, grid2d(c.w, c.h), dim3(256), 0, st, outs, nori, ntemp, d_out, c.w, c.h, wp, hp);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+static int load_v1(rife_hip* E, const std::string& dir) {
+    E->gflow.reset(new GraphNet); E->gctx.reset(new GraphNet); E->gfus.reset(new GraphNet);
+    int rc;
+    if ((rc = graph_load(*E->gflow, dir + "/flownet"))) return rc;
+    if ((rc = graph_load(*E->gctx, dir + "/contextnet"))) return rc;
+    if ((rc = graph_load(*E->gfus, dir + "/fusionnet"))) return rc;
+    // the blob-name contract RIFE::process relies on (rife.cpp:948-950, 1027-1060, 1070-1098)
+    static const char* const need_f[] = {"input0", "input1", "flow"};
+    static const char* const need_c[] = {"input.1", "flow.0", "flow.1", "f1", "f2", "f3", "f4"};
+    static const char* const need_u[] = {"img0", "img1", "flow", "3", "4", "5", "6", "7", "8", "9", "10", "output"};
+    for (const char* n : need_f) if (E->gflow->blob(n) < 0) return fail(RIFE_HIP_EMODEL, dir + "/flownet.param has no blob " + n);
+    for (const char* n : need_c) if (E->gctx->blob(n) < 0) return fail(RIFE_HIP_EMODEL, dir + "/contextnet.param has no blob " + n + " (not a v1-family model?)");
+    for (const char* n : need_u) if (E->gfus->blob(n) < 0) return fail(RIFE_HIP_EMODEL, dir + "/fusionnet.param has no blob " + n);
+    E->v1 = true;
+    return 0;
+}
+
 // weights of the three v2 nets -> ConvLayers (conv/deconv each optionally followed by its PReLU in the .bin stream)
 static int load_v2(rife_hip* E, const std::string& dir) {
     NcnnModel mf, mc, mu;
@@ -1345,7 +1562,11 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {
         E->loaded = true;
         return 0;
     }
-    if (!E->v4) return fail(RIFE_HIP_ENOSYS, "the rife-v1 family (rife, rife-HD, rife-UHD, rife-anime) is not implemented");
+    if (!E->v4) {
+        if ((rc = load_v1(E, modeldir))) return rc;
+        E->loaded = true;
+        return 0;
+    }
     NcnnModel m;
     const std::string base = std::string(modeldir) + "/flownet";
     if (!m.load_param(base + ".param")) return fail(RIFE_HIP_EIO, m.error);
@@ -1458,14 +1679,16 @@ int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
         c->own_stream = true;
     }
-    rc = E->v4 ? ensure_ctx(*c, w, h) : ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1, E->v3);
+    rc = E->v4 ? ensure_ctx(*c, w, h) : E->v1 ? ensure_ctx_v1(*c, w, h, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1)
+                                              : ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1, E->v3);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(c->d_in0, in0, nbytes, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->d_in1, in1, nbytes, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) rc = fail(RIFE_HIP_EHIP, std::string("H2D: ") + hipGetErrorString(e));
     }
     if (!rc) {
-        if (!E->v4) rc = run_v2(*E, *c, c->d_in0, c->d_in1, c->d_out);
+        if (E->v1) rc = run_v1(*E, *c, c->d_in0, c->d_in1, c->d_out);
+        else if (!E->v4) rc = run_v2(*E, *c, c->d_in0, c->d_in1, c->d_out);
         else if (E->tta || E->tta_temporal) {
             // the TTA workspaces are shared by all callers: serialise, and drain before the next caller may reuse them
             std::lock_guard<std::mutex> g(E->tta_mu);
@@ -1508,7 +1731,10 @@ int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* 
     if (timestep == 0.f || timestep == 1.f) {
         HIPCHK(hipMemcpyAsync(d_out, timestep == 0.f ? d_in0 : d_in1, nbytes, hipMemcpyDeviceToDevice, c->stream));
     } else {
-        if (!E->v4) {
+        if (E->v1) {
+            if ((rc = ensure_ctx_v1(*c, w, h, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1))) return rc;
+            if ((rc = run_v1(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, (uint8_t*)d_out))) return rc;
+        } else if (!E->v4) {
             if ((rc = ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1, E->v3))) return rc;
             if ((rc = run_v2(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, (uint8_t*)d_out))) return rc;
         } else if (E->tta || E->tta_temporal) {
@@ -1588,6 +1814,12 @@ int rife_hip_v4_extract_flow(const rife_hip_t* E, const uint8_t* in0, const uint
     HIPCHK(hipMemcpyAsync(out6chw, tmp, (size_t)Hb * Wb * nc * 4, hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
     return 0;
+}
+
+int rife_hip_graph_check(const char* base) {
+    if (!base) return fail(RIFE_HIP_EINVAL, "null argument");
+    GraphNet n;
+    return graph_load(n, base, true);
 }
 
 int rife_hip_v4_flow_dims(const rife_hip_t* E, int w, int h, int fi, int* channels, int* fh, int* fw) {

@@ -91,7 +91,25 @@ bool NcnnModel::load_bin(const std::string& path) {
             L.slope.resize(n);
             std::memcpy(L.slope.data(), &raw[pos], (size_t)n * 4); pos += (size_t)n * 4;
         } else if (L.type == "InnerProduct") {
-            error = path + ": InnerProduct layers (rife-HD/UHD/anime families) are not supported"; return false;
+            // 0 = num_output, 1 = bias_term, 2 = weight_data_size (SE blocks of the v1 family, models/rife/flownet.param:15-16)
+            const int n = L.geti(2, 0), outc = L.geti(0, 0);
+            if (!have(4)) { error = path + ": truncated"; return false; }
+            uint32_t tag; std::memcpy(&tag, &raw[pos], 4); pos += 4;
+            L.weight.resize(n);
+            if (tag == 0x01306B47u) {
+                const size_t bytes = ((size_t)n * 2 + 3) & ~(size_t)3;
+                if (!have(bytes)) { error = path + ": truncated"; return false; }
+                for (int i = 0; i < n; i++) { uint16_t h; std::memcpy(&h, &raw[pos + (size_t)i * 2], 2); L.weight[i] = h2f(h); }
+                pos += bytes;
+            } else if (tag == 0) {
+                if (!have((size_t)n * 4)) { error = path + ": truncated"; return false; }
+                std::memcpy(L.weight.data(), &raw[pos], (size_t)n * 4); pos += (size_t)n * 4;
+            } else { error = path + ": unsupported weight storage tag"; return false; }
+            L.bias.assign(outc, 0.f);
+            if (L.geti(1, 0)) {
+                if (!have((size_t)outc * 4)) { error = path + ": truncated"; return false; }
+                std::memcpy(L.bias.data(), &raw[pos], (size_t)outc * 4); pos += (size_t)outc * 4;
+            }
         }
     }
     if (pos != total) { error = path + ": trailing bytes after the last weighted layer"; return false; }

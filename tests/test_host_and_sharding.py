@@ -111,3 +111,28 @@ def test_cpp_class_shim_compiles_and_fails_cleanly_without_gpu(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 3                      # load() reported failure, no crash, no fallback
     assert "RIFE" in r.stderr
+
+
+def test_graph_executor_has_a_kernel_for_every_layer_of_the_generated_graphs(modeldirs):
+    """CPU-only dry run of the generic graph executor's loader (rife_hip_graph_check) on every generated graph."""
+    import os
+    for fam, d in modeldirs.items():
+        if fam == "rife-v4":
+            continue            # 5-channel deconv head: handled by the dedicated rife-v4 schedule (padded to 8)
+        for net in ("flownet", "contextnet", "fusionnet"):
+            if os.path.exists(os.path.join(d, net + ".param")):
+                amd.graph_check(os.path.join(d, net))
+    with pytest.raises(amd.RifeError):
+        amd.graph_check(os.path.join(modeldirs["rife-v4"], "flownet"))
+
+
+def test_graph_executor_covers_the_reference_model_zoo():
+    import os
+    from conftest import REFERENCE
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("reference tree only exists in the build container")
+    for fam in sorted(os.listdir(os.path.join(REFERENCE, "models"))):
+        for net in ("flownet", "contextnet", "fusionnet"):
+            base = os.path.join(REFERENCE, "models", fam, net)
+            if os.path.exists(base + ".param") and fam != "rife-v4":
+                amd.graph_check(base)
