@@ -61,26 +61,29 @@ struct ConvArgs {
     int cpad = 0;
 };
 
-template <int STRIDE, int MS> struct ConvGeom {
+template <int STRIDE, int MS, int KS = 3> struct ConvGeom {
     static constexpr int TH = 4 * MS, TW = 32;
-    static constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
+    static constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
 };
 
-template <int EPI> constexpr int conv_ntaps() { return EPI == EPI_STORE ? 9 : 4; }
+// TAG 5 selects the 5 x 5 (pad 2) geometry of the rife-HD IFNet; every other TAG is a 3 x 3 (pad 1) convolution
+template <int TAG> constexpr int conv_ks() { return TAG == 5 ? 5 : 3; }
+template <int EPI, int KS = 3> constexpr int conv_ntaps() { return EPI == EPI_STORE ? KS * KS : 4; }
 
-template <int STRIDE, int MS, int NS, int CC, int EPI>
+template <int STRIDE, int MS, int NS, int CC, int EPI, int KS = 3>
 constexpr int conv_lds_bytes() {
-    return (ConvGeom<STRIDE, MS>::IH * ConvGeom<STRIDE, MS>::IW * (CC + 4) + conv_ntaps<EPI>() * CC * NS * 32) * 4;
+    return (ConvGeom<STRIDE, MS, KS>::IH * ConvGeom<STRIDE, MS, KS>::IW * (CC + 4) + conv_ntaps<EPI, KS>() * CC * NS * 32) * 4;
 }
 
-// TAG only gives a layer class its own kernel symbol (so rocprofv3 --stats reports it separately).
+// TAG (other than 5) only gives a layer class its own kernel symbol (so rocprofv3 --stats reports it separately).
 template <int STRIDE, int MS, int NS, int CC, int EPI, int TAG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_mfma_kernel(ConvArgs a) {
-    using G = ConvGeom<STRIDE, MS>;
+    constexpr int KS = conv_ks<TAG>();
+    using G = ConvGeom<STRIDE, MS, KS>;
     constexpr int S = CC + 4;                 // LDS pixel stride (floats): S/4 odd -> conflict-free b128 column reads
     constexpr int NT = NS * 32;
     constexpr int NG = CC / 8;
-    constexpr int NTAPS = conv_ntaps<EPI>();
+    constexpr int NTAPS = conv_ntaps<EPI, KS>();
     constexpr int NPAR = EPI == EPI_STORE ? 1 : 4;
     constexpr int NQ = CC / 4;
     constexpr int IN_F4 = G::IH * G::IW * NQ;              // float4s of one input chunk tile
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int par = z % NPAR, ntile = z / NPAR;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int oy0 = ty * G::TH, ox0 = tx * G::TW;
-    const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;   // top-left of the staged halo tile in input pixels
+    const int iy0 = oy0 * STRIDE - KS / 2, ix0 = ox0 * STRIDE - KS / 2;   // top-left of the staged halo tile in input pixels
 
     // ---- per-thread staging slots (chunk-independent part of the addresses, hoisted out of the K loop) ----
     int goff[NIN];      // global float offset of this thread's k-th input float4 (channel chunk 0); 0 when out of image
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int t = 0; t < NTAPS; t++) {
             int dy, dx;                                   // tap offset + 1 (halo origin)
-            if (EPI == EPI_STORE) { dy = t / 3; dx = t % 3; }
+            if (EPI == EPI_STORE) { dy = t / KS; dx = t % KS; }
             else {   // deconv parity p, tap bit: 0 -> d = 0; 1 -> d = (p ? +1 : -1)   (see configure() in engine.hip)
                 dy = 1 + ((t >> 1) ? ((par >> 1) ? 1 : -1) : 0);
                 dx = 1 + ((t & 1) ? ((par & 1) ? 1 : -1) : 0);

@@ -48,6 +48,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return -code; }
 // ------------------------------------------------------------------------------------------------
 struct ConvLayer {
     int cin = 0, cin_p = 0, cout = 0, stride = 1;
+    int ks = 3;                           // 3 (pad 1) or 5 (pad 2; fp32 MFMA kernel only)
     bool deconv = false;
     int epi = EPI_STORE;
     int MS = 2, NS = 2, CC = 16;          // kernel configuration
@@ -85,12 +86,16 @@ static void configure(ConvLayer& L) {
     L.nchunks = L.cin_p / L.CC;
     L.ntaps = L.deconv ? 4 : 9;
     L.npar = L.deconv ? 4 : 1;
+    if (L.ks == 5) {   // 25 taps: 32-channel N-tiles keep the weight slab of a chunk at 25.6 KB
+        L.NS = 1; L.ntiles = (L.cout + 31) / 32; L.CC = 8; L.MS = L.stride == 2 ? 1 : 2;
+        L.cin_p = (L.cin + 7) / 8 * 8; L.nchunks = L.cin_p / 8; L.ntaps = 25; L.tag = 5;
+    }
 }
 
 // ncnn weight order [oc][ic][kh][kw] (also for Deconvolution) -> MFMA B-fragment order
 // [ntile][par][chunk][tap][g][half][n][4], channel = chunk*CC + g*8 + half*4 + s.
 static std::vector<float> pack_weights(const ConvLayer& L, const float* w) {
-    const int NT = L.NS * 32, NG = L.CC / 8, K = L.deconv ? 4 : 3;
+    const int NT = L.NS * 32, NG = L.CC / 8, K = L.deconv ? 4 : L.ks;
     // deconv: out(2y+p) gathers input y+d through kernel row k with 2(y+d) + k - 1 = 2y + p
     //   p=0: tap bit 0 -> (d=0,k=1), bit 1 -> (d=-1,k=3);  p=1: bit 0 -> (d=0,k=2), bit 1 -> (d=+1,k=0)   (offsets: conv_mfma.h)
     static const int KD[2][2] = {{1, 3}, {2, 0}};
@@ -102,7 +107,7 @@ static std::vector<float> pack_weights(const ConvLayer& L, const float* w) {
                 for (int t = 0; t < L.ntaps; t++) {
                     int ky, kx;
                     if (L.deconv) { ky = KD[par >> 1][t >> 1]; kx = KD[par & 1][t & 1]; }
-                    else { ky = t / 3; kx = t % 3; }
+                    else { ky = t / K; kx = t % K; }
                     for (int g = 0; g < NG; g++)
                         for (int half = 0; half < 2; half++)
                             for (int n = 0; n < NT; n++)
@@ -209,8 +214,9 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
     HIPCHK(hipMemcpy(L.d_w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(L.d_bias, b.data(), cp * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(L.d_slope, s.data(), cp * 4, hipMemcpyHostToDevice));
-    const int K = L.deconv ? 16 : 9;
+    const int K = L.deconv ? 16 : L.ks * L.ks;
     L.flops_per_pixel = 2.0 * L.cin * L.cout * K;
+    if (L.ks != 3) return 0;          // the 8-wave and split-f16 variants below are 3 x 3 kernels
     if (!L.deconv && L.stride == 1 && L.epi == EPI_STORE && L.NS >= 2 && L.cin % 8 == 0) {
         if (L.CC == 8) { L.d_w8 = nullptr; L.nchunks8 = L.nchunks; }     // the normal packing already is CC = 8
         else {
@@ -277,7 +283,7 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
 template <int STRIDE, int MS, int NS, int CC, int EPI, int TAG>
 static hipError_t launch_cfg(const ConvArgs& a, int nblocks, hipStream_t st) {
     auto kfn = conv_mfma_kernel<STRIDE, MS, NS, CC, EPI, TAG>;
-    constexpr int lds = conv_lds_bytes<STRIDE, MS, NS, CC, EPI>();
+    constexpr int lds = conv_lds_bytes<STRIDE, MS, NS, CC, EPI, conv_ks<TAG>()>();
     static_assert(lds <= 64 * 1024, "tile does not fit the default dynamic LDS limit");
     hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(256), lds, st, a);
     return hipGetLastError();
@@ -488,6 +494,9 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
     hipError_t e = hipErrorInvalidValue;
 #define RIFE_CFG(S_, MS_, NS_, CC_, E_, T_) \
     if (L.stride == S_ && MS == MS_ && L.NS == NS_ && L.CC == CC_ && L.epi == E_ && L.tag == T_) e = launch_cfg<S_, MS_, NS_, CC_, E_, T_>(a, nblocks, st); else
+    RIFE_CFG(2, 1, 1, 8, EPI_STORE, 5)
+    RIFE_CFG(1, 2, 1, 8, EPI_STORE, 5)
+    RIFE_CFG(1, 1, 1, 8, EPI_STORE, 5)
     RIFE_CFG(2, 1, 1, 8, EPI_STORE, 0)
     RIFE_CFG(2, 1, 2, 8, EPI_STORE, 0)
     RIFE_CFG(2, 1, 3, 8, EPI_STORE, 0)

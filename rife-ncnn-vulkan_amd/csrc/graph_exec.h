@@ -128,11 +128,12 @@ static int graph_load(GraphNet& N, const std::string& base, bool check_only = fa
                 if (!check_only && (int)P.nl->slope.size() == outc) slope = P.nl->slope;
                 if (check_only || (int)P.nl->slope.size() == outc) { P.folded = true; L.out_blob = P.tops[0]; }
             }
-            const bool mfma = deconv ? (k == 4 && stride == 2 && pad == 1) : (k == 3 && pad == 1 && (stride == 1 || stride == 2));
+            const bool mfma = deconv ? (k == 4 && stride == 2 && pad == 1) : ((k == 3 || k == 5) && pad == k / 2 && (stride == 1 || stride == 2));
             if (mfma) {
                 L.kind = deconv ? G_DECONV : G_CONV;
                 L.conv.cin = cin; L.conv.cout = outc; L.conv.stride = deconv ? 1 : stride; L.conv.deconv = deconv; L.conv.epi = deconv ? EPI_DECONV : EPI_STORE;
-                L.conv.cls = deconv ? "g_deconv4x4" : (stride == 2 ? "g_conv3x3_s2" : "g_conv3x3"); L.conv.tag = 0; L.conv.skip = false;
+                L.conv.ks = deconv ? 3 : k;
+                L.conv.cls = deconv ? "g_deconv4x4" : (k == 5 ? "g_conv5x5" : (stride == 2 ? "g_conv3x3_s2" : "g_conv3x3")); L.conv.tag = 0; L.conv.skip = false;
                 if (!check_only && (rc = upload_layer(L.conv, nl.weight.data(), nl.bias.data(), slope.data(), 1.0f))) return rc;
             } else {
                 if (deconv || pad != k / 2 || (stride != 1 && stride != 2)) return bad("no kernel for this convolution geometry");

@@ -132,22 +132,30 @@ __global__ void kg_warp(GView img, GView flow, GView out) {
     for (int q = 0; q < img.c; q++) o[q] = warp_lerp(a[q], b[q], c[q], d[q], t.alpha, t.beta);
 }
 
-// Global average pooling, stage 1: per-channel partial sums of one pixel chunk (double accumulation: the result is the
-// correctly rounded mean to well below the fp32 sequential sum of the reference, whose own error is ~1e-6 relative)
-// grid (ceil(c / 64), nchunks), block 256 = 64 channels x 4 pixel phases
+// Global average pooling, stage 1: per-channel partial sums of one contiguous pixel chunk per block (double accumulation: the
+// result is the correctly rounded mean to well below the fp32 sequential sum of the reference, whose own error is ~1e-6 relative).
+// 256 threads = (256 / (c/4)) pixel lanes x (c/4) channel quads, float4 loads; needs c % 4 == 0 and c <= 1024.
 __global__ void kg_pool_partial(GView in, double* __restrict__ partial, int nchunks) {
-    __shared__ double sm[4][64];
-    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    const int q = blockIdx.x * 64 + cl;
+    __shared__ double sm[256 * 4];
+    const int cq = in.c / 4, ppb = 256 / cq;
+    const int pl = threadIdx.x / cq, q = threadIdx.x - pl * cq;
     const size_t npix = (size_t)in.h * in.w;
     const size_t per = (npix + nchunks - 1) / nchunks;
-    const size_t p0 = (size_t)blockIdx.y * per, p1 = min(npix, p0 + per);
-    double s = 0.0;
-    if (q < in.c)
-        for (size_t p = p0 + ph; p < p1; p += 4) s += (double)in.p[p * in.ld + q];
-    sm[ph][cl] = s;
+    const size_t p0 = (size_t)blockIdx.x * per, p1 = min(npix, p0 + per);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (pl < ppb)
+        for (size_t p = p0 + pl; p < p1; p += ppb) {
+            const float4 v = *reinterpret_cast<const float4*>(in.p + p * in.ld + q * 4);
+            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+        }
+    sm[threadIdx.x * 4 + 0] = a0; sm[threadIdx.x * 4 + 1] = a1; sm[threadIdx.x * 4 + 2] = a2; sm[threadIdx.x * 4 + 3] = a3;
     __syncthreads();
-    if (ph == 0 && q < in.c) partial[(size_t)blockIdx.y * in.c + q] = sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl];
+    for (int c = threadIdx.x; c < in.c; c += 256) {
+        const int qq = c >> 2, e = c & 3;
+        double s = 0.0;
+        for (int l = 0; l < ppb; l++) s += sm[(l * cq + qq) * 4 + e];
+        partial[(size_t)blockIdx.x * in.c + c] = s;
+    }
 }
 
 __global__ void kg_pool_finish(const double* __restrict__ partial, int nchunks, int c, double inv_npix, float* __restrict__ out) {

@@ -167,7 +167,8 @@ static int graph_run(const rife_hip& E, const GraphNet& N, GraphInst& I, hipStre
             case G_POOL: {
                 if ((rc = out_alloc(x.c, 1, 1, true))) return rc;
                 const size_t npix = (size_t)x.h * x.w;
-                const int nchunks = (int)std::min<size_t>(128, (npix + 255) / 256);
+                if (x.c % 4 || x.c > 1024) return fail(RIFE_HIP_EMODEL, N.name + ": global pooling needs a channel count that is a multiple of 4 (<= 1024) at " + nl.name);
+                const int nchunks = (int)std::min<size_t>(512, (npix + 511) / 512);
                 const size_t needp = (size_t)nchunks * x.c;
                 if (I.partial_cap < needp) {
                     HIPCHK(hipStreamSynchronize(st));
@@ -177,7 +178,7 @@ static int graph_run(const rife_hip& E, const GraphNet& N, GraphInst& I, hipStre
                     I.partial_cap = needp;
                 }
                 Timed t(E.prof, "g_pool", 0, st);
-                hipLaunchKernelGGL(kg_pool_partial, dim3((x.c + 63) / 64, nchunks), dim3(256), 0, st, x, I.partial, nchunks);
+                hipLaunchKernelGGL(kg_pool_partial, dim3(nchunks), dim3(256), 0, st, x, I.partial, nchunks);
                 hipLaunchKernelGGL(kg_pool_finish, dim3((x.c + 255) / 256), dim3(256), 0, st, (const double*)I.partial, nchunks, x.c, 1.0 / (double)npix, I.v[ob].p);
                 break;
             }
