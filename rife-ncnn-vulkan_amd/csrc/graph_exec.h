@@ -22,6 +22,7 @@ struct GLayer {
     int out_blob = -1;                                // where the result goes (the folded PReLU's top for conv + PReLU pairs)
     bool folded = false;                              // PReLU executed by its producer
     int post_act = 0;                                 // activation the conv epilogue cannot apply (4 = sigmoid): extra pointwise pass
+    int se_y = -1, se_scale = -1, se_skip = -1;       // G_PRELU closing an SE block: y * scale + skip is computed here too (kg_se_tail)
 };
 
 struct GraphNet {
@@ -149,6 +150,23 @@ static int graph_load(GraphNet& N, const std::string& base, bool check_only = fa
                 }
             }
         } else return bad("unsupported layer type");
+    }
+    // squeeze-and-excitation tails: BinaryOp mul (y, per-channel vector) -> BinaryOp add (., skip) -> PReLU, each link read once
+    for (size_t li = 0; li < N.layers.size(); li++) {
+        GLayer& P = N.layers[li];
+        if (P.kind != G_PRELU || P.folded) continue;
+        const int pb = N.producer[P.bottoms[0]];
+        if (pb < 0 || nuse[P.bottoms[0]] != 1) continue;
+        GLayer& B = N.layers[pb];
+        if (B.kind != G_BINARY || B.nl->geti(0, 0) != 0 || B.bottoms.size() != 2) continue;
+        const int pa = N.producer[B.bottoms[0]];
+        if (pa < 0 || nuse[B.bottoms[0]] != 1) continue;
+        GLayer& A = N.layers[pa];
+        if (A.kind != G_BINARY || A.nl->geti(0, 0) != 2 || A.bottoms.size() != 2) continue;
+        const int pv = N.producer[A.bottoms[1]];
+        if (pv < 0 || N.layers[pv].kind != G_INNER) continue;                      // the scale must be the pooled FC output
+        P.se_y = A.bottoms[0]; P.se_scale = A.bottoms[1]; P.se_skip = B.bottoms[1];
+        A.folded = true; B.folded = true;
     }
     return 0;
 }

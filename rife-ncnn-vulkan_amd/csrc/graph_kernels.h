@@ -109,6 +109,18 @@ __global__ void kg_pointwise(GView a, GView out, int mode, float p0, float p1, c
     out.p[p * out.ld + q] = v;
 }
 
+// tail of a squeeze-and-excitation residual block in one pass: BinaryOp mul (per-channel scale) -> BinaryOp add (skip) -> PReLU
+__global__ void kg_se_tail(GView y, const float* __restrict__ scale, GView skip, const float* __restrict__ slopes, GView out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)y.h * y.w * y.c;
+    if (i >= n) return;
+    const size_t p = i / y.c; const int q = (int)(i - p * y.c);
+    float v = y.p[p * y.ld + q] * scale[q];
+    v = v + skip.p[p * skip.ld + q];
+    if (v < 0.f) v = v * slopes[q];
+    out.p[p * out.ld + q] = v;
+}
+
 // ncnn PixelShuffle (mode 0): out[c][y*r+i][x*r+j] = in[c*r*r + i*r + j][y][x]
 __global__ void kg_pixelshuffle(GView in, GView out, int r) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

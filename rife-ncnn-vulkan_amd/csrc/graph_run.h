@@ -33,7 +33,19 @@ static int graph_run(const rife_hip& E, const GraphNet& N, GraphInst& I, hipStre
         if (!need[li]) continue;
         const GLayer& L = N.layers[li];
         const NcnnLayer& nl = *L.nl;
-        if (L.kind == G_PRELU && L.folded) { have[L.tops[0]] = 1; continue; }      // executed by its producer
+        if (L.folded) { have[L.tops[0]] = 1; continue; }                           // executed by its producer (PReLU) or its consumer (SE tail)
+        if (L.kind == G_PRELU && L.se_y >= 0) {
+            const GView y = I.v[L.se_y], sc = I.v[L.se_scale], sk = I.v[L.se_skip];
+            if (!have[L.se_y] || !have[L.se_scale] || !have[L.se_skip]) return fail(RIFE_HIP_EMODEL, N.name + ": SE tail operands missing at " + nl.name);
+            if (sc.c != y.c || sc.h != 1 || sc.w != 1 || sk.c != y.c || sk.h != y.h || sk.w != y.w || (int)nl.slope.size() != y.c)
+                return fail(RIFE_HIP_EMODEL, N.name + ": SE tail shape mismatch at " + nl.name);
+            if ((rc = g_alloc(I, L.out_blob, y.c, y.h, y.w, false, st))) return rc;
+            Timed t(E.prof, "g_se_tail", 0, st);
+            hipLaunchKernelGGL(kg_se_tail, dim3(g_blocks((size_t)y.h * y.w * y.c)), dim3(256), 0, st, y, (const float*)sc.p, sk, (const float*)L.d_slope, I.v[L.out_blob]);
+            HIPCHK(hipGetLastError());
+            have[L.out_blob] = 1;
+            continue;
+        }
         for (int b : L.bottoms)
             if (!have[b]) return fail(RIFE_HIP_EMODEL, N.name + ": blob " + N.blob_names[b] + " is not available for " + nl.name);
         const GView x = L.bottoms.empty() ? GView{nullptr, 0, 0, 0, 0} : I.v[L.bottoms[0]];
