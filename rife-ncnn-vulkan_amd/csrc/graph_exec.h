@@ -115,7 +115,7 @@ static int graph_load(GraphNet& N, const std::string& base, bool check_only = fa
             const bool deconv = t == "Deconvolution";
             const int outc = nl.geti(0, 0), k = nl.geti(1, 1), stride = nl.geti(3, 1), pad = nl.geti(4, 0), act = nl.geti(9, 0);
             if (nl.geti(2, 1) != 1) return bad("dilation is not supported");
-            if (outc % 4) return bad("output channels must be a multiple of 4");
+            const int outc_p = (outc + 3) / 4 * 4;      // the kernels store 4 channels at a time: pad with zero filters (writes zeros into the blob's pad channels)
             if (act != 0 && act != 2 && act != 4) return bad("unsupported fused activation");
             const int cin = outc > 0 && k > 0 ? nl.geti(6, 0) / (outc * k * k) : 0;
             if (cin <= 0 || cin * outc * k * k != nl.geti(6, 0)) return bad("weight count does not factor");
@@ -135,10 +135,21 @@ static int graph_load(GraphNet& N, const std::string& base, bool check_only = fa
                 L.conv.cin = cin; L.conv.cout = outc; L.conv.stride = deconv ? 1 : stride; L.conv.deconv = deconv; L.conv.epi = deconv ? EPI_DECONV : EPI_STORE;
                 L.conv.ks = deconv ? 3 : k;
                 L.conv.cls = deconv ? "g_deconv4x4" : (k == 5 ? "g_conv5x5" : (stride == 2 ? "g_conv3x3_s2" : "g_conv3x3")); L.conv.tag = 0; L.conv.skip = false;
-                if (!check_only && (rc = upload_layer(L.conv, nl.weight.data(), nl.bias.data(), slope.data(), 1.0f))) return rc;
+                if (!check_only) {
+                    if (outc_p == outc) { if ((rc = upload_layer(L.conv, nl.weight.data(), nl.bias.data(), slope.data(), 1.0f))) return rc; }
+                    else {
+                        std::vector<float> wp((size_t)outc_p * cin * k * k, 0.f), bp(outc_p, 0.f), sp(outc_p, 1.f);
+                        std::copy(nl.weight.begin(), nl.weight.end(), wp.begin());               // [oc][ic][ky][kx]: extra filters go last
+                        std::copy(nl.bias.begin(), nl.bias.end(), bp.begin());
+                        std::copy(slope.begin(), slope.end(), sp.begin());
+                        L.conv.cout = outc_p;
+                        if ((rc = upload_layer(L.conv, wp.data(), bp.data(), sp.data(), 1.0f))) return rc;
+                    }
+                }
             } else {
                 if (deconv || pad != k / 2 || (stride != 1 && stride != 2)) return bad("no kernel for this convolution geometry");
                 L.kind = G_CONV_DIRECT;
+                if (outc % 4) return bad("the direct kernel needs an output channel count that is a multiple of 4");
                 if (!check_only) {
                     std::vector<float> w((size_t)k * k * cin * outc);
                     for (int o = 0; o < outc; o++)

@@ -99,14 +99,14 @@ static int graph_run(const rife_hip& E, const GraphNet& N, GraphInst& I, hipStre
                 const bool dc = L.kind == G_DECONV;
                 const int oh = dc ? 2 * x.h : (x.h - 1) / L.conv.stride + 1, ow = dc ? 2 * x.w : (x.w - 1) / L.conv.stride + 1;
                 if (x.c != L.conv.cin) return fail(RIFE_HIP_EMODEL, N.name + ": channel mismatch at " + nl.name);
-                if ((rc = out_alloc(L.conv.cout, oh, ow))) return rc;
+                if ((rc = out_alloc(nl.geti(0, 0), oh, ow))) return rc;
                 {
                     Timed t(E.prof, L.conv.cls, L.conv.flops_per_pixel * (dc ? (double)x.h * x.w : (double)oh * ow), st);
                     if ((rc = launch_conv(L.conv, {x.p, x.ld, 0}, x.h, x.w, {I.v[ob].p, I.v[ob].ld, 0}, nullptr, st))) return rc;
                 }
                 if (L.post_act == 4) {
                     Timed t(E.prof, "g_pointwise", 0, st);
-                    hipLaunchKernelGGL(kg_pointwise, dim3(g_blocks((size_t)oh * ow * L.conv.cout)), dim3(256), 0, st, I.v[ob], I.v[ob], 1, 0.f, 0.f, (const float*)nullptr);
+                    hipLaunchKernelGGL(kg_pointwise, dim3(g_blocks((size_t)oh * ow * I.v[ob].c)), dim3(256), 0, st, I.v[ob], I.v[ob], 1, 0.f, 0.f, (const float*)nullptr);
                 }
                 break;
             }
