@@ -12,17 +12,26 @@ from conftest import ROOT
 FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
 
 
+def meta(g):
+    """family + mode flags of a fixture (fixtures from before the family field are rife-v4.6)"""
+    fam = str(g["family"]) if "family" in g.files else "rife-v4.6"
+    kw = dict(tta_mode=bool(g["tta"]), tta_temporal_mode=bool(g["temporal"]), uhd_mode=bool(g["uhd"]) if "uhd" in g.files else False,
+              rife_v2=fam.startswith(("rife-v2", "rife-v3")), rife_v4=fam.startswith("rife-v4"))
+    return fam, kw
+
+
 def test_fixtures_exist():
-    assert len(FIXTURES) >= 4
+    assert len(FIXTURES) >= 10
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
 def test_oracle_reproduces_golden(modeldirs, path):
     from oracle import pyoracle
     g = np.load(path)
-    o = pyoracle.OracleRIFE(tta_mode=bool(g["tta"]), tta_temporal_mode=bool(g["temporal"]), rife_v4=True)
+    fam, kw = meta(g)
+    o = pyoracle.OracleRIFE(**kw)
     o.set_gpu_crop(1)
-    o.load(modeldirs["rife-v4.6"])
+    o.load(modeldirs[fam])
     out = o.process(g["in0"], g["in1"], float(g["timestep"]))
     assert np.abs(out.astype(int) - g["out"].astype(int)).max() <= 1
     assert (out != g["out"]).mean() < 1e-3
@@ -33,8 +42,9 @@ def test_oracle_reproduces_golden(modeldirs, path):
 def test_hip_engine_matches_golden(modeldirs, path):
     amd = importlib.import_module("rife-ncnn-vulkan_amd")
     g = np.load(path)
-    e = amd.RIFE(0, tta_mode=bool(g["tta"]), tta_temporal_mode=bool(g["temporal"]), rife_v4=True)
-    e.load(modeldirs["rife-v4.6"])
+    fam, kw = meta(g)
+    e = amd.RIFE(0, **kw)
+    e.load(modeldirs[fam])
     out = e.process(g["in0"], g["in1"], float(g["timestep"]))
     assert np.abs(out.astype(int) - g["out"].astype(int)).max() <= 1          # north_star: <= 1 LSB per channel
     if "flow3" in g.files:
