@@ -141,9 +141,15 @@ def main():
     for i in range(args.warmup):
         step(i)
     sh.barrier(dist, torch.cuda.synchronize)
-    eng.profile_enable(os.environ.get("RIFE_BENCH_NOPROF", "") == "")
+    # THE timed region (`value`): K steps, nothing but the product path (the per-launch HIP events of the profiler cost 5 % at
+    # 4K and 20 % at 1080p, so they are kept out of it) ...
     elapsed = sh.timed_steps(lambda i: run_steps(i, args.steps), 1, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
                              make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+    # ... and the same K steps again with HIP events around every launch on its stream (`roofline_in_timed_region`)
+    sh.barrier(dist, torch.cuda.synchronize)
+    eng.profile_enable(True)
+    elapsed_instr = sh.timed_steps(lambda i: run_steps(i, args.steps), 1, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
+                                   make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
     prof = eng.profile_read()
     eng.profile_enable(False)
     # second region, same K steps with ONE pair in flight: kernels of different pairs no longer overlap, so the HIP-event time of
@@ -174,7 +180,7 @@ def main():
         if prof1 is not None:
             roof = roofline_of(prof1.get(DOMINANT[family][0], dict(ms=0.0, launches=0, flops=0.0)), family, w, h, f32_mode)
             if roof is not None:
-                roof["measured_in"] = "second region of the same %d steps with 1 pair in flight (non-overlapping launches); see roofline_in_timed_region" % args.steps
+                roof["measured_in"] = "HIP events on the launch stream over a region of the same %d steps with 1 pair in flight (non-overlapping launches); roofline_in_timed_region = the timed region repeated with the events on" % args.steps
         traffic_file = os.path.join(ROOT, "profiles", "r1", "pmc_%s.json" % args.workload)
         if roof is not None and os.path.exists(traffic_file):
             tf = json.load(open(traffic_file))                   # from the committed rocprofv3 --pmc passes (not live)
@@ -194,7 +200,8 @@ def main():
             "roofline": roof,
             "roofline_in_timed_region": roof_timed if prof1 is not None else None,
             "cpu_baseline": cpu,
-            "extra": {"frames_per_s_with_1_pair_in_flight": None if fps1 is None else round(fps1, 3), "kernel_ms_per_pair": round(all_ms / args.steps, 4), "conv_ms_per_pair": round(conv_ms / args.steps, 4),
+            "extra": {"frames_per_s_same_region_with_per_launch_events": round(world * args.steps / elapsed_instr, 3),
+                      "frames_per_s_with_1_pair_in_flight": None if fps1 is None else round(fps1, 3), "kernel_ms_per_pair": round(all_ms / args.steps, 4), "conv_ms_per_pair": round(conv_ms / args.steps, 4),
                       "conv_tflops_overall": round(gflop_pair / max(conv_ms / args.steps, 1e-9), 2),
                       "frac_of_fused_hbm_roofline_e2e": None if roofline_ms is None else round(roofline_ms / (elapsed / args.steps * 1e3), 5),
                       "per_class_ms_per_pair": {k: round(v["ms"] / args.steps, 4) for k, v in sorted((prof1 or prof).items(), key=lambda kv: -kv[1]["ms"])}},

@@ -88,8 +88,10 @@ __device__ __forceinline__ float down4(float v00, float v01, float v10, float v1
 }
 
 // Block-0 input: x = Interp(1/8)(Concat(in0, in1, in2)) -> NHWC8 {in0.rgb, in1.rgb, t, 0}   (flownet.param:9-10)
-__global__ void k_assemble0(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float timestep,
+// `tsp` != null: the timestep is read from device memory (hipGraph replays need launch parameters that never change)
+__global__ void k_assemble0(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float timestep_arg, const float* __restrict__ tsp,
                             float* __restrict__ X, int wp, int hp) {
+    const float timestep = tsp ? *tsp : timestep_arg;
     const int Wb = wp / 8, Hb = hp / 8;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= Wb || y >= Hb) return;
@@ -141,8 +143,9 @@ __device__ __forceinline__ void assemble_pixel(const uint32_t* __restrict__ img0
 }
 
 template <int S>
-__global__ void k_assemble(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float timestep,
+__global__ void k_assemble(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float timestep_arg, const float* __restrict__ tsp,
                            const float4* __restrict__ F, const float* __restrict__ M, float* __restrict__ X, int wp, int hp) {
+    const float timestep = tsp ? *tsp : timestep_arg;
     const int Wb = wp / S, Hb = hp / S;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= Wb || y >= Hb) return;

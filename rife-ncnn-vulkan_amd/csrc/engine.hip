@@ -589,6 +589,11 @@ struct Ctx {
     float* flow[4] = {nullptr, nullptr, nullptr, nullptr};           // [hp/s][wp/s][8]
     float4* F = nullptr; float* M = nullptr;                         // full-resolution flow (4ch) and mask logit
     float4* outf = nullptr;                                          // TTA only: out0 as float, padded
+    // hipGraph replay of the plain v4 schedule for launch-bound frame sizes: fixed staging buffers (d_in0 / d_in1 / d_out), the
+    // timestep in device memory, one warm-up pass (lazy allocations, kernel attributes), then capture once and replay
+    float* d_ts = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    bool g_warm = false;
     // rife-v2.x only
     bool v2 = false;
     float4 *acc = nullptr, *D = nullptr, *head = nullptr;           // running half-res flow, deconv output, fusion head
@@ -605,6 +610,7 @@ struct Ctx {
     std::unique_ptr<GraphInst> ginst[2][5];
     std::vector<void*> allocs;
     ~Ctx() {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
         for (void* p : allocs) (void)hipFree(p);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -683,6 +689,8 @@ static const uint64_t V46_HASH_OUT0 = RIFE_V46_HASH_OUT0;
 static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scratch = nullptr, bool own_images = true, bool want_outf = false) {
     if (!c.v2 && c.wp == wp && c.hp == hp && c.w == w && c.h == h && (!want_outf || c.outf)) return 0;
     c.v2 = false;
+    if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
+    c.g_warm = false; c.d_ts = nullptr;
     for (void* p : c.allocs) (void)hipFree(p);
     c.allocs.clear();
     c.outf = nullptr;
@@ -712,6 +720,7 @@ static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scra
     }
     if ((rc = dalloc(c, c.F, P))) return rc;
     if ((rc = dalloc(c, c.M, P))) return rc;
+    if (!scratch && (rc = dalloc(c, c.d_ts, 4))) return rc;
     if (want_outf && (rc = dalloc(c, c.outf, P))) return rc;
     return 0;
 }
@@ -732,33 +741,33 @@ static inline dim3 grid2d(int w, int h) { return dim3((w + 255) / 256, h); }
 #include "graph_run.h"
 namespace rife {
 
-static int run_assemble(const rife_hip& E, Ctx& c, int b, float timestep) {
+static int run_assemble(const rife_hip& E, Ctx& c, int b, float timestep, const float* tsp = nullptr) {
     hipStream_t st = c.stream;
     Timed t(E.prof, "assemble", 0, st);
     const int s = E.blk[b].scale;
     dim3 g = grid2d(c.wp / s, c.hp / s);
-    if (b == 0) hipLaunchKernelGGL(k_assemble0, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.X, c.wp, c.hp);
-    else if (s == 4) hipLaunchKernelGGL(k_assemble<4>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
-    else if (s == 2) hipLaunchKernelGGL(k_assemble<2>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
-    else hipLaunchKernelGGL(k_assemble<1>, g, dim3(256), 0, st, c.img0, c.img1, timestep, c.F, c.M, c.X, c.wp, c.hp);
+    if (b == 0) hipLaunchKernelGGL(k_assemble0, g, dim3(256), 0, st, c.img0, c.img1, timestep, tsp, c.X, c.wp, c.hp);
+    else if (s == 4) hipLaunchKernelGGL(k_assemble<4>, g, dim3(256), 0, st, c.img0, c.img1, timestep, tsp, c.F, c.M, c.X, c.wp, c.hp);
+    else if (s == 2) hipLaunchKernelGGL(k_assemble<2>, g, dim3(256), 0, st, c.img0, c.img1, timestep, tsp, c.F, c.M, c.X, c.wp, c.hp);
+    else hipLaunchKernelGGL(k_assemble<1>, g, dim3(256), 0, st, c.img0, c.img1, timestep, tsp, c.F, c.M, c.X, c.wp, c.hp);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 // One IFBlock: stems, 8 residual convs, head -> flow[b]   (flownet.param:11-46, 63-98, 116-151, 166-201)
-static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, const FinalArgs* fin = nullptr) {
+static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, const FinalArgs* fin = nullptr, const float* tsp = nullptr) {
     const rife_hip::Block& B = E.blk[b];
     hipStream_t st = c.stream;
     const int s = B.scale, Hb = c.hp / s, Wb = c.wp / s;
     const int xin_ld = b == 0 ? 8 : 16;
     int rc;
-    if (b == 0 && (rc = run_assemble(E, c, 0, timestep))) return rc;
+    if (b == 0 && (rc = run_assemble(E, c, 0, timestep, tsp))) return rc;
     if (b > 0 && B.stem0.d_wh && g_trunk_h2 && g_fuse_stem) {
         // assemble + stem-0 in one kernel (stem_fused.h): the block input never goes to HBM
         Timed t(E.prof, B.stem0.cls, B.stem0.flops_per_pixel * (Hb / 2) * (Wb / 2), st);
         StemFusedArgs fa;
         fa.img0 = c.img0; fa.img1 = c.img1; fa.F = c.F; fa.M = c.M; fa.wpk = B.stem0.d_wh; fa.bias = B.stem0.d_bias; fa.slope = B.stem0.d_slope;
-        fa.out = c.S1; fa.timestep = timestep; fa.wp = c.wp; fa.hp = c.hp; fa.Ho = Hb / 2; fa.Wo = Wb / 2; fa.out_ld = B.c / 2; fa.Cout = B.c / 2;
+        fa.out = c.S1; fa.timestep = timestep; fa.tsp = tsp; fa.wp = c.wp; fa.hp = c.hp; fa.Ho = Hb / 2; fa.Wo = Wb / 2; fa.out_ld = B.c / 2; fa.Cout = B.c / 2;
         fa.tiles_x = (fa.Wo + 31) / 32;
         const int nb = fa.tiles_x * ((fa.Ho + 3) / 4);
         {
@@ -776,7 +785,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         else hipLaunchKernelGGL((stem0_fused_kernel<1, 1>), dim3(nb), dim3(512), stemf_lds_bytes<1>(), st, fa);
         HIPCHK(hipGetLastError());
     } else {
-        if (b > 0 && (rc = run_assemble(E, c, b, timestep))) return rc;
+        if (b > 0 && (rc = run_assemble(E, c, b, timestep, tsp))) return rc;
         Timed t(E.prof, B.stem0.cls, B.stem0.flops_per_pixel * (Hb / 2) * (Wb / 2), st);
         if ((rc = launch_conv(B.stem0, {c.X, xin_ld, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, nullptr, st))) return rc;
     }
@@ -826,7 +835,7 @@ static int run_flow_update(const rife_hip& E, Ctx& c, int b) {
 }
 
 // RIFE::process_v4, non-TTA branch (rife.cpp:2931-3173) on device-resident frames.
-static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t* d_in1, float timestep, uint8_t* d_out) {
+static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t* d_in1, float timestep, uint8_t* d_out, const float* tsp = nullptr) {
     hipStream_t st = c.stream;
     int rc;
     {
@@ -839,7 +848,7 @@ static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     const bool fuse_tail = !E.v40 && g_trunk_h2 && g_head_h2 && g_fuse_tail && E.blk[3].head.d_wh != nullptr;
     FinalArgs fin{c.img0, c.img1, c.F, c.M, d_out, c.w, c.h, c.wp, c.hp};
     for (int b = 0; b < 4; b++) {
-        if ((rc = run_block_convs(E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr))) return rc;
+        if ((rc = run_block_convs(E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr, tsp))) return rc;
         if ((b < 3 || E.v40) && (rc = run_flow_update(E, c, b))) return rc;
     }
     if (E.v40) {
@@ -851,6 +860,43 @@ static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
         hipLaunchKernelGGL(k_final, grid2d(c.w, c.h), dim3(256), 0, st, c.img0, c.img1, c.F, c.M, c.flow[3], d_out, c.w, c.h, c.wp, c.hp);
         HIPCHK(hipGetLastError());
     }
+    return 0;
+}
+
+// Plain v4 pass replayed from a hipGraph for small frames (<= 1920 x 1088 padded), opt-in with RIFE_HIP_GRAPH=1: one graph launch
+// instead of ~50 kernel launches (+ two small device copies into the fixed staging buffers).  Measured on MI355X
+// (tools/graph_bench.py, profiler off): 1080p 1.116 vs 1.119 ms per pair, 720p 0.782 vs 0.782, 360p 0.673 vs 0.674 - no gain: the
+// chain of ~50 dependent kernels (fill / drain of each launch), not host launch overhead, sets the floor, and a replayed graph
+// executes the same chain.  Kept off by default; the profiler (events around every launch) bypasses it.
+static const bool g_use_graph = []() { const char* e = getenv("RIFE_HIP_GRAPH"); return e && e[0] == '1'; }();
+
+static int run_v4_replay(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t* d_in1, float timestep, uint8_t* d_out) {
+    const bool eligible = g_use_graph && !E.prof.on && c.d_ts && (size_t)c.wp * c.hp <= (size_t)1920 * 1088;
+    if (!eligible) return run_v4(E, c, d_in0, d_in1, timestep, d_out);
+    hipStream_t st = c.stream;
+    const size_t nbytes = (size_t)c.w * c.h * 3;
+    if (d_in0 != c.d_in0) HIPCHK(hipMemcpyAsync(c.d_in0, d_in0, nbytes, hipMemcpyDeviceToDevice, st));
+    if (d_in1 != c.d_in1) HIPCHK(hipMemcpyAsync(c.d_in1, d_in1, nbytes, hipMemcpyDeviceToDevice, st));
+    uint32_t bits; std::memcpy(&bits, &timestep, 4);
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c.d_ts, (int)bits, 1, st));
+    int rc = 0;
+    if (c.gexec) HIPCHK(hipGraphLaunch(c.gexec, st));
+    else if (!c.g_warm) {
+        if ((rc = run_v4(E, c, c.d_in0, c.d_in1, timestep, c.d_out, c.d_ts))) return rc;
+        c.g_warm = true;
+    } else {
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        rc = run_v4(E, c, c.d_in0, c.d_in1, timestep, c.d_out, c.d_ts);
+        const hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess || !graph) return fail(RIFE_HIP_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        const hipError_t ei = hipGraphInstantiate(&c.gexec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) { c.gexec = nullptr; return fail(RIFE_HIP_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+        HIPCHK(hipGraphLaunch(c.gexec, st));
+    }
+    if (d_out != c.d_out) HIPCHK(hipMemcpyAsync(d_out, c.d_out, nbytes, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -1703,7 +1749,7 @@ int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1
             std::lock_guard<std::mutex> g(E->tta_mu);
             rc = run_v4_tta(*E, c->stream, c->d_in0, c->d_in1, w, h, timestep, c->d_out);
             if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "TTA stream sync failed");
-        } else rc = run_v4(*E, *c, c->d_in0, c->d_in1, timestep, c->d_out);
+        } else rc = run_v4_replay(*E, *c, c->d_in0, c->d_in1, timestep, c->d_out);
     }
     if (!rc) {
         hipError_t e = hipMemcpyAsync(out, c->d_out, nbytes, hipMemcpyDeviceToHost, c->stream);
@@ -1753,7 +1799,7 @@ int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* 
             HIPCHK(hipStreamSynchronize(c->stream));
         } else {
             if ((rc = ensure_ctx(*c, w, h))) return rc;
-            if ((rc = run_v4(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, timestep, (uint8_t*)d_out))) return rc;
+            if ((rc = run_v4_replay(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, timestep, (uint8_t*)d_out))) return rc;
         }
     }
     if (!hip_stream) HIPCHK(hipStreamSynchronize(c->stream));
@@ -2038,7 +2084,7 @@ int rife_hip_bench_stemf(int gpuid, int wp, int hp, int variant, int iters, floa
     HIPCHK(hipMemset(i0, 0x40, P * 4)); HIPCHK(hipMemset(i1, 0x60, P * 4)); HIPCHK(hipMemset(F, 0, P * 16)); HIPCHK(hipMemset(M, 0, P * 4));
     HIPCHK(hipMemset(bias, 0, 256)); HIPCHK(hipMemset(wh, 0, 9 * 2 * 32 * 16));
     StemFusedArgs fa;
-    fa.img0 = i0; fa.img1 = i1; fa.F = F; fa.M = M; fa.wpk = wh; fa.bias = bias; fa.slope = bias; fa.out = out; fa.timestep = 0.5f;
+    fa.img0 = i0; fa.img1 = i1; fa.F = F; fa.M = M; fa.wpk = wh; fa.bias = bias; fa.slope = bias; fa.out = out; fa.timestep = 0.5f; fa.tsp = nullptr;
     fa.wp = wp; fa.hp = hp; fa.Ho = hp / 2; fa.Wo = wp / 2; fa.out_ld = 32; fa.Cout = 32; fa.tiles_x = (fa.Wo + 31) / 32;
     const int nb = fa.tiles_x * ((fa.Ho + 3) / 4);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));

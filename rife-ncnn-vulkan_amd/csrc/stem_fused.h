@@ -19,6 +19,7 @@ struct StemFusedArgs {
     const float *bias, *slope;
     float* out;            // NHWC, out_ld floats per pixel
     float timestep;
+    const float* tsp;      // != null: timestep read from device memory (hipGraph replays)
     int wp, hp;            // padded full resolution
     int Ho, Wo, out_ld, Cout, tiles_x;
 };
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* const lw = ldsb + NPIX * PIXB;
 
+    const float timestep = a.tsp ? *a.tsp : a.timestep;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv8 = tid >> 6;
     const int wv = wv8 & 3, nsel = wv8 >> 2;          // output row, N-subtile of this wave
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int py_ = p_ / IW, px_ = p_ - py_ * IW;                                                             \
         const int by_ = iy0 + py_, bx_ = ix0 + px_;                                                               \
         const bool in_ = by_ >= 0 && by_ < Hb && bx_ >= 0 && bx_ < Wb;                                            \
-        assemble_pixel<S>(a.img0, a.img1, a.timestep, a.F, a.M, a.wp, a.hp, min(max(bx_, 0), Wb - 1), min(max(by_, 0), Hb - 1), O); \
+        assemble_pixel<S>(a.img0, a.img1, timestep, a.F, a.M, a.wp, a.hp, min(max(bx_, 0), Wb - 1), min(max(by_, 0), Hb - 1), O); \
         _Pragma("unroll") for (int c = 0; c < 12; c++) O[c] = in_ ? O[c] : 0.f;                                   \
     }
 #define STEM_STAGE(P, O)                                                                                          \
