@@ -105,8 +105,11 @@ class RIFE:
             raise RifeError("rife_hip_create: " + lib().rife_hip_last_error().decode())
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().rife_hip_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:       # at interpreter shutdown the module globals may be gone already
+            try:
+                _lib.rife_hip_destroy(self._h)
+            except Exception:
+                pass
             self._h = None
 
     def load(self, modeldir):
