@@ -740,187 +740,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// conv_h2p_kernel: conv_h2b_kernel as a PERSISTENT kernel.  A trunk layer has only 4-12 K chunks per tile, so in the
-// one-tile-per-workgroup kernels the exposed prologue (first chunk: global load -> LDS -> barrier) and epilogue are as long
-// as the matrix work itself.  Here the grid is 2 workgroups per CU and every workgroup walks its tiles with ONE software
-// pipeline over the flattened (tile, chunk) sequence: while tile k's last chunks are on the matrix pipe, the first chunks of
-// tile k+1 are already in registers / LDS, and tile k's stores overlap the next tile's loads.  Same operand layout, same
-// arithmetic and summation order per output as conv_h2b_kernel (bit-identical results).  Direct 16-byte epilogue stores: the
-// LDS staging buffers are never idle, so there is no room for the transposed epilogue.
-// ------------------------------------------------------------------------------------------------------------
-template <int NS, int NTAPS, int TAG>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_h2p_kernel(ConvArgs a, int n_total) {
-    constexpr int IH = 10, IW = 34, CC = 16, NT = NS * 32;
-    constexpr int PIXB = 80;
-    constexpr int IN_F4 = IH * IW * 4;
-    constexpr int W_16 = NTAPS * 2 * NT;
-    constexpr int NIN = (IN_F4 + 511) / 512, NW = (W_16 + 511) / 512;
-    constexpr int INB = IH * IW * PIXB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    unsigned char* const lw = ldsb + 2 * INB;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int half = lane >> 5, li = lane & 31;
-    const int G = gridDim.x;
-    const int ntl = (n_total - (int)blockIdx.x + G - 1) / G;       // tiles of this workgroup (grid <= n_total, so >= 1)
-    const int nch = a.nchunks;
-    const int total = ntl * nch;
-
-    // per-tile state: C = tile being computed, N = the tile after it
-    int goffC[NIN], goffN[NIN];
-    unsigned insC = 0, insN = 0;
-    int oy0C = 0, ox0C = 0, ntC = 0, oy0N = 0, ox0N = 0, ntN = 0;
-#define H2P_SETUP(K, GOFF, INS, OY0, OX0, NTL)                                                              \
-    {                                                                                                       \
-        const int vb_ = (int)blockIdx.x + (K) * G;                                                          \
-        const int q_ = n_total >> 3, r_ = n_total & 7, xcd_ = vb_ & 7;                                      \
-        const int L_ = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + (vb_ >> 3);       \
-        const int tile_ = L_ / a.nz;                                                                        \
-        NTL = L_ - tile_ * a.nz;                                                                            \
-        const int ty_ = tile_ / a.tiles_x, tx_ = tile_ - ty_ * a.tiles_x;                                   \
-        OY0 = ty_ * 8; OX0 = tx_ * 32;                                                                      \
-        INS = 0;                                                                                            \
-        _Pragma("unroll") for (int k = 0; k < NIN; k++) {                                                   \
-            const int idx = tid + k * 512;                                                                  \
-            const int p = idx >> 2, q = idx & 3;                                                            \
-            const int py = p / IW, px = p - py * IW;                                                        \
-            const int gy = OY0 - 1 + py, gx = OX0 - 1 + px;                                                 \
-            const bool ok = idx < IN_F4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;                      \
-            GOFF[k] = ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff;                       \
-            INS |= ok ? (1u << k) : 0u;                                                                     \
-        }                                                                                                   \
-    }
-    H2P_SETUP(0, goffC, insC, oy0C, ox0C, ntC)
-    if (ntl > 1) H2P_SETUP(1, goffN, insN, oy0N, ox0N, ntN)
-    const f32x4* const wbase = reinterpret_cast<const f32x4*>(a.wpk);
-
-    f32x4 rin[NIN], rw[NW];
-    unsigned rin_ins = 0;                                  // `inside` mask of the tile the registers rin belong to
-    // chunk CH of the current (NEXT = false) or next (NEXT = true) tile -> registers
-#define H2P_ISSUE_IN(CH, NEXT)                                                                              \
-    {                                                                                                       \
-        _Pragma("unroll") for (int k = 0; k < NIN; k++)                                                     \
-            rin[k] = *reinterpret_cast<const f32x4*>(a.in + ((NEXT) ? goffN[k] : goffC[k]) + (CH) * CC);    \
-        rin_ins = (NEXT) ? insN : insC;                                                                     \
-    }
-#define H2P_ISSUE_W(CH, NEXT)                                                                               \
-    {                                                                                                       \
-        const f32x4* wsrc_ = wbase + ((size_t)((NEXT) ? ntN : ntC) * nch + (CH)) * W_16;                    \
-        _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                    \
-            const int idx = tid + k * 512;                                                                  \
-            rw[k] = wsrc_[(W_16 % 512 == 0 || idx < W_16) ? idx : 0];                                       \
-        }                                                                                                   \
-    }
-#define H2P_WRITE_IN(BUFP)                                                                                  \
-    _Pragma("unroll") for (int k = 0; k < NIN; k++) {                                                       \
-        const int idx = tid + k * 512;                                                                      \
-        const int p = idx >> 2, q = idx & 3;                                                                \
-        f16x4 hi4, lo4;                                                                                     \
-        _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                     \
-            const float v = ((rin_ins >> k) & 1u) ? rin[k][e] : 0.f;                                        \
-            const _Float16 h = (_Float16)v;                                                                 \
-            hi4[e] = h;                                                                                     \
-            lo4[e] = (_Float16)(v - (float)h);                                                              \
-        }                                                                                                   \
-        if (IN_F4 % 512 == 0 || idx < IN_F4) {                                                              \
-            *reinterpret_cast<f16x4*>((BUFP) + p * PIXB + q * 8) = hi4;                                     \
-            *reinterpret_cast<f16x4*>((BUFP) + p * PIXB + 32 + q * 8) = lo4;                                \
-        }                                                                                                   \
-    }
-#define H2P_WRITE_W()                                                                                       \
-    _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                        \
-        const int idx = tid + k * 512;                                                                      \
-        if (W_16 % 512 == 0 || idx < W_16) reinterpret_cast<f32x4*>(lw)[idx] = rw[k];                       \
-    }
-#define H2P_TAPS(BUFP, T0, T1)                                                                              \
-    {                                                                                                       \
-        const unsigned char* ab_ = (BUFP) + (wv * IW + li) * PIXB + half * 16;                              \
-        const unsigned char* bb_ = lw + (half * NT + li) * 16;                                              \
-        _Pragma("unroll") for (int t = (T0); t < (T1); t++) {                                               \
-            const int dy = t == 9 ? 1 : t / 3, dx = t == 9 ? 1 : t % 3;                                     \
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(ab_ + (dy * IW + dx) * PIXB);                  \
-            const f16x8 al = *reinterpret_cast<const f16x8*>(ab_ + (dy * IW + dx) * PIXB + 32);             \
-            f16x8 bw[NS];                                                                                   \
-            _Pragma("unroll") for (int n = 0; n < NS; n++)                                                  \
-                bw[n] = *reinterpret_cast<const f16x8*>(bb_ + (t * 2 * NT + n * 32) * 16);                  \
-            _Pragma("unroll") for (int n = 0; n < NS; n++)                                                  \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[n], ah, acc[n], 0, 0, 0);                \
-            _Pragma("unroll") for (int n = 0; n < NS; n++)                                                  \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[n], al, acc[n], 0, 0, 0);                \
-        }                                                                                                   \
-    }
-
-    f32x16 acc[NS];
-#pragma unroll
-    for (int n = 0; n < NS; n++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
-
-    // prologue: flattened step 0 -> LDS, step 1 -> registers (a tile has >= 2 chunks, so step 1 is chunk 1 of the first tile)
-    H2P_ISSUE_IN(0, false)
-    H2P_ISSUE_W(0, false)
-    H2P_WRITE_IN(ldsb)
-    H2P_WRITE_W()
-    if (total > 1) { H2P_ISSUE_IN(1, false) H2P_ISSUE_W(1, false) }
-    __syncthreads();
-    int ch = 0, tk = 0;                                    // chunk within the tile, tile ordinal of this workgroup
-    for (int g = 0; g < total; g++) {
-        unsigned char* cur = ldsb + (g & 1) * INB;
-        unsigned char* oth = ldsb + ((g & 1) ^ 1) * INB;
-        const bool last = ch == nch - 1;
-        const bool nxt2 = ch + 2 >= nch;                   // step g+2 belongs to the next tile
-        const int ch2 = nxt2 ? ch + 2 - nch : ch + 2;
-        H2P_TAPS(cur, 0, NTAPS / 2)
-        if (g + 1 < total) { H2P_WRITE_IN(oth) }           // input of step g+1 (in registers since the middle of step g-1)
-        if (g + 2 < total) { if (nxt2) H2P_ISSUE_IN(ch2, true) else H2P_ISSUE_IN(ch2, false) }
-        H2P_TAPS(cur, NTAPS / 2, NTAPS)
-        if (last) {
-            // ---- epilogue of tile tk: bias, activation, one 16-byte store per register quad ----
-            const int oy = oy0C + wv, ox = ox0C + li;
-            const bool pok = oy < a.Ho && ox < a.Wo;
-#pragma unroll
-            for (int n = 0; n < NS; n++) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int c0 = ntC * NT + n * 32 + 8 * q + 4 * half;
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
-                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
-                    f32x4 v;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { v[k] = acc[n][4 * q + k] + b4[k]; v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k]; }
-                    if (pok && c0 < a.Cout) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < NS; n++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
-        }
-        if (g + 1 < total) {
-            __syncthreads();                               // everyone is done with the weight slab (and the input buffer) of step g
-            H2P_WRITE_W()
-            if (g + 2 < total) { if (nxt2) H2P_ISSUE_W(ch2, true) else H2P_ISSUE_W(ch2, false) }
-            if (last) {                                    // step g closed its tile: the next tile becomes the current one
-                tk++;
-#pragma unroll
-                for (int k = 0; k < NIN; k++) goffC[k] = goffN[k];
-                insC = insN; oy0C = oy0N; ox0C = ox0N; ntC = ntN;
-                if (tk + 1 < ntl) H2P_SETUP(tk + 1, goffN, insN, oy0N, ox0N, ntN)
-                ch = 0;
-            } else ch++;
-            __syncthreads();
-        }
-    }
-#undef H2P_SETUP
-#undef H2P_ISSUE_IN
-#undef H2P_ISSUE_W
-#undef H2P_WRITE_IN
-#undef H2P_WRITE_W
-#undef H2P_TAPS
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // conv_h2s2_kernel: 3x3 stride-2 convolution (the second stem conv of every IFBlock, c/2 -> c) on the split-f16 pipe.
 //   256 threads = 4 waves, tile = 4 x 32 outputs <- 9 x 65 input pixels per 16-channel chunk (46.8 KB) + weight slab;
 //   single LDS buffer, next chunk prefetched into registers (issue early / write late); two workgroups per CU.

@@ -435,28 +435,6 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
             if (!a.partial) return fail(RIFE_HIP_EHIP, "split-K workspace allocation failed");
             nbl = nb * nsplit;
         }
-        // plenty of tiles (>= 2 per workgroup slot): persistent kernel, one software pipeline across the tiles of a workgroup
-        static const bool persist = []() { const char* e = getenv("RIFE_HIP_PERSIST"); return !(e && e[0] == '0'); }();
-        if (persist && g_h2b && nsplit == 1 && L.NS == 2 && nb >= 1024 && a.nchunks >= 2) {
-            {
-                static std::mutex pmu; static std::map<int, bool> pdone;
-                int dev = 0; (void)hipGetDevice(&dev);
-                std::lock_guard<std::mutex> g(pmu);
-                if (!pdone[dev]) {
-                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2p_kernel<2, 10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lb10));
-                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2p_kernel<2, 10, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb10));
-                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2p_kernel<2, 9, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb9));
-                    pdone[dev] = true;
-                }
-            }
-            const int G = 512;                               // 2 workgroups per CU x 256 CUs; multiple of 8 (XCD-aware tile walk)
-            if (L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2p_kernel<2, 10, 3>), dim3(G), dim3(512), lb10, st, a, nb);
-            else if (L.skip) hipLaunchKernelGGL((conv_h2p_kernel<2, 10, 0>), dim3(G), dim3(512), lb10, st, a, nb);
-            else hipLaunchKernelGGL((conv_h2p_kernel<2, 9, 0>), dim3(G), dim3(512), lb9, st, a, nb);
-            hipError_t ep = hipGetLastError();
-            if (ep != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_h2p launch: ") + hipGetErrorString(ep));
-            return 0;
-        }
         const int nb_saved = nb; (void)nb_saved;
 #define nb nbl
         constexpr int lb110 = convh2b_lds_bytes<1, 10>();
