@@ -50,6 +50,12 @@ int rife_hip_load(rife_hip_t* r, const char* modeldir);
 int rife_hip_process(const rife_hip_t* r, const uint8_t* in0_rgb, const uint8_t* in1_rgb, int w, int h,
                      float timestep, uint8_t* out_rgb);
 
+/* Optional throughput entry point: n independent pairs from host memory in one call, spread over internal
+ * streams so that the copies of one pair overlap the kernels of the others - what the reference gets from its proc threads
+ * (src/main.cpp:849-866).  Same pixels as n rife_hip_process() calls; timestep 0 / 1 entries are copies. */
+int rife_hip_process_batch(const rife_hip_t* r, int n, const uint8_t* const* in0_rgb, const uint8_t* const* in1_rgb, const float* timestep,
+                           uint8_t* const* out_rgb, int w, int h);
+
 /* Same, with all three frames already resident in device memory (what ncnn's VkMat path does internally between
  * record_clone and submit, src/rife.cpp:2522-2530,3176-3186).  Work is enqueued on `hip_stream` (a hipStream_t;
  * NULL = the engine's own stream) and the call returns without synchronising when a stream is given. */

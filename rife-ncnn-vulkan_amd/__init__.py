@@ -22,7 +22,7 @@ _lib = None
 # every symbol include/rife_hip.h declares
 C_ABI_SYMBOLS = [
     "rife_hip_device_count", "rife_hip_create", "rife_hip_destroy", "rife_hip_load", "rife_hip_process",
-    "rife_hip_process_device", "rife_hip_last_error", "rife_hip_profile_enable", "rife_hip_profile_read",
+    "rife_hip_process_device", "rife_hip_process_batch", "rife_hip_last_error", "rife_hip_profile_enable", "rife_hip_profile_read",
     "rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_graph_check", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
 ]
 
@@ -66,6 +66,7 @@ def lib():
     L.rife_hip_v4_extract_flow.argtypes = [vp, vp, vp, ci, ci, cf, ci, vp, ci, vp]
     L.rife_hip_v4_flow_dims.argtypes = [vp, ci, ci, ci, vp, vp, vp]
     L.rife_hip_graph_check.argtypes = [ctypes.c_char_p]
+    L.rife_hip_process_batch.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci]
     L.rife_hip_op_conv3x3.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, ci, vp, vp, vp]
     L.rife_hip_op_deconv4x4.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, vp, vp]
     L.rife_hip_op_warp.argtypes = [ci, vp, vp, ci, ci, ci, vp]
@@ -132,6 +133,27 @@ class RIFE:
         _check(lib().rife_hip_process_device(self._h, d_in0, d_in1, w, h, float(timestep), d_out, stream), "process_device")
 
     # ---- measurement / parity taps ----
+    def process_batch(self, in0images, in1images, timesteps, outimages=None):
+        """n independent pairs in one call (rife_hip_process_batch); returns the list of interpolated frames
+        (`outimages`: optional preallocated (h, w, 3) uint8 arrays to write into)."""
+        a = [np.ascontiguousarray(x, dtype=np.uint8) for x in in0images]
+        b = [np.ascontiguousarray(x, dtype=np.uint8) for x in in1images]
+        n = len(a)
+        if n == 0:
+            return []
+        h, w, _ = a[0].shape
+        if any(x.shape != (h, w, 3) for x in a + b) or len(b) != n or len(timesteps) != n:
+            raise ValueError("all frames of a batch must share one size, and there must be one timestep per pair")
+        outs = list(outimages) if outimages is not None else [np.empty((h, w, 3), np.uint8) for _ in range(n)]
+        if len(outs) != n or any(o.shape != (h, w, 3) or o.dtype != np.uint8 or not o.flags.c_contiguous for o in outs):
+            raise ValueError("outimages must be n contiguous (h, w, 3) uint8 arrays")
+        pa = (ctypes.c_void_p * n)(*[x.ctypes.data for x in a])
+        pb = (ctypes.c_void_p * n)(*[x.ctypes.data for x in b])
+        po = (ctypes.c_void_p * n)(*[x.ctypes.data for x in outs])
+        ts = (ctypes.c_float * n)(*[float(t) for t in timesteps])
+        _check(lib().rife_hip_process_batch(self._h, n, pa, pb, ts, po, w, h), "process_batch")
+        return outs
+
     def profile_enable(self, on=True):
         _check(lib().rife_hip_profile_enable(self._h, int(on)), "profile_enable")
 

@@ -17,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rife_hip.h"
@@ -1715,6 +1716,47 @@ static int process_common(const rife_hip* E, int w, int h, float timestep) {
     return 0;
 }
 
+// lease a workspace (+ its private stream) from the pool of the host-buffer entry points
+static int lease_ctx(const rife_hip* E, std::unique_ptr<Ctx>& c, int w, int h) {
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        if (!E->free_ctx.empty()) { c = std::move(E->free_ctx.back()); E->free_ctx.pop_back(); }
+    }
+    if (!c) {
+        c.reset(new Ctx);
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
+        c->own_stream = true;
+    }
+    return E->v4 ? ensure_ctx(*c, w, h) : E->v1 ? ensure_ctx_v1(*c, w, h, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1)
+                                                : ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1, E->v3);
+}
+
+static void release_ctx(const rife_hip* E, std::unique_ptr<Ctx>& c) {
+    std::lock_guard<std::mutex> g(E->mu);
+    E->free_ctx.push_back(std::move(c));
+}
+
+// H2D of both frames, the whole pass and the D2H of the result, all enqueued on the workspace's stream (no host wait)
+static int enqueue_host_pair(const rife_hip* E, Ctx& c, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, uint8_t* out) {
+    const size_t nbytes = (size_t)w * h * 3;
+    hipError_t e = hipMemcpyAsync(c.d_in0, in0, nbytes, hipMemcpyHostToDevice, c.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c.d_in1, in1, nbytes, hipMemcpyHostToDevice, c.stream);
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("H2D: ") + hipGetErrorString(e));
+    int rc;
+    if (E->v1) rc = run_v1(*E, c, c.d_in0, c.d_in1, c.d_out);
+    else if (!E->v4) rc = run_v2(*E, c, c.d_in0, c.d_in1, c.d_out);
+    else if (E->tta || E->tta_temporal) {
+        // the TTA workspaces are shared by all callers: serialise, and drain before the next caller may reuse them
+        std::lock_guard<std::mutex> g(E->tta_mu);
+        rc = run_v4_tta(*E, c.stream, c.d_in0, c.d_in1, w, h, timestep, c.d_out);
+        if (!rc && hipStreamSynchronize(c.stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "TTA stream sync failed");
+    } else rc = run_v4_replay(*E, c, c.d_in0, c.d_in1, timestep, c.d_out);
+    if (rc) return rc;
+    e = hipMemcpyAsync(out, c.d_out, nbytes, hipMemcpyDeviceToHost, c.stream);
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("D2H: ") + hipGetErrorString(e));
+    return 0;
+}
+
 int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, uint8_t* out) {
     int rc;
     if ((rc = process_common(E, w, h, timestep))) return rc;
@@ -1725,42 +1767,41 @@ int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1
     if (timestep == 1.f) { std::memmove(out, in1, nbytes); return 0; }
     if ((rc = check_device(E->gpuid))) return rc;
     std::unique_ptr<Ctx> c;
-    {
-        std::lock_guard<std::mutex> g(E->mu);
-        if (!E->free_ctx.empty()) { c = std::move(E->free_ctx.back()); E->free_ctx.pop_back(); }
-    }
-    if (!c) {
-        c.reset(new Ctx);
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
-        c->own_stream = true;
-    }
-    rc = E->v4 ? ensure_ctx(*c, w, h) : E->v1 ? ensure_ctx_v1(*c, w, h, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1)
-                                              : ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1, E->v3);
-    if (!rc) {
-        hipError_t e = hipMemcpyAsync(c->d_in0, in0, nbytes, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->d_in1, in1, nbytes, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) rc = fail(RIFE_HIP_EHIP, std::string("H2D: ") + hipGetErrorString(e));
-    }
-    if (!rc) {
-        if (E->v1) rc = run_v1(*E, *c, c->d_in0, c->d_in1, c->d_out);
-        else if (!E->v4) rc = run_v2(*E, *c, c->d_in0, c->d_in1, c->d_out);
-        else if (E->tta || E->tta_temporal) {
-            // the TTA workspaces are shared by all callers: serialise, and drain before the next caller may reuse them
-            std::lock_guard<std::mutex> g(E->tta_mu);
-            rc = run_v4_tta(*E, c->stream, c->d_in0, c->d_in1, w, h, timestep, c->d_out);
-            if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "TTA stream sync failed");
-        } else rc = run_v4_replay(*E, *c, c->d_in0, c->d_in1, timestep, c->d_out);
-    }
-    if (!rc) {
-        hipError_t e = hipMemcpyAsync(out, c->d_out, nbytes, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(RIFE_HIP_EHIP, std::string("D2H/sync: ") + hipGetErrorString(e));
-    }
-    {
-        std::lock_guard<std::mutex> g(E->mu);
-        E->free_ctx.push_back(std::move(c));
-    }
+    rc = lease_ctx(E, c, w, h);
+    if (!rc) rc = enqueue_host_pair(E, *c, in0, in1, w, h, timestep, out);
+    if (c && hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(RIFE_HIP_EHIP, "stream sync failed");
+    if (c) release_ctx(E, c);
     return rc;
+}
+
+// n independent frame pairs from host memory in one call.  Copies from / to pageable host memory block the thread that issues
+// them, so overlap of one pair's copies with another pair's kernels needs several host threads - the reference's proc threads
+// (src/main.cpp:849-866).  The batch call brings its own: 2 workers (the reference default), each a plain rife_hip_process() loop over its share of
+// the pairs (every call leases its own workspace + stream).  Same pixels as n rife_hip_process() calls.
+int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0, const uint8_t* const* in1, const float* timestep,
+                           uint8_t* const* out, int w, int h) {
+    int rc;
+    if (n < 0 || (n > 0 && (!in0 || !in1 || !timestep || !out))) return fail(RIFE_HIP_EINVAL, "bad batch arguments");
+    if ((rc = process_common(E, w, h, 0.5f))) return rc;
+    for (int i = 0; i < n; i++) if (!in0[i] || !in1[i] || !out[i]) return fail(RIFE_HIP_EINVAL, "null frame pointer");
+    if (n == 0) return 0;
+    if ((rc = check_device(E->gpuid))) return rc;
+    const int K = std::min(n, 2);                          // measured on MI355X + EPYC 9575F: 2 workers beat 1 and 3 (pageable copies contend)
+    std::vector<int> rcs(K, 0);
+    std::vector<std::string> errs(K);
+    auto worker = [&](int k) {
+        (void)hipSetDevice(E->gpuid);
+        for (int i = k; i < n; i += K) {
+            const int r = rife_hip_process(E, in0[i], in1[i], w, h, timestep[i], out[i]);
+            if (r) { rcs[k] = r; errs[k] = g_err; return; }     // g_err is thread-local: carry it back to the caller
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < K; k++) th.emplace_back(worker, k);
+    worker(0);
+    for (auto& t : th) t.join();
+    for (int k = 0; k < K; k++) if (rcs[k]) { g_err = errs[k]; return rcs[k]; }
+    return 0;
 }
 
 int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* d_in1, int w, int h, float timestep, void* d_out, void* hip_stream) {

@@ -164,3 +164,15 @@ def test_4k_within_1_lsb(engines):
     mx, f0, f1, psnr = lsb_report(g.process(a, b, 0.5), o.process(a, b, 0.5))
     assert mx <= 1, (mx, f0, f1, psnr)
     assert f0 > 0.97
+
+
+def test_process_batch_equals_single_calls(engines):
+    """rife_hip_process_batch: n pairs over internal streams give the same pixels as n process() calls (incl. timestep 0 / 1 copies)."""
+    g, _ = engines
+    frames = [gen_frames.smooth_pair(160, 96, 70 + i)[0] for i in range(6)]
+    ts = [0.5, 0.25, 0.0, 0.7, 1.0]
+    want = [g.process(frames[i], frames[i + 1], ts[i]) for i in range(5)]
+    got = g.process_batch(frames[:5], frames[1:6], ts)
+    for i in range(5):
+        assert np.array_equal(got[i], want[i]), i
+    assert g.process_batch([], [], []) == []
