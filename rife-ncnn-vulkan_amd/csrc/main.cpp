@@ -1,0 +1,435 @@
+// rife-hip — the reference's command line (src/main.cpp:102-121 usage, 442-917 main) on top of `class RIFE` (rife.h):
+//
+//     rife-hip -0 in0.png -1 in1.png -o out.png [options]
+//     rife-hip -i indir -o outdir [options]
+//
+// Same flags, defaults, validation order and messages, frame / timestep schedule (src/main.cpp:705-731) and three-stage
+// pipeline (load -> proc -> save over bounded queues, one RIFE per -g id, -j load:proc[,proc..]:save; src/main.cpp:248-436,
+// 819-904), re-hosted on std::thread.  Codecs: this build links nothing but zlib, so it reads and writes PNG (8-bit, non-interlaced)
+// and binary PPM; jpg / webp paths are rejected with a message (the Python front end, cli.py, covers them through PIL).
+// Host glue only: every pixel of arithmetic happens in librife_hip.so.
+#include <dirent.h>
+#include <getopt.h>
+#include <sys/stat.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rife_hip.h"
+#include "rife.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// image files: PNG (zlib) and PPM (P6)
+// ---------------------------------------------------------------------------------------------------------------
+static bool read_file(const std::string& path, std::vector<unsigned char>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    const bool ok = n >= 0 && fread(out.data(), 1, out.size(), f) == out.size();
+    fclose(f);
+    return ok;
+}
+
+static uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+static int paeth(int a, int b, int c) {
+    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// 8-bit, non-interlaced PNG of colour type gray / RGB / palette / gray+alpha / RGBA -> tightly packed RGB
+static bool decode_png(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgb) {
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (d.size() < 33 || memcmp(d.data(), sig, 8)) return false;
+    size_t pos = 8;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<unsigned char> idat, pal;
+    while (pos + 12 <= d.size()) {
+        const uint32_t len = be32(&d[pos]);
+        const unsigned char* typ = &d[pos + 4];
+        if (pos + 12 + (size_t)len > d.size()) return false;
+        const unsigned char* body = &d[pos + 8];
+        if (!memcmp(typ, "IHDR", 4)) { w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        else if (!memcmp(typ, "PLTE", 4)) pal.assign(body, body + len);
+        else if (!memcmp(typ, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+        else if (!memcmp(typ, "IEND", 4)) break;
+        pos += 12 + (size_t)len;
+    }
+    if (w <= 0 || h <= 0 || depth != 8 || interlace != 0) return false;
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch || (ctype == 3 && pal.empty())) return false;
+    const size_t stride = (size_t)w * ch;
+    std::vector<unsigned char> raw((stride + 1) * h);
+    uLongf rawlen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;
+    std::vector<unsigned char> img(stride * h);
+    for (int y = 0; y < h; y++) {
+        const unsigned char* src = &raw[(stride + 1) * y];
+        unsigned char* cur = &img[stride * y];
+        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
+        const int ft = src[0];
+        for (size_t x = 0; x < stride; x++) {
+            const int a = x >= (size_t)ch ? cur[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+            int v = src[1 + x];
+            switch (ft) {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: v += paeth(a, b, c); break;
+                default: return false;
+            }
+            cur[x] = (unsigned char)v;
+        }
+    }
+    rgb.resize((size_t)w * h * 3);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        const unsigned char* p = &img[i * ch];
+        unsigned char* o = &rgb[i * 3];
+        if (ctype == 2 || ctype == 6) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+        else if (ctype == 0 || ctype == 4) { o[0] = o[1] = o[2] = p[0]; }
+        else {
+            const size_t k = (size_t)p[0] * 3;
+            if (k + 2 >= pal.size()) return false;
+            o[0] = pal[k]; o[1] = pal[k + 1]; o[2] = pal[k + 2];
+        }
+    }
+    return true;
+}
+
+static void put_chunk(std::vector<unsigned char>& out, const char* typ, const unsigned char* body, size_t len) {
+    const unsigned char l[4] = {(unsigned char)(len >> 24), (unsigned char)(len >> 16), (unsigned char)(len >> 8), (unsigned char)len};
+    out.insert(out.end(), l, l + 4);
+    const size_t start = out.size();
+    out.insert(out.end(), typ, typ + 4);
+    if (len) out.insert(out.end(), body, body + len);
+    const uint32_t crc = (uint32_t)crc32(0L, &out[start], (uInt)(len + 4));
+    const unsigned char c[4] = {(unsigned char)(crc >> 24), (unsigned char)(crc >> 16), (unsigned char)(crc >> 8), (unsigned char)crc};
+    out.insert(out.end(), c, c + 4);
+}
+
+static bool encode_png(const std::string& path, int w, int h, const unsigned char* rgb) {
+    const size_t stride = (size_t)w * 3;
+    std::vector<unsigned char> raw((stride + 1) * h);
+    for (int y = 0; y < h; y++) {              // filter "up": cheap and effective on video frames
+        unsigned char* dst = &raw[(stride + 1) * y];
+        const unsigned char* cur = rgb + stride * y;
+        const unsigned char* up = y ? rgb + stride * (y - 1) : nullptr;
+        dst[0] = up ? 2 : 0;
+        for (size_t x = 0; x < stride; x++) dst[1 + x] = (unsigned char)(cur[x] - (up ? up[x] : 0));
+    }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<unsigned char> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 3) != Z_OK) return false;
+    std::vector<unsigned char> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    unsigned char ihdr[13] = {(unsigned char)(w >> 24), (unsigned char)(w >> 16), (unsigned char)(w >> 8), (unsigned char)w,
+                              (unsigned char)(h >> 24), (unsigned char)(h >> 16), (unsigned char)(h >> 8), (unsigned char)h, 8, 2, 0, 0, 0};
+    put_chunk(out, "IHDR", ihdr, 13);
+    put_chunk(out, "IDAT", comp.data(), clen);
+    put_chunk(out, "IEND", nullptr, 0);
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    fclose(f);
+    return ok;
+}
+
+static bool decode_ppm(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgb) {
+    if (d.size() < 7 || d[0] != 'P' || d[1] != '6') return false;
+    size_t pos = 2;
+    int vals[3], n = 0;
+    while (n < 3 && pos < d.size()) {
+        while (pos < d.size() && (isspace(d[pos]) || d[pos] == '#')) { if (d[pos] == '#') while (pos < d.size() && d[pos] != '\n') pos++; else pos++; }
+        int v = 0; bool any = false;
+        while (pos < d.size() && isdigit(d[pos])) { v = v * 10 + (d[pos] - '0'); pos++; any = true; }
+        if (!any) return false;
+        vals[n++] = v;
+    }
+    if (n != 3 || vals[2] != 255 || pos >= d.size()) return false;
+    pos++;                                       // the single whitespace after maxval
+    w = vals[0]; h = vals[1];
+    if (w <= 0 || h <= 0 || d.size() - pos < (size_t)w * h * 3) return false;
+    rgb.assign(d.begin() + pos, d.begin() + pos + (size_t)w * h * 3);
+    return true;
+}
+
+static bool encode_ppm(const std::string& path, int w, int h, const unsigned char* rgb) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "P6\n%d %d\n255\n", w, h);
+    const bool ok = fwrite(rgb, 1, (size_t)w * h * 3, f) == (size_t)w * h * 3;
+    fclose(f);
+    return ok;
+}
+
+static std::string ext_of(const std::string& p) {
+    const size_t dot = p.rfind('.');
+    if (dot == std::string::npos || p.find('/', dot) != std::string::npos) return "";
+    std::string e = p.substr(dot + 1);
+    std::transform(e.begin(), e.end(), e.begin(), ::tolower);
+    return e;
+}
+
+static bool decode_image(const std::string& path, int& w, int& h, std::vector<unsigned char>& rgb) {
+    std::vector<unsigned char> d;
+    if (!read_file(path, d)) return false;
+    if (decode_png(d, w, h, rgb) || decode_ppm(d, w, h, rgb)) return true;
+    const std::string e = ext_of(path);
+    if (e == "jpg" || e == "jpeg" || e == "webp") fprintf(stderr, "%s: jpg / webp decoding is not built into rife-hip (png and ppm are); use cli.py\n", path.c_str());
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tasks and queues (src/main.cpp:231-295)
+// ---------------------------------------------------------------------------------------------------------------
+struct Task {
+    int id = 0;
+    float timestep = 0.5f;
+    std::string in0path, in1path, outpath;
+    std::vector<unsigned char> px0, px1, out;
+    int w = 0, h = 0;
+};
+
+class TaskQueue {
+public:
+    void put(Task&& t) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return q.size() < 8; });          // bounded at 8 like the reference (main.cpp:260)
+        q.push(std::move(t));
+        cv.notify_all();
+    }
+    Task get() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !q.empty(); });
+        Task t = std::move(q.front());
+        q.pop();
+        cv.notify_all();
+        return t;
+    }
+private:
+    std::mutex mu;
+    std::condition_variable cv;
+    std::queue<Task> q;
+};
+
+static void print_usage() {
+    fprintf(stderr, "Usage: rife-hip -0 infile -1 infile1 -o outfile [options]...\n");
+    fprintf(stderr, "       rife-hip -i indir -o outdir [options]...\n\n");
+    fprintf(stderr, "  -h                   show this help\n");
+    fprintf(stderr, "  -v                   verbose output\n");
+    fprintf(stderr, "  -0 input0-path       input image0 path (png/ppm)\n");
+    fprintf(stderr, "  -1 input1-path       input image1 path (png/ppm)\n");
+    fprintf(stderr, "  -i input-path        input image directory (png/ppm)\n");
+    fprintf(stderr, "  -o output-path       output image path (png/ppm) or directory\n");
+    fprintf(stderr, "  -n num-frame         target frame count (default=N*2)\n");
+    fprintf(stderr, "  -s time-step         time step (0~1, default=0.5)\n");
+    fprintf(stderr, "  -m model-path        rife model path (default=rife-v2.3)\n");
+    fprintf(stderr, "  -g gpu-id            gpu device to use (default=0) can be 0,1,2 for multi-gpu\n");
+    fprintf(stderr, "  -j load:proc:save    thread count for load/proc/save (default=1:2:2) can be 1:2,2,2:2 for multi-gpu\n");
+    fprintf(stderr, "  -x                   enable spatial tta mode\n");
+    fprintf(stderr, "  -z                   enable temporal tta mode\n");
+    fprintf(stderr, "  -u                   enable UHD mode\n");
+    fprintf(stderr, "  -f pattern-format    output image filename pattern format (%%08d.png/ppm, default=ext/%%08d.png)\n");
+}
+
+static bool is_dir(const std::string& p) { struct stat s; return stat(p.c_str(), &s) == 0 && S_ISDIR(s.st_mode); }
+
+static bool list_directory(const std::string& d, std::vector<std::string>& names) {
+    DIR* dir = opendir(d.c_str());
+    if (!dir) return false;
+    while (struct dirent* e = readdir(dir)) {
+        const std::string full = d + "/" + e->d_name;
+        struct stat s;
+        if (stat(full.c_str(), &s) == 0 && S_ISREG(s.st_mode)) names.push_back(e->d_name);
+    }
+    closedir(dir);
+    std::sort(names.begin(), names.end());
+    return true;
+}
+
+static std::vector<int> parse_int_list(const std::string& s) {
+    std::vector<int> v;
+    size_t pos = 0;
+    while (pos <= s.size()) {
+        const size_t c = s.find(',', pos);
+        const std::string tok = s.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+        v.push_back(atoi(tok.c_str()));
+        if (c == std::string::npos) break;
+        pos = c + 1;
+    }
+    return v;
+}
+
+int main(int argc, char** argv) {
+    std::string input0, input1, inputpath, outputpath, model = "rife-v2.3", pattern_format = "%08d.png";
+    int numframe = 0;
+    float timestep = 0.5f;
+    std::vector<int> gpuid, jobs_proc;
+    int jobs_load = 1, jobs_save = 2;
+    bool verbose = false, tta = false, tta_temporal = false, uhd = false;
+
+    int opt;
+    while ((opt = getopt(argc, argv, "0:1:i:o:n:s:m:g:j:f:vxzuh")) != -1) {
+        switch (opt) {
+            case '0': input0 = optarg; break;
+            case '1': input1 = optarg; break;
+            case 'i': inputpath = optarg; break;
+            case 'o': outputpath = optarg; break;
+            case 'n': numframe = atoi(optarg); break;
+            case 's': timestep = (float)atof(optarg); break;
+            case 'm': model = optarg; break;
+            case 'g': gpuid = parse_int_list(optarg); break;
+            case 'j': {
+                const std::string a = optarg;
+                const size_t c1 = a.find(':'), c2 = a.rfind(':');
+                if (c1 == std::string::npos || c1 == c2) { fprintf(stderr, "invalid thread count argument\n"); return -1; }
+                jobs_load = atoi(a.substr(0, c1).c_str());
+                jobs_proc = parse_int_list(a.substr(c1 + 1, c2 - c1 - 1));
+                jobs_save = atoi(a.substr(c2 + 1).c_str());
+                break;
+            }
+            case 'f': pattern_format = optarg; break;
+            case 'v': verbose = true; break;
+            case 'x': tta = true; break;
+            case 'z': tta_temporal = true; break;
+            case 'u': uhd = true; break;
+            case 'h':
+            default: print_usage(); return -1;
+        }
+    }
+
+    // ---- validation, in the reference's order (src/main.cpp:575-689) ----
+    if (((input0.empty() || input1.empty()) && inputpath.empty()) || outputpath.empty()) { print_usage(); return -1; }
+    if (inputpath.empty() && (timestep <= 0.f || timestep >= 1.f)) { fprintf(stderr, "invalid timestep argument, must be 0~1\n"); return -1; }
+    if (!inputpath.empty() && numframe < 0) { fprintf(stderr, "invalid numframe argument, must not be negative\n"); return -1; }
+    if (jobs_load < 1 || jobs_save < 1) { fprintf(stderr, "invalid thread count argument\n"); return -1; }
+    if (!jobs_proc.empty() && jobs_proc.size() != (gpuid.empty() ? 1 : gpuid.size())) { fprintf(stderr, "invalid jobs_proc thread count argument\n"); return -1; }
+    for (int j : jobs_proc) if (j < 1) { fprintf(stderr, "invalid jobs_proc thread count argument\n"); return -1; }
+
+    std::string pattern = pattern_format, format;
+    {
+        const size_t dot = pattern_format.rfind('.');
+        if (dot != std::string::npos) { pattern = pattern_format.substr(0, dot); format = pattern_format.substr(dot + 1); }
+        else { pattern = "%08d"; format = pattern_format; }
+        if (pattern.empty()) pattern = "%08d";
+    }
+    if (!is_dir(outputpath)) {
+        const std::string e = ext_of(outputpath);
+        if (e == "png") format = "png";
+        else if (e == "ppm") format = "ppm";
+        else if (e == "webp" || e == "jpg" || e == "jpeg") { fprintf(stderr, "jpg / webp encoding is not built into rife-hip (png and ppm are); use cli.py\n"); return -1; }
+        else { fprintf(stderr, "invalid outputpath extension type\n"); return -1; }
+    }
+    if (format != "png" && format != "ppm") { fprintf(stderr, "invalid format argument\n"); return -1; }
+
+    bool rife_v2 = false, rife_v4 = false;      // family from the directory name (src/main.cpp:658-683)
+    if (model.find("rife-v2") != std::string::npos || model.find("rife-v3") != std::string::npos) rife_v2 = true;
+    else if (model.find("rife-v4") != std::string::npos) rife_v4 = true;
+    else if (model.find("rife") == std::string::npos) { fprintf(stderr, "unknown model dir type\n"); return -1; }
+    if (!rife_v4 && (numframe != 0 || timestep != 0.5f)) { fprintf(stderr, "only rife-v4 model support custom numframe and timestep\n"); return -1; }
+
+    // ---- task list (src/main.cpp:692-766) ----
+    std::vector<Task> tasks;
+    if (!inputpath.empty() && is_dir(inputpath) && is_dir(outputpath)) {
+        std::vector<std::string> names;
+        if (!list_directory(inputpath, names) || names.size() < 2) return -1;
+        const int count = (int)names.size();
+        if (numframe == 0) numframe = count * 2;
+        const double scale = (double)count / numframe;                          // double product rounded to float, like src/main.cpp:713-718
+        for (int i = 0; i < numframe; i++) {
+            float fx = (float)(i * scale);
+            int sx = (int)std::floor(fx);
+            fx -= sx;
+            if (sx < 0) { sx = 0; fx = 0.f; }
+            if (sx >= count - 1) { sx = count - 2; fx = 1.f; }
+            char name[512];
+            snprintf(name, sizeof name, pattern.c_str(), i + 1);               // ffmpeg numbering starts at 1
+            Task t;
+            t.id = i; t.timestep = fx;
+            t.in0path = inputpath + "/" + names[sx]; t.in1path = inputpath + "/" + names[sx + 1];
+            t.outpath = outputpath + "/" + name + "." + format;
+            tasks.push_back(std::move(t));
+        }
+    } else if (inputpath.empty() && !is_dir(input0) && !is_dir(input1) && !is_dir(outputpath)) {
+        Task t;
+        t.timestep = timestep; t.in0path = input0; t.in1path = input1; t.outpath = outputpath;
+        tasks.push_back(std::move(t));
+    } else {
+        fprintf(stderr, "input0path, input1path and outputpath must be file at the same time\n");
+        fprintf(stderr, "inputpath and outputpath must be directory at the same time\n");
+        return -1;
+    }
+
+    // ---- devices (src/main.cpp:774-828) ----
+    if (gpuid.empty()) gpuid.push_back(0);
+    if (jobs_proc.empty()) jobs_proc.assign(gpuid.size(), 2);
+    const int ndev = rife_hip_device_count();
+    for (int g : gpuid) if (g < 0 || g >= ndev) { fprintf(stderr, "invalid gpu device\n"); return -1; }
+    std::vector<RIFE*> rife;
+    for (int g : gpuid) {
+        RIFE* r = new RIFE(g, tta, tta_temporal, uhd, 1, rife_v2, rife_v4);
+        if (r->load(model) != 0) { fprintf(stderr, "loading %s failed: %s\n", model.c_str(), rife_hip_last_error()); return -1; }
+        rife.push_back(r);
+    }
+
+    // ---- load -> proc -> save (src/main.cpp:309-436, 830-904) ----
+    TaskQueue toproc, tosave;
+    std::mutex next_mu;
+    size_t next_task = 0;
+    auto load = [&]() {
+        for (;;) {
+            size_t k;
+            { std::lock_guard<std::mutex> g(next_mu); if (next_task >= tasks.size()) return; k = next_task++; }
+            Task t = std::move(tasks[k]);
+            int w1 = 0, h1 = 0;
+            if (!decode_image(t.in0path, t.w, t.h, t.px0) || !decode_image(t.in1path, w1, h1, t.px1)) { fprintf(stderr, "decode image %s or %s failed\n", t.in0path.c_str(), t.in1path.c_str()); continue; }
+            if (w1 != t.w || h1 != t.h) { fprintf(stderr, "%s and %s differ in size\n", t.in0path.c_str(), t.in1path.c_str()); continue; }
+            toproc.put(std::move(t));
+        }
+    };
+    auto proc = [&](RIFE* r) {
+        for (;;) {
+            Task t = toproc.get();
+            if (t.id == -233) return;                                          // end marker, like the reference
+            ncnn::Mat in0(t.w, t.h, (void*)t.px0.data(), (size_t)3, 3), in1(t.w, t.h, (void*)t.px1.data(), (size_t)3, 3);
+            ncnn::Mat out(t.w, t.h, (size_t)3, 3);
+            if (r->process(in0, in1, t.timestep, out) != 0) { fprintf(stderr, "process %s failed: %s\n", t.outpath.c_str(), rife_hip_last_error()); continue; }
+            t.out.assign((const unsigned char*)out.data, (const unsigned char*)out.data + (size_t)t.w * t.h * 3);
+            tosave.put(std::move(t));
+        }
+    };
+    auto save = [&]() {
+        for (;;) {
+            Task t = tosave.get();
+            if (t.id == -233) return;
+            const bool ok = ext_of(t.outpath) == "ppm" ? encode_ppm(t.outpath, t.w, t.h, t.out.data()) : encode_png(t.outpath, t.w, t.h, t.out.data());
+            if (!ok) fprintf(stderr, "encode image %s failed\n", t.outpath.c_str());
+            else if (verbose) fprintf(stderr, "%s %s %f -> %s done\n", t.in0path.c_str(), t.in1path.c_str(), t.timestep, t.outpath.c_str());
+        }
+    };
+    std::vector<std::thread> loaders, procs, savers;
+    for (int i = 0; i < jobs_load; i++) loaders.emplace_back(load);
+    for (size_t d = 0; d < gpuid.size(); d++) for (int i = 0; i < jobs_proc[d]; i++) procs.emplace_back(proc, rife[d]);
+    for (int i = 0; i < jobs_save; i++) savers.emplace_back(save);
+    for (auto& t : loaders) t.join();
+    for (size_t i = 0; i < procs.size(); i++) { Task e; e.id = -233; toproc.put(std::move(e)); }
+    for (auto& t : procs) t.join();
+    for (size_t i = 0; i < savers.size(); i++) { Task e; e.id = -233; tosave.put(std::move(e)); }
+    for (auto& t : savers) t.join();
+    for (RIFE* r : rife) delete r;
+    return 0;
+}

@@ -76,3 +76,57 @@ def test_cli_file_mode(modeldirs, tmp_path):
     assert cli.main(["-0", str(tmp_path / "a.png"), "-1", str(tmp_path / "b.png"), "-o", str(tmp_path / "o.png"), "-m", modeldirs["rife-v2.3"]]) == 0
     g = amd.RIFE(0, rife_v2=True); g.load(modeldirs["rife-v2.3"])
     assert np.array_equal(np.asarray(Image.open(tmp_path / "o.png").convert("RGB")), g.process(a, b, 0.5))
+
+
+# ---- the C++ command line (rife-ncnn-vulkan_amd/rife-hip, csrc/main.cpp) ----
+RIFE_HIP = os.path.join(ROOT, "rife-ncnn-vulkan_amd", "rife-hip")
+
+
+def run_cpp(args):
+    import subprocess
+    p = subprocess.run([RIFE_HIP] + args, capture_output=True, text=True)
+    return p.returncode, p.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(RIFE_HIP), reason="rife-hip is not built")
+def test_cpp_cli_validation_matches_the_reference_messages():
+    rc, err = run_cpp([])
+    assert rc == 255 and "Usage:" in err
+    rc, err = run_cpp(["-0", "a.png", "-1", "b.png", "-o", "o.png", "-s", "1.5", "-m", "rife-v4.6"])
+    assert rc == 255 and "invalid timestep argument, must be 0~1" in err
+    rc, err = run_cpp(["-0", "a.png", "-1", "b.png", "-o", "o.bmp", "-m", "rife-v4.6"])
+    assert rc == 255 and "invalid outputpath extension type" in err
+    rc, err = run_cpp(["-0", "a.png", "-1", "b.png", "-o", "o.png", "-s", "0.3", "-m", "rife-v2.3"])
+    assert rc == 255 and "only rife-v4 model support custom numframe and timestep" in err
+    rc, err = run_cpp(["-0", "a.png", "-1", "b.png", "-o", "o.png", "-m", "nonsense"])
+    assert rc == 255 and "unknown model dir type" in err
+    rc, err = run_cpp(["-0", "a.png", "-1", "b.png", "-o", "o.png", "-j", "1:2,2:2", "-m", "rife-v4.6"])
+    assert rc == 255 and "invalid jobs_proc thread count argument" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(RIFE_HIP), reason="rife-hip is not built")
+def test_cpp_cli_directory_and_file_modes(modeldirs, tmp_path):
+    """PNG in (written by PIL, adaptive filters) -> rife-hip -> PNG out (read back by PIL) equals the engine's own output."""
+    from PIL import Image
+    from tools import gen_frames
+    amd = importlib.import_module("rife-ncnn-vulkan_amd")
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir(); outd.mkdir()
+    frames = [gen_frames.smooth_pair(100, 60, 5)[0], gen_frames.smooth_pair(100, 60, 5)[1], gen_frames.smooth_pair(100, 60, 6)[0]]
+    for i, f in enumerate(frames):
+        Image.fromarray(f).save(ind / ("%03d.png" % i))
+    model = modeldirs["rife-v4.6"]
+    rc, err = run_cpp(["-i", str(ind), "-o", str(outd), "-m", model, "-n", "5", "-j", "1:2:2", "-g", "0", "-v"])
+    assert rc == 0, err
+    assert sorted(os.listdir(outd)) == ["%08d.png" % i for i in range(1, 6)]
+    g = amd.RIFE(0, rife_v4=True); g.load(model)
+    for i, (sx, fx) in enumerate(cli.build_schedule(3, 5)):
+        got = np.asarray(Image.open(outd / ("%08d.png" % (i + 1))).convert("RGB"))
+        assert np.array_equal(got, g.process(frames[sx], frames[sx + 1], fx)), i
+    # file mode with a ppm output and an RGBA + a palette input
+    Image.fromarray(frames[0]).convert("RGBA").save(tmp_path / "a.png")
+    Image.fromarray(frames[1]).save(tmp_path / "b.png")
+    rc, err = run_cpp(["-0", str(tmp_path / "a.png"), "-1", str(tmp_path / "b.png"), "-o", str(tmp_path / "o.ppm"), "-m", model, "-s", "0.25"])
+    assert rc == 0, err
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "o.ppm").convert("RGB")), g.process(frames[0], frames[1], 0.25))
