@@ -535,8 +535,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef H2_WRITE
 #undef H2_TAPS
 
+    // epilogue: like conv_h2b_kernel, the wave's 32 x NT tile goes through LDS (both staging buffers are free after the last
+    // barrier of the K loop) so that consecutive lanes store consecutive 16-byte chunks of a pixel; direct stores otherwise
     const int oy = oy0 + wv, ox = ox0 + li;
     const bool pok = oy < a.Ho && ox < a.Wo;
+    constexpr int ROWF = NT + 4;
+    const bool via_lds = a.res == nullptr && a.out_ld == NT && a.Cout == NT && a.nz == 1;
+    float* const tl = reinterpret_cast<float*>(ldsb) + wv * 32 * ROWF;
 #pragma unroll
     for (int n = 0; n < NS; n++) {
 #pragma unroll
@@ -555,8 +560,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k];
-            if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
+            if (via_lds) *reinterpret_cast<f32x4*>(tl + li * ROWF + n * 32 + 8 * q + 4 * half) = v;
+            else if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
         }
+    }
+    if (via_lds) {
+        // 8 lanes per pixel and 32-channel sub-tile: every store instruction writes eight full 128-byte segments
+        const int pl = lane >> 3, chunk = lane & 7;
+        float* const orow = a.out + ((size_t)oy * a.Wo + ox0) * a.out_ld + a.out_coff;
+#pragma unroll
+        for (int n = 0; n < NS; n++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int px = j * 8 + pl;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tl + px * ROWF + n * 32 + chunk * 4);
+                if (oy < a.Ho && ox0 + px < a.Wo) *reinterpret_cast<f32x4*>(orow + (size_t)px * a.out_ld + n * 32 + chunk * 4) = v;
+            }
     }
 }
 
