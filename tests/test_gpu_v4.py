@@ -176,3 +176,12 @@ def test_process_batch_equals_single_calls(engines):
     for i in range(5):
         assert np.array_equal(got[i], want[i]), i
     assert g.process_batch([], [], []) == []
+
+
+def test_8k_within_1_lsb(engines):
+    """Maximum-size case: 7680x4320 (4x the pixels of the north-star frame; ~6.5 GB of workspace)."""
+    g, o = engines
+    base = gen_frames.smooth_pair(1920, 1080, 8)
+    a, b = [np.ascontiguousarray(np.kron(x, np.ones((4, 4, 1), np.uint8))) for x in base]
+    mx, f0, f1, psnr = lsb_report(g.process(a, b, 0.5), o.process(a, b, 0.5))
+    assert mx <= 1, (mx, f0, f1, psnr)
