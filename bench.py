@@ -233,9 +233,39 @@ def cpu_baseline(modeldir, family, pixels, passes, size=None):
             break
     per_pair = dt / n
     scale = pixels / float(w * h) * passes
-    return {"value": round(1.0 / (per_pair * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d plain %s pair(s) at %dx%d in %.2f s with %d OpenMP threads; scaled by x%.3g (pixels x TTA passes, work is linear in both)"
-                      % (n, family, w, h, dt, cores, 1.0 / scale)}
+    res = {"value": round(1.0 / (per_pair * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "%d plain %s pair(s) at %dx%d in %.2f s with %d OpenMP threads; scaled by x%.3g (pixels x TTA passes, work is linear in both)"
+                     % (n, family, w, h, dt, cores, 1.0 / scale)}
+    # secondary, labelled proxy: the same graph through PyTorch-CPU (oneDNN convolutions) as a stand-in for the optimised
+    # x86 kernels of the reference's ncnn CPU path, which the naive direct convolutions of the oracle do not represent
+    if family.startswith("rife-v4"):
+        try:
+            import torch
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from torch_graph import TorchNet
+            nth = min(len(os.sched_getaffinity(0)), 64)
+            torch.set_num_threads(nth)
+            net = TorchNet(os.path.join(modeldir, "flownet.param"), os.path.join(modeldir, "flownet.bin"))
+            wp, hp = (w + 31) // 32 * 32, (h + 31) // 32 * 32
+
+            def chw(img):
+                x = np.zeros((3, hp, wp), np.float32)
+                x[:, :h, :w] = (img.astype(np.float32) * np.float32(1 / 255.0)).transpose(2, 0, 1)
+                return torch.from_numpy(x)
+            ins = {"in0": chw(a), "in1": chw(b), "in2": torch.full((1, hp, wp), np.float32(0.5))}
+            net.run(ins, ["out0"])                                   # warm-up (thread pool, oneDNN primitive cache)
+            m, t1 = 0, time.perf_counter()
+            while True:
+                net.run(ins, ["out0"])
+                m += 1
+                dt2 = time.perf_counter() - t1
+                if dt2 >= 5.0 or m >= 8:
+                    break
+            res["proxy_torch_onednn"] = {"value": round(1.0 / (dt2 / m * scale), 5), "unit": "frames/s", "cores": nth,
+                                         "sample": "%d pair(s) at %dx%d in %.2f s, graph only (no u8 pre/post), tests/torch_graph.py" % (m, w, h, dt2)}
+        except Exception as e:                                       # the proxy is optional; never let it break the bench line
+            res["proxy_torch_onednn"] = {"error": str(e)[:200]}
+    return res
 
 
 if __name__ == "__main__":
