@@ -275,6 +275,15 @@ static std::vector<int> parse_int_list(const std::string& s) {
 }
 
 int main(int argc, char** argv) {
+    // codec self-test without a GPU:  rife-hip --transcode in.(png|ppm) out.(png|ppm)
+    if (argc == 4 && std::string(argv[1]) == "--transcode") {
+        int w = 0, h = 0;
+        std::vector<unsigned char> rgb;
+        if (!decode_image(argv[2], w, h, rgb)) { fprintf(stderr, "decode image %s failed\n", argv[2]); return 1; }
+        const bool ok = ext_of(argv[3]) == "ppm" ? encode_ppm(argv[3], w, h, rgb.data()) : encode_png(argv[3], w, h, rgb.data());
+        if (!ok) { fprintf(stderr, "encode image %s failed\n", argv[3]); return 1; }
+        return 0;
+    }
     std::string input0, input1, inputpath, outputpath, model = "rife-v2.3", pattern_format = "%08d.png";
     int numframe = 0;
     float timestep = 0.5f;

@@ -130,3 +130,26 @@ def test_cpp_cli_directory_and_file_modes(modeldirs, tmp_path):
     rc, err = run_cpp(["-0", str(tmp_path / "a.png"), "-1", str(tmp_path / "b.png"), "-o", str(tmp_path / "o.ppm"), "-m", model, "-s", "0.25"])
     assert rc == 0, err
     assert np.array_equal(np.asarray(Image.open(tmp_path / "o.ppm").convert("RGB")), g.process(frames[0], frames[1], 0.25))
+
+
+@pytest.mark.skipif(not os.path.exists(RIFE_HIP), reason="rife-hip is not built")
+def test_cpp_cli_png_and_ppm_codecs_round_trip(tmp_path):
+    """rife-hip's own PNG reader (all five filter types, RGB / RGBA / gray / palette) and writer against PIL, no GPU involved."""
+    import subprocess
+    from PIL import Image
+    from tools import gen_frames
+    a, _ = gen_frames.smooth_pair(101, 67, 3)
+    n, _ = gen_frames.noise_pair(64, 33, 4)
+    cases = {"rgb": Image.fromarray(a), "noise": Image.fromarray(n), "rgba": Image.fromarray(a).convert("RGBA"), "gray": Image.fromarray(a).convert("L"),
+             "pal": Image.fromarray(a).convert("P", palette=Image.ADAPTIVE, colors=64)}
+    for name, im in cases.items():
+        src = tmp_path / (name + ".png")
+        im.save(src, optimize=(name == "rgb"))
+        want = np.asarray(im.convert("RGB"))
+        for ext in ("png", "ppm"):
+            dst = tmp_path / (name + "_out." + ext)
+            p = subprocess.run([RIFE_HIP, "--transcode", str(src), str(dst)], capture_output=True, text=True)
+            assert p.returncode == 0, (name, ext, p.stderr)
+            assert np.array_equal(np.asarray(Image.open(dst).convert("RGB")), want), (name, ext)
+    p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "missing.png"), str(tmp_path / "x.png")], capture_output=True, text=True)
+    assert p.returncode == 1
