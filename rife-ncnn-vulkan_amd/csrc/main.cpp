@@ -5,8 +5,9 @@
 //
 // Same flags, defaults, validation order and messages, frame / timestep schedule (src/main.cpp:705-731) and three-stage
 // pipeline (load -> proc -> save over bounded queues, one RIFE per -g id, -j load:proc[,proc..]:save; src/main.cpp:248-436,
-// 819-904), re-hosted on std::thread.  Codecs: this build links nothing but zlib, so it reads and writes PNG (8-bit, non-interlaced)
-// and binary PPM; jpg / webp paths are rejected with a message (the Python front end, cli.py, covers them through PIL).
+// 819-904), re-hosted on std::thread.  Codecs: PNG (8-bit, non-interlaced) through zlib, binary PPM, and WebP through the
+// system libwebp (its stable simple API, declared below because the image ships the library without headers; lossless encoding
+// like src/webp_image.h:66-68).  jpg is rejected with a message (the Python front end, cli.py, covers it through PIL).
 // Host glue only: every pixel of arithmetic happens in librife_hip.so.
 #include <dirent.h>
 #include <getopt.h>
@@ -28,6 +29,14 @@
 
 #include "../../include/rife_hip.h"
 #include "rife.h"
+
+#ifdef RIFE_HIP_WITH_WEBP
+extern "C" {      // libwebp simple API (webp/decode.h, webp/encode.h)
+uint8_t* WebPDecodeRGB(const uint8_t* data, size_t data_size, int* width, int* height);
+size_t WebPEncodeLosslessRGB(const uint8_t* rgb, int width, int height, int stride, uint8_t** output);
+void WebPFree(void* ptr);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // image files: PNG (zlib) and PPM (P6)
@@ -176,6 +185,38 @@ static bool encode_ppm(const std::string& path, int w, int h, const unsigned cha
     return ok;
 }
 
+static bool decode_webp(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgb) {
+#ifdef RIFE_HIP_WITH_WEBP
+    if (d.size() < 12 || memcmp(d.data(), "RIFF", 4) || memcmp(d.data() + 8, "WEBP", 4)) return false;
+    uint8_t* px = WebPDecodeRGB(d.data(), d.size(), &w, &h);
+    if (!px) return false;
+    rgb.assign(px, px + (size_t)w * h * 3);
+    WebPFree(px);
+    return true;
+#else
+    (void)d; (void)w; (void)h; (void)rgb;
+    return false;
+#endif
+}
+
+static bool encode_webp(const std::string& path, int w, int h, const unsigned char* rgb) {
+#ifdef RIFE_HIP_WITH_WEBP
+    uint8_t* out = nullptr;
+    const size_t n = WebPEncodeLosslessRGB(rgb, w, h, w * 3, &out);
+    if (!n || !out) return false;
+    FILE* f = fopen(path.c_str(), "wb");
+    const bool ok = f && fwrite(out, 1, n, f) == n;
+    if (f) fclose(f);
+    WebPFree(out);
+    return ok;
+#else
+    (void)path; (void)w; (void)h; (void)rgb;
+    return false;
+#endif
+}
+
+static bool encode_image(const std::string& path, int w, int h, const unsigned char* rgb);
+
 static std::string ext_of(const std::string& p) {
     const size_t dot = p.rfind('.');
     if (dot == std::string::npos || p.find('/', dot) != std::string::npos) return "";
@@ -187,10 +228,17 @@ static std::string ext_of(const std::string& p) {
 static bool decode_image(const std::string& path, int& w, int& h, std::vector<unsigned char>& rgb) {
     std::vector<unsigned char> d;
     if (!read_file(path, d)) return false;
-    if (decode_png(d, w, h, rgb) || decode_ppm(d, w, h, rgb)) return true;
+    if (decode_png(d, w, h, rgb) || decode_ppm(d, w, h, rgb) || decode_webp(d, w, h, rgb)) return true;
     const std::string e = ext_of(path);
-    if (e == "jpg" || e == "jpeg" || e == "webp") fprintf(stderr, "%s: jpg / webp decoding is not built into rife-hip (png and ppm are); use cli.py\n", path.c_str());
+    if (e == "jpg" || e == "jpeg") fprintf(stderr, "%s: jpg decoding is not built into rife-hip (png, webp and ppm are); use cli.py\n", path.c_str());
     return false;
+}
+
+static bool encode_image(const std::string& path, int w, int h, const unsigned char* rgb) {
+    const std::string e = ext_of(path);
+    if (e == "ppm") return encode_ppm(path, w, h, rgb);
+    if (e == "webp") return encode_webp(path, w, h, rgb);
+    return encode_png(path, w, h, rgb);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -231,10 +279,10 @@ static void print_usage() {
     fprintf(stderr, "       rife-hip -i indir -o outdir [options]...\n\n");
     fprintf(stderr, "  -h                   show this help\n");
     fprintf(stderr, "  -v                   verbose output\n");
-    fprintf(stderr, "  -0 input0-path       input image0 path (png/ppm)\n");
-    fprintf(stderr, "  -1 input1-path       input image1 path (png/ppm)\n");
-    fprintf(stderr, "  -i input-path        input image directory (png/ppm)\n");
-    fprintf(stderr, "  -o output-path       output image path (png/ppm) or directory\n");
+    fprintf(stderr, "  -0 input0-path       input image0 path (png/webp/ppm)\n");
+    fprintf(stderr, "  -1 input1-path       input image1 path (png/webp/ppm)\n");
+    fprintf(stderr, "  -i input-path        input image directory (png/webp/ppm)\n");
+    fprintf(stderr, "  -o output-path       output image path (png/webp/ppm) or directory\n");
     fprintf(stderr, "  -n num-frame         target frame count (default=N*2)\n");
     fprintf(stderr, "  -s time-step         time step (0~1, default=0.5)\n");
     fprintf(stderr, "  -m model-path        rife model path (default=rife-v2.3)\n");
@@ -243,7 +291,7 @@ static void print_usage() {
     fprintf(stderr, "  -x                   enable spatial tta mode\n");
     fprintf(stderr, "  -z                   enable temporal tta mode\n");
     fprintf(stderr, "  -u                   enable UHD mode\n");
-    fprintf(stderr, "  -f pattern-format    output image filename pattern format (%%08d.png/ppm, default=ext/%%08d.png)\n");
+    fprintf(stderr, "  -f pattern-format    output image filename pattern format (%%08d.png/webp/ppm, default=ext/%%08d.png)\n");
 }
 
 static bool is_dir(const std::string& p) { struct stat s; return stat(p.c_str(), &s) == 0 && S_ISDIR(s.st_mode); }
@@ -280,7 +328,7 @@ int main(int argc, char** argv) {
         int w = 0, h = 0;
         std::vector<unsigned char> rgb;
         if (!decode_image(argv[2], w, h, rgb)) { fprintf(stderr, "decode image %s failed\n", argv[2]); return 1; }
-        const bool ok = ext_of(argv[3]) == "ppm" ? encode_ppm(argv[3], w, h, rgb.data()) : encode_png(argv[3], w, h, rgb.data());
+        const bool ok = encode_image(argv[3], w, h, rgb.data());
         if (!ok) { fprintf(stderr, "encode image %s failed\n", argv[3]); return 1; }
         return 0;
     }
@@ -340,10 +388,14 @@ int main(int argc, char** argv) {
         const std::string e = ext_of(outputpath);
         if (e == "png") format = "png";
         else if (e == "ppm") format = "ppm";
-        else if (e == "webp" || e == "jpg" || e == "jpeg") { fprintf(stderr, "jpg / webp encoding is not built into rife-hip (png and ppm are); use cli.py\n"); return -1; }
+        else if (e == "webp") format = "webp";
+        else if (e == "jpg" || e == "jpeg") { fprintf(stderr, "jpg encoding is not built into rife-hip (png, webp and ppm are); use cli.py\n"); return -1; }
         else { fprintf(stderr, "invalid outputpath extension type\n"); return -1; }
     }
-    if (format != "png" && format != "ppm") { fprintf(stderr, "invalid format argument\n"); return -1; }
+    if (format != "png" && format != "ppm" && format != "webp") { fprintf(stderr, "invalid format argument\n"); return -1; }
+#ifndef RIFE_HIP_WITH_WEBP
+    if (format == "webp") { fprintf(stderr, "this rife-hip was built without libwebp\n"); return -1; }
+#endif
 
     bool rife_v2 = false, rife_v4 = false;      // family from the directory name (src/main.cpp:658-683)
     if (model.find("rife-v2") != std::string::npos || model.find("rife-v3") != std::string::npos) rife_v2 = true;
@@ -425,7 +477,7 @@ int main(int argc, char** argv) {
         for (;;) {
             Task t = tosave.get();
             if (t.id == -233) return;
-            const bool ok = ext_of(t.outpath) == "ppm" ? encode_ppm(t.outpath, t.w, t.h, t.out.data()) : encode_png(t.outpath, t.w, t.h, t.out.data());
+            const bool ok = encode_image(t.outpath, t.w, t.h, t.out.data());
             if (!ok) fprintf(stderr, "encode image %s failed\n", t.outpath.c_str());
             else if (verbose) fprintf(stderr, "%s %s %f -> %s done\n", t.in0path.c_str(), t.in1path.c_str(), t.timestep, t.outpath.c_str());
         }

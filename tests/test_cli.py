@@ -146,10 +146,14 @@ def test_cpp_cli_png_and_ppm_codecs_round_trip(tmp_path):
         src = tmp_path / (name + ".png")
         im.save(src, optimize=(name == "rgb"))
         want = np.asarray(im.convert("RGB"))
-        for ext in ("png", "ppm"):
+        for ext in ("png", "ppm", "webp"):
             dst = tmp_path / (name + "_out." + ext)
             p = subprocess.run([RIFE_HIP, "--transcode", str(src), str(dst)], capture_output=True, text=True)
             assert p.returncode == 0, (name, ext, p.stderr)
             assert np.array_equal(np.asarray(Image.open(dst).convert("RGB")), want), (name, ext)
+    Image.fromarray(a).save(tmp_path / "in.webp", lossless=True)          # WebP decode (lossless source -> exact pixels)
+    p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "in.webp"), str(tmp_path / "from_webp.png")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "from_webp.png").convert("RGB")), a)
     p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "missing.png"), str(tmp_path / "x.png")], capture_output=True, text=True)
     assert p.returncode == 1
