@@ -1,0 +1,367 @@
+// Baseline JPEG for the rife-hip command line (host glue): the reference reads jpg through stb_image and writes
+// it through stb_image_write at quality 100 (src/main.cpp:123-229, 215); neither library nor libjpeg headers exist in this image,
+// so this is a from-scratch codec of the subset that matters for frame sequences:
+//   decode: baseline sequential DCT (SOF0 / SOF1 with 8-bit samples), Huffman, 1 or 3 components, any sampling factors up to 2x2
+//           (4:4:4, 4:2:2, 4:2:0, ...), restart intervals, JFIF YCbCr -> RGB; progressive / arithmetic / 12-bit files are refused;
+//   encode: baseline, 4:4:4, all-ones quantisation tables (what "quality 100" means), standard Huffman tables.
+// Floating-point IDCT / FDCT (separable, exact to rounding), so decoded pixels agree with libjpeg's to within +-1..2 levels.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace jpeg {
+
+static const int ZIGZAG[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                               35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Huff {
+    // canonical code tables: for each length 1..16 the first code, first symbol index and count
+    int mincode[17], maxcode[18], valptr[17];
+    uint8_t vals[256];
+    bool ok = false;
+    void build(const uint8_t* counts, const uint8_t* symbols, int nsym) {
+        std::memcpy(vals, symbols, (size_t)nsym);
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; l++) {
+            valptr[l] = k; mincode[l] = code;
+            code += counts[l - 1]; k += counts[l - 1];
+            maxcode[l] = counts[l - 1] ? code - 1 : -1;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7fffffff;
+        ok = true;
+    }
+};
+
+struct BitReader {
+    const uint8_t* p; const uint8_t* end;
+    uint32_t acc = 0; int n = 0; bool marker = false;
+    int bit() {
+        if (n == 0) {
+            int b = 0;
+            if (p < end && !marker) {
+                b = *p++;
+                if (b == 0xFF) {
+                    if (p < end && *p == 0) p++;               // stuffed zero
+                    else { marker = true; b = 0; p--; }        // a marker: feed zeros until the caller handles it
+                }
+            }
+            acc = (uint32_t)b; n = 8;
+        }
+        n--;
+        return (acc >> n) & 1;
+    }
+    int bits(int k) { int v = 0; while (k--) v = (v << 1) | bit(); return v; }
+    void align() { n = 0; }
+};
+
+static inline int decode_symbol(BitReader& br, const Huff& h) {
+    int code = 0;
+    for (int l = 1; l <= 16; l++) {
+        code = (code << 1) | br.bit();
+        if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    }
+    return -1;
+}
+
+static inline int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+
+// 8x8 inverse DCT (separable, double precision cosine table), level shift + clamp to u8
+static inline void idct8x8(const float* in, uint8_t* out, int stride) {
+    static float C[8][8]; static bool init = false;
+    if (!init) {
+        for (int x = 0; x < 8; x++) for (int u = 0; u < 8; u++) C[x][u] = (float)((u == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * u * M_PI / 16.0));
+        init = true;
+    }
+    float tmp[64];
+    for (int v = 0; v < 8; v++)            // rows: over u
+        for (int x = 0; x < 8; x++) { float s = 0; for (int u = 0; u < 8; u++) s += C[x][u] * in[v * 8 + u]; tmp[v * 8 + x] = s; }
+    for (int x = 0; x < 8; x++)
+        for (int y = 0; y < 8; y++) {
+            float s = 0; for (int v = 0; v < 8; v++) s += C[y][v] * tmp[v * 8 + x];
+            const int q = (int)std::lround(s + 128.f);
+            out[y * stride + x] = (uint8_t)(q < 0 ? 0 : q > 255 ? 255 : q);
+        }
+}
+
+inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgb, std::string* why = nullptr) {
+    auto fail = [&](const char* m) { if (why) *why = m; return false; };
+    if (d.size() < 4 || d[0] != 0xFF || d[1] != 0xD8) return fail("not a JPEG");
+    uint16_t qt[4][64]; bool have_qt[4] = {false, false, false, false};
+    Huff dc[4], ac[4];
+    struct Comp { int id, hs, vs, tq, td, ta; int bw, bh; std::vector<uint8_t> plane; int pred; } comp[3];
+    int ncomp = 0, hmax = 1, vmax = 1, restart = 0;
+    bool have_sof = false;
+    size_t pos = 2;
+    while (pos + 4 <= d.size()) {
+        if (d[pos] != 0xFF) { pos++; continue; }
+        const int m = d[pos + 1];
+        if (m == 0xFF) { pos++; continue; }
+        pos += 2;
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9) break;
+        if (pos + 2 > d.size()) return fail("truncated");
+        const size_t len = ((size_t)d[pos] << 8) | d[pos + 1];
+        if (len < 2 || pos + len > d.size()) return fail("truncated segment");
+        const uint8_t* s = &d[pos + 2]; const size_t n = len - 2;
+        if (m == 0xDB) {
+            size_t i = 0;
+            while (i < n) {
+                const int pq = s[i] >> 4, tq = s[i] & 15; i++;
+                if (tq > 3 || i + (pq ? 128 : 64) > n) return fail("bad DQT");
+                for (int k = 0; k < 64; k++) { qt[tq][ZIGZAG[k]] = pq ? (uint16_t)((s[i] << 8) | s[i + 1]) : s[i]; i += pq ? 2 : 1; }
+                have_qt[tq] = true;
+            }
+        } else if (m == 0xC4) {
+            size_t i = 0;
+            while (i + 17 <= n) {
+                const int tc = s[i] >> 4, th = s[i] & 15;
+                int total = 0; for (int k = 0; k < 16; k++) total += s[i + 1 + k];
+                if (th > 3 || total > 256 || i + 17 + total > n) return fail("bad DHT");
+                (tc ? ac[th] : dc[th]).build(&s[i + 1], &s[i + 17], total);
+                i += 17 + total;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (n < 6 || s[0] != 8) return fail("only 8-bit samples are supported");
+            h = (s[1] << 8) | s[2]; w = (s[3] << 8) | s[4]; ncomp = s[5];
+            if ((ncomp != 1 && ncomp != 3) || n < 6 + 3 * (size_t)ncomp || w <= 0 || h <= 0) return fail("unsupported component count");
+            for (int c = 0; c < ncomp; c++) {
+                comp[c].id = s[6 + 3 * c]; comp[c].hs = s[7 + 3 * c] >> 4; comp[c].vs = s[7 + 3 * c] & 15; comp[c].tq = s[8 + 3 * c];
+                if (comp[c].hs < 1 || comp[c].hs > 2 || comp[c].vs < 1 || comp[c].vs > 2 || comp[c].tq > 3) return fail("unsupported sampling factors");
+                hmax = std::max(hmax, comp[c].hs); vmax = std::max(vmax, comp[c].vs);
+            }
+            have_sof = true;
+        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+            return fail("progressive / lossless / arithmetic JPEG is not supported (baseline only)");
+        } else if (m == 0xDD) {
+            if (n >= 2) restart = (s[0] << 8) | s[1];
+        } else if (m == 0xDA) {
+            if (!have_sof) return fail("SOS before SOF");
+            if (n < 1 || s[0] != ncomp || n < 1 + 2 * (size_t)ncomp + 3) return fail("multi-scan files are not supported");
+            for (int k = 0; k < ncomp; k++) {
+                int ci = -1;
+                for (int c = 0; c < ncomp; c++) if (comp[c].id == s[1 + 2 * k]) ci = c;
+                if (ci < 0) return fail("bad scan component");
+                comp[ci].td = s[2 + 2 * k] >> 4; comp[ci].ta = s[2 + 2 * k] & 15;
+                if (!dc[comp[ci].td].ok || !ac[comp[ci].ta].ok || !have_qt[comp[ci].tq]) return fail("missing table");
+            }
+            const int mcuw = 8 * hmax, mcuh = 8 * vmax;
+            const int mx = (w + mcuw - 1) / mcuw, my = (h + mcuh - 1) / mcuh;
+            for (int c = 0; c < ncomp; c++) {
+                comp[c].bw = mx * comp[c].hs * 8; comp[c].bh = my * comp[c].vs * 8;
+                comp[c].plane.assign((size_t)comp[c].bw * comp[c].bh, 0);
+                comp[c].pred = 0;
+            }
+            BitReader br{&d[pos + len], d.data() + d.size()};
+            int count = 0;
+            for (int yy = 0; yy < my; yy++)
+                for (int xx = 0; xx < mx; xx++) {
+                    if (restart && count && count % restart == 0) {
+                        br.align();
+                        // skip to and over the RSTn marker
+                        while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) br.p++;
+                        if (br.p + 1 < br.end) br.p += 2;
+                        br.marker = false; br.n = 0;
+                        for (int c = 0; c < ncomp; c++) comp[c].pred = 0;
+                    }
+                    count++;
+                    for (int c = 0; c < ncomp; c++)
+                        for (int by = 0; by < comp[c].vs; by++)
+                            for (int bx = 0; bx < comp[c].hs; bx++) {
+                                float blk[64];
+                                for (int k = 0; k < 64; k++) blk[k] = 0.f;
+                                const int t = decode_symbol(br, dc[comp[c].td]);
+                                if (t < 0 || t > 11) return fail("bad DC code");
+                                const int diff = t ? extend(br.bits(t), t) : 0;
+                                comp[c].pred += diff;
+                                blk[0] = (float)(comp[c].pred * qt[comp[c].tq][0]);
+                                for (int k = 1; k < 64;) {
+                                    const int rs = decode_symbol(br, ac[comp[c].ta]);
+                                    if (rs < 0) return fail("bad AC code");
+                                    const int r = rs >> 4, sz = rs & 15;
+                                    if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                                    k += r;
+                                    if (k > 63) return fail("AC run past the block");
+                                    blk[ZIGZAG[k]] = (float)(extend(br.bits(sz), sz) * qt[comp[c].tq][ZIGZAG[k]]);
+                                    k++;
+                                }
+                                const int px = (xx * comp[c].hs + bx) * 8, py = (yy * comp[c].vs + by) * 8;
+                                idct8x8(blk, &comp[c].plane[(size_t)py * comp[c].bw + px], comp[c].bw);
+                            }
+                }
+            // chroma upsampling: libjpeg's "fancy" triangle filters for the two common layouts (h2v1 = 4:2:2, h2v2 = 4:2:0; the same
+            // 3:1 weights stb_image uses), replication for anything else; then JFIF YCbCr -> RGB
+            std::vector<uint8_t> full[3];
+            for (int c = 0; c < ncomp; c++) {
+                full[c].resize((size_t)w * h);
+                const Comp& C = comp[c];
+                const int cw = (w * C.hs + hmax - 1) / hmax, chh = (h * C.vs + vmax - 1) / vmax;      // valid samples of this component
+                auto S = [&](int yy, int xx) -> int { return C.plane[(size_t)std::min(std::max(yy, 0), chh - 1) * C.bw + std::min(std::max(xx, 0), cw - 1)]; };
+                const bool h2 = hmax == 2 && C.hs == 1, v2 = vmax == 2 && C.vs == 1;
+                if (C.hs == hmax && C.vs == vmax) {
+                    for (int y = 0; y < h; y++) std::memcpy(&full[c][(size_t)y * w], &C.plane[(size_t)y * C.bw], (size_t)w);
+                } else if (h2 && !v2 && C.vs == vmax) {                                                 // h2v1
+                    for (int y = 0; y < h; y++)
+                        for (int x = 0; x < w; x++) {
+                            const int i = x >> 1;
+                            int v;
+                            if (cw == 1) v = S(y, 0);
+                            else if (x == 0) v = S(y, 0);
+                            else if (x == 2 * cw - 1) v = S(y, cw - 1);
+                            else v = (x & 1) ? (S(y, i) * 3 + S(y, i + 1) + 2) >> 2 : (S(y, i) * 3 + S(y, i - 1) + 1) >> 2;
+                            full[c][(size_t)y * w + x] = (uint8_t)v;
+                        }
+                } else if (h2 && v2) {                                                                  // h2v2
+                    for (int y = 0; y < h; y++) {
+                        const int r = y >> 1, rn = (y & 1) ? r + 1 : r - 1;                             // nearer / farther input row (edges replicate)
+                        for (int x = 0; x < w; x++) {
+                            const int i = x >> 1;
+                            const int cs = S(r, i) * 3 + S(rn, i);
+                            int v;
+                            if (cw == 1) v = (cs * 4 + 8) >> 4;
+                            else if (x == 0) v = (cs * 4 + 8) >> 4;
+                            else if (x == 2 * cw - 1) v = (cs * 4 + 7) >> 4;
+                            else if (x & 1) v = (cs * 3 + S(r, i + 1) * 3 + S(rn, i + 1) + 7) >> 4;
+                            else v = (cs * 3 + S(r, i - 1) * 3 + S(rn, i - 1) + 8) >> 4;
+                            full[c][(size_t)y * w + x] = (uint8_t)v;
+                        }
+                    }
+                } else {
+                    for (int y = 0; y < h; y++)
+                        for (int x = 0; x < w; x++) full[c][(size_t)y * w + x] = (uint8_t)S(y * C.vs / vmax, x * C.hs / hmax);
+                }
+            }
+            rgb.resize((size_t)w * h * 3);
+            for (size_t i = 0; i < (size_t)w * h; i++) {
+                unsigned char* o = &rgb[i * 3];
+                if (ncomp == 1) { o[0] = o[1] = o[2] = full[0][i]; continue; }
+                const float Y = full[0][i], cb = (float)full[1][i] - 128.f, cr = (float)full[2][i] - 128.f;
+                const int ri = (int)std::lround(Y + 1.402f * cr), gi = (int)std::lround(Y - 0.344136f * cb - 0.714136f * cr), bi = (int)std::lround(Y + 1.772f * cb);
+                o[0] = (uint8_t)(ri < 0 ? 0 : ri > 255 ? 255 : ri); o[1] = (uint8_t)(gi < 0 ? 0 : gi > 255 ? 255 : gi); o[2] = (uint8_t)(bi < 0 ? 0 : bi > 255 ? 255 : bi);
+            }
+            return true;
+        }
+        pos += len;
+    }
+    return fail("no scan found");
+}
+
+// ------------------------------------------------------------------- encoder -------------------------------------------------------------------
+// standard Huffman tables of ITU T.81 Annex K.3
+static const uint8_t DC_L_BITS[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0}, DC_C_BITS[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+static const uint8_t DC_VALS[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t AC_L_BITS[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d}, AC_C_BITS[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+static const uint8_t AC_L_VALS[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1,
+    0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39,
+    0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75,
+    0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7,
+    0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8,
+    0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+static const uint8_t AC_C_VALS[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09,
+    0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38,
+    0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74,
+    0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5,
+    0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+    0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+struct EncTable { uint16_t code[256]; uint8_t len[256]; };
+static inline void make_enc(const uint8_t* bits, const uint8_t* vals, EncTable& t) {
+    std::memset(&t, 0, sizeof t);
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; l++) {
+        for (int i = 0; i < bits[l - 1]; i++, k++) { t.code[vals[k]] = (uint16_t)code; t.len[vals[k]] = (uint8_t)l; code++; }
+        code <<= 1;
+    }
+}
+
+struct BitWriter {
+    std::vector<unsigned char>& out; uint32_t acc = 0; int n = 0;
+    void put(int code, int len) {
+        acc = (acc << len) | (uint32_t)(code & ((1 << len) - 1)); n += len;
+        while (n >= 8) { const uint8_t b = (uint8_t)(acc >> (n - 8)); out.push_back(b); if (b == 0xFF) out.push_back(0); n -= 8; }
+    }
+    void flush() { if (n) put(0x7F, 8 - n); }
+};
+
+static inline void fdct8x8(const float* in, float* out) {
+    static float C[8][8]; static bool init = false;
+    if (!init) {
+        for (int x = 0; x < 8; x++) for (int u = 0; u < 8; u++) C[x][u] = (float)((u == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * u * M_PI / 16.0));
+        init = true;
+    }
+    float tmp[64];
+    for (int y = 0; y < 8; y++) for (int u = 0; u < 8; u++) { float s = 0; for (int x = 0; x < 8; x++) s += C[x][u] * in[y * 8 + x]; tmp[y * 8 + u] = s; }
+    for (int u = 0; u < 8; u++) for (int v = 0; v < 8; v++) { float s = 0; for (int y = 0; y < 8; y++) s += C[y][v] * tmp[y * 8 + u]; out[v * 8 + u] = s; }
+}
+
+static inline void seg(std::vector<unsigned char>& o, int marker, const std::vector<unsigned char>& body) {
+    o.push_back(0xFF); o.push_back((unsigned char)marker);
+    const size_t len = body.size() + 2;
+    o.push_back((unsigned char)(len >> 8)); o.push_back((unsigned char)len);
+    o.insert(o.end(), body.begin(), body.end());
+}
+
+// quality 100 (all-ones quantisation), 4:4:4, JFIF
+inline bool encode(const std::string& path, int w, int h, const unsigned char* rgb) {
+    std::vector<unsigned char> o = {0xFF, 0xD8};
+    seg(o, 0xE0, {'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0});
+    { std::vector<unsigned char> q(65, 1); q[0] = 0; seg(o, 0xDB, q); }
+    seg(o, 0xC0, {8, (unsigned char)(h >> 8), (unsigned char)h, (unsigned char)(w >> 8), (unsigned char)w, 3, 1, 0x11, 0, 2, 0x11, 0, 3, 0x11, 0});
+    auto dht = [&](int tc_th, const uint8_t* bits, const uint8_t* vals, int n) {
+        std::vector<unsigned char> b; b.push_back((unsigned char)tc_th); b.insert(b.end(), bits, bits + 16); b.insert(b.end(), vals, vals + n); seg(o, 0xC4, b);
+    };
+    dht(0x00, DC_L_BITS, DC_VALS, 12); dht(0x10, AC_L_BITS, AC_L_VALS, 162); dht(0x01, DC_C_BITS, DC_VALS, 12); dht(0x11, AC_C_BITS, AC_C_VALS, 162);
+    seg(o, 0xDA, {3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0});
+    EncTable dcl, acl, dcc, acc_;
+    make_enc(DC_L_BITS, DC_VALS, dcl); make_enc(AC_L_BITS, AC_L_VALS, acl); make_enc(DC_C_BITS, DC_VALS, dcc); make_enc(AC_C_BITS, AC_C_VALS, acc_);
+    BitWriter bw{o};
+    int pred[3] = {0, 0, 0};
+    for (int by = 0; by < h; by += 8)
+        for (int bx = 0; bx < w; bx += 8) {
+            float blk[3][64];
+            for (int y = 0; y < 8; y++)
+                for (int x = 0; x < 8; x++) {
+                    const int sx = std::min(bx + x, w - 1), sy = std::min(by + y, h - 1);
+                    const unsigned char* p = rgb + ((size_t)sy * w + sx) * 3;
+                    const float r = p[0], g = p[1], b = p[2];
+                    blk[0][y * 8 + x] = 0.299f * r + 0.587f * g + 0.114f * b - 128.f;
+                    blk[1][y * 8 + x] = -0.168736f * r - 0.331264f * g + 0.5f * b;
+                    blk[2][y * 8 + x] = 0.5f * r - 0.418688f * g - 0.081312f * b;
+                }
+            for (int c = 0; c < 3; c++) {
+                float f[64]; fdct8x8(blk[c], f);
+                int q[64];
+                for (int k = 0; k < 64; k++) { q[k] = (int)std::lround(f[ZIGZAG[k]]); q[k] = q[k] < -1023 ? -1023 : q[k] > 1023 ? 1023 : q[k]; }   // size categories <= 10 (AC) / 11 (DC diff)
+                const EncTable& dct = c ? dcc : dcl; const EncTable& act = c ? acc_ : acl;
+                const int diff = q[0] - pred[c]; pred[c] = q[0];
+                int a = diff < 0 ? -diff : diff, t = 0; while (a) { t++; a >>= 1; }
+                bw.put(dct.code[t], dct.len[t]);
+                if (t) bw.put(diff < 0 ? diff - 1 : diff, t);
+                int run = 0;
+                for (int k = 1; k < 64; k++) {
+                    if (q[k] == 0) { run++; continue; }
+                    while (run > 15) { bw.put(act.code[0xF0], act.len[0xF0]); run -= 16; }
+                    int aa = q[k] < 0 ? -q[k] : q[k], s = 0; while (aa) { s++; aa >>= 1; }
+                    bw.put(act.code[(run << 4) | s], act.len[(run << 4) | s]);
+                    bw.put(q[k] < 0 ? q[k] - 1 : q[k], s);
+                    run = 0;
+                }
+                if (run) bw.put(act.code[0], act.len[0]);
+            }
+        }
+    bw.flush();
+    o.push_back(0xFF); o.push_back(0xD9);
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(o.data(), 1, o.size(), f) == o.size();
+    fclose(f);
+    return ok;
+}
+
+}  // namespace jpeg

@@ -7,7 +7,7 @@
 // pipeline (load -> proc -> save over bounded queues, one RIFE per -g id, -j load:proc[,proc..]:save; src/main.cpp:248-436,
 // 819-904), re-hosted on std::thread.  Codecs: PNG (8-bit, non-interlaced) through zlib, binary PPM, and WebP through the
 // system libwebp (its stable simple API, declared below because the image ships the library without headers; lossless encoding
-// like src/webp_image.h:66-68).  jpg is rejected with a message (the Python front end, cli.py, covers it through PIL).
+// like src/webp_image.h:66-68), and baseline JPEG through jpeg_codec.h (quality 100 on output like src/main.cpp:215).
 // Host glue only: every pixel of arithmetic happens in librife_hip.so.
 #include <dirent.h>
 #include <getopt.h>
@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/rife_hip.h"
+#include "jpeg_codec.h"
 #include "rife.h"
 
 #ifdef RIFE_HIP_WITH_WEBP
@@ -229,8 +230,9 @@ static bool decode_image(const std::string& path, int& w, int& h, std::vector<un
     std::vector<unsigned char> d;
     if (!read_file(path, d)) return false;
     if (decode_png(d, w, h, rgb) || decode_ppm(d, w, h, rgb) || decode_webp(d, w, h, rgb)) return true;
-    const std::string e = ext_of(path);
-    if (e == "jpg" || e == "jpeg") fprintf(stderr, "%s: jpg decoding is not built into rife-hip (png, webp and ppm are); use cli.py\n", path.c_str());
+    std::string why;
+    if (jpeg::decode(d, w, h, rgb, &why)) return true;
+    if (d.size() > 2 && d[0] == 0xFF && d[1] == 0xD8) fprintf(stderr, "%s: %s\n", path.c_str(), why.c_str());
     return false;
 }
 
@@ -238,6 +240,7 @@ static bool encode_image(const std::string& path, int w, int h, const unsigned c
     const std::string e = ext_of(path);
     if (e == "ppm") return encode_ppm(path, w, h, rgb);
     if (e == "webp") return encode_webp(path, w, h, rgb);
+    if (e == "jpg" || e == "jpeg") return jpeg::encode(path, w, h, rgb);
     return encode_png(path, w, h, rgb);
 }
 
@@ -279,10 +282,10 @@ static void print_usage() {
     fprintf(stderr, "       rife-hip -i indir -o outdir [options]...\n\n");
     fprintf(stderr, "  -h                   show this help\n");
     fprintf(stderr, "  -v                   verbose output\n");
-    fprintf(stderr, "  -0 input0-path       input image0 path (png/webp/ppm)\n");
-    fprintf(stderr, "  -1 input1-path       input image1 path (png/webp/ppm)\n");
-    fprintf(stderr, "  -i input-path        input image directory (png/webp/ppm)\n");
-    fprintf(stderr, "  -o output-path       output image path (png/webp/ppm) or directory\n");
+    fprintf(stderr, "  -0 input0-path       input image0 path (jpg/png/webp/ppm)\n");
+    fprintf(stderr, "  -1 input1-path       input image1 path (jpg/png/webp/ppm)\n");
+    fprintf(stderr, "  -i input-path        input image directory (jpg/png/webp/ppm)\n");
+    fprintf(stderr, "  -o output-path       output image path (jpg/png/webp/ppm) or directory\n");
     fprintf(stderr, "  -n num-frame         target frame count (default=N*2)\n");
     fprintf(stderr, "  -s time-step         time step (0~1, default=0.5)\n");
     fprintf(stderr, "  -m model-path        rife model path (default=rife-v2.3)\n");
@@ -291,7 +294,7 @@ static void print_usage() {
     fprintf(stderr, "  -x                   enable spatial tta mode\n");
     fprintf(stderr, "  -z                   enable temporal tta mode\n");
     fprintf(stderr, "  -u                   enable UHD mode\n");
-    fprintf(stderr, "  -f pattern-format    output image filename pattern format (%%08d.png/webp/ppm, default=ext/%%08d.png)\n");
+    fprintf(stderr, "  -f pattern-format    output image filename pattern format (%%08d.jpg/png/webp/ppm, default=ext/%%08d.png)\n");
 }
 
 static bool is_dir(const std::string& p) { struct stat s; return stat(p.c_str(), &s) == 0 && S_ISDIR(s.st_mode); }
@@ -389,10 +392,10 @@ int main(int argc, char** argv) {
         if (e == "png") format = "png";
         else if (e == "ppm") format = "ppm";
         else if (e == "webp") format = "webp";
-        else if (e == "jpg" || e == "jpeg") { fprintf(stderr, "jpg encoding is not built into rife-hip (png, webp and ppm are); use cli.py\n"); return -1; }
+        else if (e == "jpg" || e == "jpeg") format = "jpg";
         else { fprintf(stderr, "invalid outputpath extension type\n"); return -1; }
     }
-    if (format != "png" && format != "ppm" && format != "webp") { fprintf(stderr, "invalid format argument\n"); return -1; }
+    if (format != "png" && format != "ppm" && format != "webp" && format != "jpg") { fprintf(stderr, "invalid format argument\n"); return -1; }
 #ifndef RIFE_HIP_WITH_WEBP
     if (format == "webp") { fprintf(stderr, "this rife-hip was built without libwebp\n"); return -1; }
 #endif

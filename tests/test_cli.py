@@ -157,3 +157,33 @@ def test_cpp_cli_png_and_ppm_codecs_round_trip(tmp_path):
     assert np.array_equal(np.asarray(Image.open(tmp_path / "from_webp.png").convert("RGB")), a)
     p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "missing.png"), str(tmp_path / "x.png")], capture_output=True, text=True)
     assert p.returncode == 1
+
+
+@pytest.mark.skipif(not os.path.exists(RIFE_HIP), reason="rife-hip is not built")
+def test_cpp_cli_jpeg_codec_against_libjpeg(tmp_path):
+    """csrc/jpeg_codec.h (baseline decode with libjpeg-style fancy chroma upsampling; quality-100 encode) against PIL's libjpeg."""
+    import subprocess
+    from PIL import Image
+    from tools import gen_frames
+    for (w, h) in ((203, 117), (64, 48), (17, 9)):
+        a, _ = gen_frames.smooth_pair(w, h, 3)
+        variants = {"q95_420": dict(quality=95), "q100_444": dict(quality=100, subsampling=0), "q90_422": dict(quality=90, subsampling=1),
+                    "q75_opt": dict(quality=75, optimize=True), "gray": dict(quality=95)}
+        for name, kw in variants.items():
+            src = tmp_path / ("%s_%d.jpg" % (name, w))
+            (Image.fromarray(a).convert("L") if name == "gray" else Image.fromarray(a)).save(src, **kw)
+            dst = tmp_path / ("%s_%d.png" % (name, w))
+            p = subprocess.run([RIFE_HIP, "--transcode", str(src), str(dst)], capture_output=True, text=True)
+            assert p.returncode == 0, (name, p.stderr)
+            d = np.abs(np.asarray(Image.open(dst).convert("RGB")).astype(int) - np.asarray(Image.open(src).convert("RGB")).astype(int))
+            assert d.max() <= 3 and d.mean() < 0.1, (name, w, int(d.max()), float(d.mean()))
+        # encoder: quality 100, 4:4:4 -> PIL must read back (almost) the original
+        Image.fromarray(a).save(tmp_path / "src.png")
+        p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "src.png"), str(tmp_path / "enc.jpg")], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        d = np.abs(np.asarray(Image.open(tmp_path / "enc.jpg").convert("RGB")).astype(int) - a.astype(int))
+        assert d.max() <= 4 and d.mean() < 1.0, (w, int(d.max()), float(d.mean()))
+    a, _ = gen_frames.smooth_pair(64, 48, 3)
+    Image.fromarray(a).save(tmp_path / "prog.jpg", progressive=True)
+    p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "prog.jpg"), str(tmp_path / "prog.png")], capture_output=True, text=True)
+    assert p.returncode == 1 and "progressive" in p.stderr
