@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <string>
@@ -251,8 +252,36 @@ struct Task {
     int id = 0;
     float timestep = 0.5f;
     std::string in0path, in1path, outpath;
-    std::vector<unsigned char> px0, px1, out;
+    std::shared_ptr<const std::vector<unsigned char>> px0, px1;      // decoded frames are shared between the tasks that use them
+    std::vector<unsigned char> out;
     int w = 0, h = 0;
+};
+
+// Decoded-frame cache: in directory mode consecutive tasks use the same files (output i takes frames sx, sx + 1; with the default
+// -n every input frame is needed by about four tasks), and decoding is the slowest stage of the whole program.  The reference
+// decodes per task (src/main.cpp:315-334); this keeps the last few decoded frames.
+class FrameCache {
+public:
+    struct Frame { int w = 0, h = 0; std::shared_ptr<const std::vector<unsigned char>> px; };
+    template <class Decode>
+    bool get(const std::string& path, Frame& f, Decode decode) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (auto& e : entries) if (e.first == path) { f = e.second; return true; }
+        }
+        auto px = std::make_shared<std::vector<unsigned char>>();
+        Frame n;
+        if (!decode(path, n.w, n.h, *px)) return false;
+        n.px = px;
+        std::lock_guard<std::mutex> g(mu);
+        entries.emplace_back(path, n);
+        if (entries.size() > 6) entries.erase(entries.begin());
+        f = n;
+        return true;
+    }
+private:
+    std::mutex mu;
+    std::vector<std::pair<std::string, Frame>> entries;
 };
 
 class TaskQueue {
@@ -452,6 +481,7 @@ int main(int argc, char** argv) {
 
     // ---- load -> proc -> save (src/main.cpp:309-436, 830-904) ----
     TaskQueue toproc, tosave;
+    FrameCache cache;
     std::mutex next_mu;
     size_t next_task = 0;
     auto load = [&]() {
@@ -459,9 +489,10 @@ int main(int argc, char** argv) {
             size_t k;
             { std::lock_guard<std::mutex> g(next_mu); if (next_task >= tasks.size()) return; k = next_task++; }
             Task t = std::move(tasks[k]);
-            int w1 = 0, h1 = 0;
-            if (!decode_image(t.in0path, t.w, t.h, t.px0) || !decode_image(t.in1path, w1, h1, t.px1)) { fprintf(stderr, "decode image %s or %s failed\n", t.in0path.c_str(), t.in1path.c_str()); continue; }
-            if (w1 != t.w || h1 != t.h) { fprintf(stderr, "%s and %s differ in size\n", t.in0path.c_str(), t.in1path.c_str()); continue; }
+            FrameCache::Frame f0, f1;
+            if (!cache.get(t.in0path, f0, decode_image) || !cache.get(t.in1path, f1, decode_image)) { fprintf(stderr, "decode image %s or %s failed\n", t.in0path.c_str(), t.in1path.c_str()); continue; }
+            if (f1.w != f0.w || f1.h != f0.h) { fprintf(stderr, "%s and %s differ in size\n", t.in0path.c_str(), t.in1path.c_str()); continue; }
+            t.w = f0.w; t.h = f0.h; t.px0 = f0.px; t.px1 = f1.px;
             toproc.put(std::move(t));
         }
     };
@@ -469,7 +500,7 @@ int main(int argc, char** argv) {
         for (;;) {
             Task t = toproc.get();
             if (t.id == -233) return;                                          // end marker, like the reference
-            ncnn::Mat in0(t.w, t.h, (void*)t.px0.data(), (size_t)3, 3), in1(t.w, t.h, (void*)t.px1.data(), (size_t)3, 3);
+            ncnn::Mat in0(t.w, t.h, (void*)t.px0->data(), (size_t)3, 3), in1(t.w, t.h, (void*)t.px1->data(), (size_t)3, 3);
             ncnn::Mat out(t.w, t.h, (size_t)3, 3);
             if (r->process(in0, in1, t.timestep, out) != 0) { fprintf(stderr, "process %s failed: %s\n", t.outpath.c_str(), rife_hip_last_error()); continue; }
             t.out.assign((const unsigned char*)out.data, (const unsigned char*)out.data + (size_t)t.w * t.h * 3);
