@@ -62,6 +62,17 @@ int rife_hip_process_batch(const rife_hip_t* r, int n, const uint8_t* const* in0
 int rife_hip_process_device(const rife_hip_t* r, const void* d_in0_rgb, const void* d_in1_rgb, int w, int h,
                             float timestep, void* d_out_rgb, void* hip_stream);
 
+/* Stream mode (absent in the reference, whose tasks upload both frames every time, src/main.cpp:315-334,
+ * src/rife.cpp:2490-2530): in a frame sequence every frame is the second frame of one pair and the first frame of the next,
+ * and with -n > 2N it serves several timesteps, so a caller can upload a frame ONCE and interpolate between resident frames.
+ * A frame belongs to the device of the engine that uploaded it and may be used by any thread and by several calls at once
+ * (it is read-only); release it after the last call that uses it has returned.  Pixels are identical to rife_hip_process(). */
+typedef struct rife_hip_frame rife_hip_frame_t;
+int rife_hip_frame_upload(const rife_hip_t* r, const uint8_t* rgb, int w, int h, rife_hip_frame_t** frame);
+int rife_hip_process_frames(const rife_hip_t* r, const rife_hip_frame_t* frame0, const rife_hip_frame_t* frame1, float timestep,
+                            uint8_t* out_rgb);
+void rife_hip_frame_release(rife_hip_frame_t* frame);
+
 const char* rife_hip_last_error(void);
 
 /* ---- measurement hooks (bench.py / profiles) ---------------------------------------------------------------

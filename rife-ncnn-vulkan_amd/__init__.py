@@ -22,7 +22,8 @@ _lib = None
 # every symbol include/rife_hip.h declares
 C_ABI_SYMBOLS = [
     "rife_hip_device_count", "rife_hip_create", "rife_hip_destroy", "rife_hip_load", "rife_hip_process",
-    "rife_hip_process_device", "rife_hip_process_batch", "rife_hip_last_error", "rife_hip_profile_enable", "rife_hip_profile_read",
+    "rife_hip_process_device", "rife_hip_process_batch", "rife_hip_frame_upload", "rife_hip_process_frames", "rife_hip_frame_release",
+    "rife_hip_last_error", "rife_hip_profile_enable", "rife_hip_profile_read",
     "rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_graph_check", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
 ]
 
@@ -67,6 +68,9 @@ def lib():
     L.rife_hip_v4_flow_dims.argtypes = [vp, ci, ci, ci, vp, vp, vp]
     L.rife_hip_graph_check.argtypes = [ctypes.c_char_p]
     L.rife_hip_process_batch.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci]
+    L.rife_hip_frame_upload.argtypes = [vp, vp, ci, ci, vp]
+    L.rife_hip_process_frames.argtypes = [vp, vp, vp, cf, vp]
+    L.rife_hip_frame_release.argtypes = [vp]
     L.rife_hip_op_conv3x3.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, ci, vp, vp, vp]
     L.rife_hip_op_deconv4x4.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, vp, vp]
     L.rife_hip_op_warp.argtypes = [ci, vp, vp, ci, ci, ci, vp]
@@ -94,6 +98,20 @@ def graph_check(param_base):
 
 def device_count():
     return lib().rife_hip_device_count()
+
+
+class Frame:
+    """A frame resident in device memory (rife_hip_frame_t): upload once, use as either side of any number of pairs."""
+
+    def __init__(self, handle, w, h):
+        self._f, self.w, self.h = handle, w, h
+
+    def release(self):
+        if getattr(self, "_f", None) and _lib is not None:
+            _lib.rife_hip_frame_release(self._f)
+        self._f = None
+
+    __del__ = release
 
 
 class RIFE:
@@ -126,6 +144,25 @@ class RIFE:
         h, w, _ = a.shape
         out = outimage if outimage is not None else np.empty_like(a)
         _check(lib().rife_hip_process(self._h, _p(a), _p(b), w, h, float(timestep), _p(out)), "process")
+        return out
+
+    def upload(self, image):
+        """Stream mode: copy one (h, w, 3) uint8 frame to the device and keep it there."""
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("frame must be an (h, w, 3) uint8 array")
+        f = ctypes.c_void_p()
+        _check(lib().rife_hip_frame_upload(self._h, _p(a), a.shape[1], a.shape[0], ctypes.byref(f)), "frame_upload")
+        return Frame(f, a.shape[1], a.shape[0])
+
+    def process_frames(self, frame0, frame1, timestep, outimage=None):
+        """process() between two resident frames; same pixels as process() on the host arrays they were uploaded from."""
+        if frame0._f is None or frame1._f is None:
+            raise ValueError("frame was released")
+        out = outimage if outimage is not None else np.empty((frame0.h, frame0.w, 3), np.uint8)
+        if out.shape != (frame0.h, frame0.w, 3) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("outimage must be a contiguous (h, w, 3) uint8 array of the frames' size")
+        _check(lib().rife_hip_process_frames(self._h, frame0._f, frame1._f, float(timestep), _p(out)), "process_frames")
         return out
 
     def process_device(self, d_in0, d_in1, w, h, timestep, d_out, stream=None):

@@ -633,6 +633,35 @@ using namespace rife;
 // ------------------------------------------------------------------------------------------------
 // the engine object behind rife_hip_t
 // ------------------------------------------------------------------------------------------------
+// Device buffers of released resident frames (rife_hip_frame_*), reused by the next upload of the same size: hipFree waits for
+// the whole device, which would stall the pairs in flight every time a frame of a sequence retires.
+struct FramePool {
+    int gpuid = 0;
+    std::mutex mu;
+    std::vector<std::pair<size_t, uint8_t*>> idle;
+    uint8_t* take(size_t nbytes) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].first == nbytes) { uint8_t* p = idle[i].second; idle.erase(idle.begin() + i); return p; }
+        }
+        uint8_t* p = nullptr;
+        return hipMalloc((void**)&p, nbytes) == hipSuccess ? p : nullptr;
+    }
+    void give(uint8_t* p, size_t nbytes) {
+        uint8_t* evict = nullptr;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (idle.size() >= 16) { evict = idle.front().second; idle.erase(idle.begin()); }      // oldest out: sizes may change over time
+            idle.emplace_back(nbytes, p);
+        }
+        if (evict && hipSetDevice(gpuid) == hipSuccess) (void)hipFree(evict);
+    }
+    ~FramePool() {
+        if (!idle.empty() && hipSetDevice(gpuid) == hipSuccess) for (auto& e : idle) (void)hipFree(e.second);
+    }
+};
+
 struct rife_hip {
     int gpuid = 0;
     bool tta = false, tta_temporal = false, uhd = false, v2 = false, v4 = false;
@@ -659,6 +688,8 @@ struct rife_hip {
     mutable std::vector<std::unique_ptr<Ctx>> free_ctx;                  // pool for the host-buffer entry point
     mutable std::map<void*, std::unique_ptr<Ctx>> stream_ctx;            // one workspace per caller stream
     mutable std::mutex tta_mu;                                           // TTA passes share one set of workspaces
+    std::shared_ptr<FramePool> frame_pool;                               // shared with the frames: they may outlive the engine
+    mutable std::vector<hipStream_t> upload_streams;                     // rife_hip_frame_upload: one copy stream per concurrent uploader
     mutable std::unique_ptr<Ctx> tta_ctx[2][8];                          // [direction][orientation]
     static constexpr int NLANE = 4;                                      // spatial TTA: orientations run on 4 worker streams
     mutable hipStream_t tta_lane[NLANE] = {nullptr, nullptr, nullptr, nullptr};
@@ -669,6 +700,7 @@ struct rife_hip {
         free_ctx.clear(); stream_ctx.clear();
         for (auto& d : tta_ctx) for (auto& c : d) c.reset();
         for (auto& l : tta_lane) if (l) (void)hipStreamDestroy(l);
+        for (auto& u : upload_streams) (void)hipStreamDestroy(u);
         for (auto& e : tta_fork) if (e) (void)hipEventDestroy(e);
         for (auto& r : tta_join) for (auto& e : r) if (e) (void)hipEventDestroy(e);
         for (auto& b : blk) { free_layer(b.stem0); free_layer(b.stem1); for (auto& r : b.res) free_layer(r); free_layer(b.head); }
@@ -1604,6 +1636,8 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     rife_hip* E = new rife_hip;
     E->gpuid = gpuid; E->tta = tta_mode; E->tta_temporal = tta_temporal_mode; E->uhd = uhd_mode;
     E->num_threads = num_threads; E->v2 = rife_v2; E->v4 = rife_v4;
+    E->frame_pool = std::make_shared<FramePool>();
+    E->frame_pool->gpuid = gpuid;
     return E;
 }
 
@@ -1802,6 +1836,77 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     for (auto& t : th) t.join();
     for (int k = 0; k < K; k++) if (rcs[k]) { g_err = errs[k]; return rcs[k]; }
     return 0;
+}
+
+// ---- stream mode: frames resident in device memory across calls (include/rife_hip.h) ----
+struct rife_hip_frame {
+    uint8_t* d = nullptr;      // tight u8 HWC RGB, the layout every run_* entry takes
+    int w = 0, h = 0, gpuid = 0;
+    size_t nbytes = 0;
+    std::shared_ptr<FramePool> pool;
+};
+
+int rife_hip_frame_upload(const rife_hip_t* E, const uint8_t* rgb, int w, int h, rife_hip_frame_t** frame) {
+    if (frame) *frame = nullptr;
+    if (!E || !rgb || !frame) return fail(RIFE_HIP_EINVAL, "null argument");
+    if (w <= 0 || h <= 0) return fail(RIFE_HIP_EINVAL, "bad frame size");
+    int rc;
+    if ((rc = check_device(E->gpuid))) return rc;
+    std::unique_ptr<rife_hip_frame> f(new rife_hip_frame);
+    f->w = w; f->h = h; f->gpuid = E->gpuid;
+    const size_t nbytes = (size_t)w * h * 3;
+    f->nbytes = nbytes; f->pool = E->frame_pool;
+    if (!(f->d = f->pool->take(nbytes))) return fail(RIFE_HIP_EHIP, "hipMalloc of a resident frame failed");
+    // a copy on its own stream, drained here: the frame is complete before any stream of any caller can see the handle
+    hipStream_t st = nullptr;
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        if (!E->upload_streams.empty()) { st = E->upload_streams.back(); E->upload_streams.pop_back(); }
+    }
+    hipError_t e = st ? hipSuccess : hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(f->d, rgb, nbytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (st) { std::lock_guard<std::mutex> g(E->mu); E->upload_streams.push_back(st); }
+    if (e != hipSuccess) { f->pool->give(f->d, nbytes); return fail(RIFE_HIP_EHIP, std::string("frame upload: ") + hipGetErrorString(e)); }
+    *frame = f.release();
+    return 0;
+}
+
+void rife_hip_frame_release(rife_hip_frame_t* f) {
+    if (!f) return;
+    if (f->d) f->pool->give(f->d, f->nbytes);
+    delete f;
+}
+
+int rife_hip_process_frames(const rife_hip_t* E, const rife_hip_frame_t* f0, const rife_hip_frame_t* f1, float timestep, uint8_t* out) {
+    if (!f0 || !f1 || !out) return fail(RIFE_HIP_EINVAL, "null frame pointer");
+    if (f0->w != f1->w || f0->h != f1->h) return fail(RIFE_HIP_EINVAL, "the two frames differ in size");
+    const int w = f0->w, h = f0->h;
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (f0->gpuid != E->gpuid || f1->gpuid != E->gpuid) return fail(RIFE_HIP_EINVAL, "frame was uploaded to another device");
+    if ((rc = check_device(E->gpuid))) return rc;
+    const size_t nbytes = (size_t)w * h * 3;
+    if (timestep == 0.f || timestep == 1.f) {                 // rife.cpp:2470-2480
+        HIPCHK(hipMemcpy(out, timestep == 0.f ? f0->d : f1->d, nbytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    std::unique_ptr<Ctx> c;
+    rc = lease_ctx(E, c, w, h);
+    if (!rc) {
+        Ctx& C = *c;
+        if (E->v1) rc = run_v1(*E, C, f0->d, f1->d, C.d_out);
+        else if (!E->v4) rc = run_v2(*E, C, f0->d, f1->d, C.d_out);
+        else if (E->tta || E->tta_temporal) {
+            std::lock_guard<std::mutex> g(E->tta_mu);
+            rc = run_v4_tta(*E, C.stream, f0->d, f1->d, w, h, timestep, C.d_out);
+            if (!rc && hipStreamSynchronize(C.stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "TTA stream sync failed");
+        } else rc = run_v4_replay(*E, C, f0->d, f1->d, timestep, C.d_out);
+        if (!rc && hipMemcpyAsync(out, C.d_out, nbytes, hipMemcpyDeviceToHost, C.stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "D2H failed");
+    }
+    if (c && hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(RIFE_HIP_EHIP, "stream sync failed");
+    if (c) release_ctx(E, c);
+    return rc;
 }
 
 int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* d_in1, int w, int h, float timestep, void* d_out, void* hip_stream) {

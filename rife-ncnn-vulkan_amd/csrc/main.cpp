@@ -248,11 +248,30 @@ static bool encode_image(const std::string& path, int w, int h, const unsigned c
 // ---------------------------------------------------------------------------------------------------------------
 // tasks and queues (src/main.cpp:231-295)
 // ---------------------------------------------------------------------------------------------------------------
+// A decoded frame plus its copies in device memory, one per engine that has needed it so far (uploaded by the first proc thread
+// that does).  The reference uploads both frames in every process() call (src/rife.cpp:2490-2530); in a sequence each frame serves
+// two pairs and, with -n, several timesteps per pair, so the upload happens once here.
+struct SharedFrame {
+    int w = 0, h = 0;
+    std::vector<unsigned char> px;
+    const rife_hip_frame* on(const RIFE* r) {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& e : resident) if (e.first == r) return e.second;
+        rife_hip_frame* f = r->upload(ncnn::Mat(w, h, (void*)px.data(), (size_t)3, 3));
+        if (f) resident.emplace_back(r, f);
+        return f;
+    }
+    ~SharedFrame() { for (auto& e : resident) RIFE::release(e.second); }
+private:
+    std::mutex mu;
+    std::vector<std::pair<const RIFE*, rife_hip_frame*>> resident;
+};
+
 struct Task {
     int id = 0;
     float timestep = 0.5f;
     std::string in0path, in1path, outpath;
-    std::shared_ptr<const std::vector<unsigned char>> px0, px1;      // decoded frames are shared between the tasks that use them
+    std::shared_ptr<SharedFrame> fr0, fr1;                            // decoded frames are shared between the tasks that use them
     std::vector<unsigned char> out;
     int w = 0, h = 0;
 };
@@ -262,23 +281,23 @@ struct Task {
 // decodes per task (src/main.cpp:315-334); this keeps the last few decoded frames.
 class FrameCache {
 public:
-    struct Frame { int w = 0, h = 0; std::shared_ptr<const std::vector<unsigned char>> px; };
+    typedef std::shared_ptr<SharedFrame> Frame;
     template <class Decode>
     bool get(const std::string& path, Frame& f, Decode decode) {
         {
             std::lock_guard<std::mutex> g(mu);
             for (auto& e : entries) if (e.first == path) { f = e.second; return true; }
         }
-        auto px = std::make_shared<std::vector<unsigned char>>();
-        Frame n;
-        if (!decode(path, n.w, n.h, *px)) return false;
-        n.px = px;
+        Frame n = std::make_shared<SharedFrame>();
+        if (!decode(path, n->w, n->h, n->px)) return false;
         std::lock_guard<std::mutex> g(mu);
+        for (auto& e : entries) if (e.first == path) { f = e.second; return true; }     // another loader decoded it meanwhile: keep one copy
         entries.emplace_back(path, n);
         if (entries.size() > 6) entries.erase(entries.begin());
         f = n;
         return true;
     }
+    void clear() { std::lock_guard<std::mutex> g(mu); entries.clear(); }
 private:
     std::mutex mu;
     std::vector<std::pair<std::string, Frame>> entries;
@@ -491,8 +510,8 @@ int main(int argc, char** argv) {
             Task t = std::move(tasks[k]);
             FrameCache::Frame f0, f1;
             if (!cache.get(t.in0path, f0, decode_image) || !cache.get(t.in1path, f1, decode_image)) { fprintf(stderr, "decode image %s or %s failed\n", t.in0path.c_str(), t.in1path.c_str()); continue; }
-            if (f1.w != f0.w || f1.h != f0.h) { fprintf(stderr, "%s and %s differ in size\n", t.in0path.c_str(), t.in1path.c_str()); continue; }
-            t.w = f0.w; t.h = f0.h; t.px0 = f0.px; t.px1 = f1.px;
+            if (f1->w != f0->w || f1->h != f0->h) { fprintf(stderr, "%s and %s differ in size\n", t.in0path.c_str(), t.in1path.c_str()); continue; }
+            t.w = f0->w; t.h = f0->h; t.fr0 = f0; t.fr1 = f1;
             toproc.put(std::move(t));
         }
     };
@@ -500,10 +519,15 @@ int main(int argc, char** argv) {
         for (;;) {
             Task t = toproc.get();
             if (t.id == -233) return;                                          // end marker, like the reference
-            ncnn::Mat in0(t.w, t.h, (void*)t.px0->data(), (size_t)3, 3), in1(t.w, t.h, (void*)t.px1->data(), (size_t)3, 3);
-            ncnn::Mat out(t.w, t.h, (size_t)3, 3);
-            if (r->process(in0, in1, t.timestep, out) != 0) { fprintf(stderr, "process %s failed: %s\n", t.outpath.c_str(), rife_hip_last_error()); continue; }
-            t.out.assign((const unsigned char*)out.data, (const unsigned char*)out.data + (size_t)t.w * t.h * 3);
+            if (t.timestep == 0.f || t.timestep == 1.f) t.out = (t.timestep == 0.f ? t.fr0 : t.fr1)->px;      // rife.cpp:2470-2480: an input frame, unchanged
+            else {
+                const rife_hip_frame* d0 = t.fr0->on(r);
+                const rife_hip_frame* d1 = t.fr1->on(r);
+                t.out.resize((size_t)t.w * t.h * 3);
+                ncnn::Mat out(t.w, t.h, (void*)t.out.data(), (size_t)3, 3);
+                if (!d0 || !d1 || r->process(d0, d1, t.timestep, out) != 0) { fprintf(stderr, "process %s failed: %s\n", t.outpath.c_str(), rife_hip_last_error()); continue; }
+            }
+            t.fr0.reset(); t.fr1.reset();                                      // the save stage needs only the output
             tosave.put(std::move(t));
         }
     };
@@ -525,6 +549,7 @@ int main(int argc, char** argv) {
     for (auto& t : procs) t.join();
     for (size_t i = 0; i < savers.size(); i++) { Task e; e.id = -233; tosave.put(std::move(e)); }
     for (auto& t : savers) t.join();
+    cache.clear();                                                             // resident frames go before their engines
     for (RIFE* r : rife) delete r;
     return 0;
 }

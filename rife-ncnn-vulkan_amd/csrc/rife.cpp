@@ -56,6 +56,30 @@ int RIFE::process(const ncnn::Mat& in0image, const ncnn::Mat& in1image, float ti
     return ret;
 }
 
+rife_hip_frame* RIFE::upload(const ncnn::Mat& image) const
+{
+    if (!engine || !image.data) return 0;
+    rife_hip_frame* f = 0;
+    if (rife_hip_frame_upload(engine, (const unsigned char*)image.data, image.w, image.h, &f))
+        fprintf(stderr, "RIFE::upload: %s\n", rife_hip_last_error());
+    return f;
+}
+
+int RIFE::process(const rife_hip_frame* frame0, const rife_hip_frame* frame1, float timestep, ncnn::Mat& outimage) const
+{
+    if (!engine) return -RIFE_HIP_ENODEV;
+    if (!outimage.data) return -RIFE_HIP_EINVAL;
+    // the engine checks the two frames against each other; outimage must be the caller's w x h x 3 buffer as in main.cpp:332
+    int ret = rife_hip_process_frames(engine, frame0, frame1, timestep, (unsigned char*)outimage.data);
+    if (ret) fprintf(stderr, "RIFE::process: %s\n", rife_hip_last_error());
+    return ret;
+}
+
+void RIFE::release(rife_hip_frame* frame)
+{
+    rife_hip_frame_release(frame);
+}
+
 int RIFE::process_v4(const ncnn::Mat& in0image, const ncnn::Mat& in1image, float timestep, ncnn::Mat& outimage) const
 {
     return process(in0image, in1image, timestep, outimage);

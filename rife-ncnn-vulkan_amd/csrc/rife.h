@@ -9,6 +9,7 @@
 #include "ncnn_mat.h"
 
 struct rife_hip;
+struct rife_hip_frame;
 
 class RIFE
 {
@@ -25,6 +26,12 @@ public:
     int process_cpu(const ncnn::Mat& in0image, const ncnn::Mat& in1image, float timestep, ncnn::Mat& outimage) const;
     int process_v4(const ncnn::Mat& in0image, const ncnn::Mat& in1image, float timestep, ncnn::Mat& outimage) const;
     int process_v4_cpu(const ncnn::Mat& in0image, const ncnn::Mat& in1image, float timestep, ncnn::Mat& outimage) const;
+
+    // Extension, not in the reference (include/rife_hip.h "stream mode"): a frame uploaded once and used by several process()
+    // calls - consecutive pairs share a frame, and every timestep of a pair shares both.  Same pixels as the host-buffer call.
+    rife_hip_frame* upload(const ncnn::Mat& image) const;
+    int process(const rife_hip_frame* frame0, const rife_hip_frame* frame1, float timestep, ncnn::Mat& outimage) const;
+    static void release(rife_hip_frame* frame);
 
 private:
     RIFE(const RIFE&);

@@ -1,0 +1,76 @@
+"""Stream mode (rife_hip_frame_upload / rife_hip_process_frames / rife_hip_frame_release): frames uploaded once
+and shared by consecutive pairs give exactly the pixels of the host-buffer call, for every model family and mode."""
+import importlib
+import threading
+
+import numpy as np
+import pytest
+
+from tools import gen_frames
+
+pytestmark = pytest.mark.gpu
+amd = importlib.import_module("rife-ncnn-vulkan_amd")
+
+CASES = [("rife-v4.6", {}), ("rife-v4.6", dict(tta_mode=True, tta_temporal_mode=True)), ("rife-v4", {}), ("rife-v2.3", {}),
+         ("rife-v2.3", dict(uhd_mode=True)), ("rife-v3.1", {}), ("rife", {}), ("rife-HD", {})]
+
+
+def _engine(modeldirs, fam, kw):
+    fl = dict(kw, rife_v2=fam.startswith(("rife-v2", "rife-v3")), rife_v4=fam.startswith("rife-v4"))
+    g = amd.RIFE(0, **fl)
+    g.load(modeldirs[fam])
+    return g
+
+
+@pytest.mark.parametrize("fam,kw", CASES)
+def test_sequence_through_resident_frames_equals_host_calls(modeldirs, fam, kw):
+    g = _engine(modeldirs, fam, kw)
+    frames = [gen_frames.smooth_pair(192, 128, 300 + i)[0] for i in range(4)]
+    res = [g.upload(f) for f in frames]
+    for i in range(3):
+        for t in (0.5, 0.25):
+            want = g.process(frames[i], frames[i + 1], t)
+            got = g.process_frames(res[i], res[i + 1], t)
+            assert np.array_equal(got, want), (fam, i, t)
+    # the reference's early-outs (rife.cpp:2470-2480)
+    assert np.array_equal(g.process_frames(res[0], res[1], 0.0), frames[0])
+    assert np.array_equal(g.process_frames(res[0], res[1], 1.0), frames[1])
+    for r in res:
+        r.release()
+
+
+def test_resident_frames_shared_by_concurrent_calls(modeldirs):
+    """One frame is the second frame of one pair and the first frame of the next while both are in flight."""
+    g = _engine(modeldirs, "rife-v4.6", {})
+    frames = [gen_frames.smooth_pair(256, 160, 320 + i)[0] for i in range(5)]
+    want = [g.process(frames[i], frames[i + 1], 0.5) for i in range(4)]
+    res = [g.upload(f) for f in frames]
+    got = [None] * 4
+
+    def work(i):
+        got[i] = g.process_frames(res[i], res[i + 1], 0.5)
+    for _ in range(3):
+        th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        [t.start() for t in th]; [t.join() for t in th]
+        for i in range(4):
+            assert np.array_equal(got[i], want[i]), i
+
+
+def test_frame_errors_and_lifetime(modeldirs):
+    g = _engine(modeldirs, "rife-v4.6", {})
+    a = g.upload(gen_frames.smooth_pair(64, 64, 1)[0])
+    b = g.upload(gen_frames.smooth_pair(96, 64, 1)[0])
+    with pytest.raises(amd.RifeError, match="differ in size"):
+        g.process_frames(a, b, 0.5)
+    b.release()
+    with pytest.raises(ValueError):
+        g.process_frames(a, b, 0.5)
+    # buffers of released frames are recycled; a frame may outlive its engine
+    for i in range(40):
+        f = g.upload(gen_frames.smooth_pair(64, 64, i)[0])
+        f.release()
+    c = g.upload(gen_frames.smooth_pair(64, 64, 2)[0])
+    ref = g.process(gen_frames.smooth_pair(64, 64, 1)[0], gen_frames.smooth_pair(64, 64, 2)[0], 0.5)
+    assert np.array_equal(g.process_frames(a, c, 0.5), ref)
+    del g
+    a.release(); c.release()
