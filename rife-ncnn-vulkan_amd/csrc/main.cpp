@@ -15,6 +15,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -133,24 +135,73 @@ static void put_chunk(std::vector<unsigned char>& out, const char* typ, const un
     out.insert(out.end(), c, c + 4);
 }
 
-static bool encode_png(const std::string& path, int w, int h, const unsigned char* rgb) {
+// Helper threads one encode_png() call may use besides its own (set in main() from the core count and the -j settings).
+static int g_png_helpers = 0;
+
+// One band of rows: filter "up" (cheap and effective on video frames; the first row of the image has no row above) and raw deflate.
+// Every band but the last ends with a sync flush, i.e. on a byte boundary, so the bands concatenate into one valid deflate stream -
+// the bands share no history, which costs a little ratio and lets them run on separate cores.
+static bool png_deflate_band(const unsigned char* rgb, int w, int y0, int y1, bool last, std::vector<unsigned char>& comp, uLong& adler) {
     const size_t stride = (size_t)w * 3;
-    std::vector<unsigned char> raw((stride + 1) * h);
-    for (int y = 0; y < h; y++) {              // filter "up": cheap and effective on video frames
-        unsigned char* dst = &raw[(stride + 1) * y];
+    std::vector<unsigned char> raw((stride + 1) * (size_t)(y1 - y0));
+    for (int y = y0; y < y1; y++) {
+        unsigned char* dst = &raw[(stride + 1) * (size_t)(y - y0)];
         const unsigned char* cur = rgb + stride * y;
         const unsigned char* up = y ? rgb + stride * (y - 1) : nullptr;
         dst[0] = up ? 2 : 0;
-        for (size_t x = 0; x < stride; x++) dst[1 + x] = (unsigned char)(cur[x] - (up ? up[x] : 0));
+        if (up) for (size_t x = 0; x < stride; x++) dst[1 + x] = (unsigned char)(cur[x] - up[x]);
+        else std::memcpy(dst + 1, cur, stride);
     }
-    uLongf clen = compressBound((uLong)raw.size());
-    std::vector<unsigned char> comp(clen);
-    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 3) != Z_OK) return false;
+    adler = adler32(adler32(0L, Z_NULL, 0), raw.data(), (uInt)raw.size());
+    z_stream z;
+    std::memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, 3, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    comp.resize(deflateBound(&z, (uLong)raw.size()) + 16);
+    z.next_in = raw.data(); z.avail_in = (uInt)raw.size();
+    z.next_out = comp.data(); z.avail_out = (uInt)comp.size();
+    const int rc = deflate(&z, last ? Z_FINISH : Z_SYNC_FLUSH);
+    const bool ok = last ? rc == Z_STREAM_END : (rc == Z_OK && z.avail_in == 0 && z.avail_out != 0);
+    comp.resize(comp.size() - z.avail_out);
+    deflateEnd(&z);
+    return ok;
+}
+
+static bool encode_png(const std::string& path, int w, int h, const unsigned char* rgb) {
+    const size_t stride = (size_t)w * 3;
+    // bands of about 1 MB of pixels, at most 64 (a band must stay below the 4 GB zlib counts in any case)
+    int nband = (int)std::min<size_t>(64, std::max<size_t>(1, stride * h >> 20));
+    nband = std::min(nband, h);
+    std::vector<std::vector<unsigned char>> comp(nband);
+    std::vector<uLong> adler(nband);
+    std::vector<size_t> rawlen(nband);
+    std::vector<char> good(nband, 0);
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (int b; (b = next.fetch_add(1)) < nband;) {
+            const int y0 = (int)((long long)h * b / nband), y1 = (int)((long long)h * (b + 1) / nband);
+            rawlen[b] = (stride + 1) * (size_t)(y1 - y0);
+            good[b] = png_deflate_band(rgb, w, y0, y1, b == nband - 1, comp[b], adler[b]);
+        }
+    };
+    std::vector<std::thread> helpers;
+    for (int i = 0; i < std::min(g_png_helpers, nband - 1); i++) helpers.emplace_back(work);
+    work();
+    for (auto& t : helpers) t.join();
+    std::vector<unsigned char> zs = {0x78, 0x5e};                       // zlib header: deflate, 32 KB window, "fast" level hint
+    uLong ad = adler32(0L, Z_NULL, 0);
+    for (int b = 0; b < nband; b++) {
+        if (!good[b]) return false;
+        zs.insert(zs.end(), comp[b].begin(), comp[b].end());
+        ad = adler32_combine(ad, adler[b], (z_off_t)rawlen[b]);
+    }
+    for (int i = 3; i >= 0; i--) zs.push_back((unsigned char)(ad >> (8 * i)));
+    const unsigned char* const comp_data = zs.data();
+    const size_t clen = zs.size();
     std::vector<unsigned char> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     unsigned char ihdr[13] = {(unsigned char)(w >> 24), (unsigned char)(w >> 16), (unsigned char)(w >> 8), (unsigned char)w,
                               (unsigned char)(h >> 24), (unsigned char)(h >> 16), (unsigned char)(h >> 8), (unsigned char)h, 8, 2, 0, 0, 0};
     put_chunk(out, "IHDR", ihdr, 13);
-    put_chunk(out, "IDAT", comp.data(), clen);
+    put_chunk(out, "IDAT", comp_data, clen);
     put_chunk(out, "IEND", nullptr, 0);
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) return false;
@@ -378,6 +429,7 @@ int main(int argc, char** argv) {
     if (argc == 4 && std::string(argv[1]) == "--transcode") {
         int w = 0, h = 0;
         std::vector<unsigned char> rgb;
+        g_png_helpers = std::max(0, std::min(15, (int)std::thread::hardware_concurrency() - 1));
         if (!decode_image(argv[2], w, h, rgb)) { fprintf(stderr, "decode image %s failed\n", argv[2]); return 1; }
         const bool ok = encode_image(argv[3], w, h, rgb.data());
         if (!ok) { fprintf(stderr, "encode image %s failed\n", argv[3]); return 1; }
@@ -486,9 +538,18 @@ int main(int argc, char** argv) {
         return -1;
     }
 
+    // RIFE_HIP_CLI_TIMING=1: one summary line on stderr that separates start-up (HIP init + model load) from the pipeline
+    const bool timing = getenv("RIFE_HIP_CLI_TIMING") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     // ---- devices (src/main.cpp:774-828) ----
     if (gpuid.empty()) gpuid.push_back(0);
     if (jobs_proc.empty()) jobs_proc.assign(gpuid.size(), 2);
+    {   // cores the load / proc threads do not need are lent to the PNG encoders (band-parallel deflate), at most 15 helpers per save thread
+        int busy = jobs_load;
+        for (int j : jobs_proc) busy += j;
+        const int spare = (int)std::thread::hardware_concurrency() - busy;
+        g_png_helpers = std::max(0, std::min(15, spare / jobs_save - 1));
+    }
     const int ndev = rife_hip_device_count();
     for (int g : gpuid) if (g < 0 || g >= ndev) { fprintf(stderr, "invalid gpu device\n"); return -1; }
     std::vector<RIFE*> rife;
@@ -498,6 +559,7 @@ int main(int argc, char** argv) {
         rife.push_back(r);
     }
 
+    const auto tp1 = std::chrono::steady_clock::now();
     // ---- load -> proc -> save (src/main.cpp:309-436, 830-904) ----
     TaskQueue toproc, tosave;
     FrameCache cache;
@@ -549,6 +611,11 @@ int main(int argc, char** argv) {
     for (auto& t : procs) t.join();
     for (size_t i = 0; i < savers.size(); i++) { Task e; e.id = -233; tosave.put(std::move(e)); }
     for (auto& t : savers) t.join();
+    if (timing) {
+        const auto tp2 = std::chrono::steady_clock::now();
+        const double a = std::chrono::duration<double>(tp1 - tp0).count(), b = std::chrono::duration<double>(tp2 - tp1).count();
+        fprintf(stderr, "timing: devices + model load %.3f s, pipeline %.3f s for %zu frames = %.1f frames/s\n", a, b, tasks.size(), tasks.size() / b);
+    }
     cache.clear();                                                             // resident frames go before their engines
     for (RIFE* r : rife) delete r;
     return 0;

@@ -151,6 +151,16 @@ def test_cpp_cli_png_and_ppm_codecs_round_trip(tmp_path):
             p = subprocess.run([RIFE_HIP, "--transcode", str(src), str(dst)], capture_output=True, text=True)
             assert p.returncode == 0, (name, ext, p.stderr)
             assert np.array_equal(np.asarray(Image.open(dst).convert("RGB")), want), (name, ext)
+    # a frame big enough for several deflate bands (the PNG writer compresses ~1 MB bands on helper threads and concatenates them)
+    big = np.kron(gen_frames.smooth_pair(320, 180, 5)[0], np.ones((4, 4, 1), np.uint8)) + gen_frames.noise_pair(1280, 720, 6)[0] % 3
+    Image.fromarray(big).save(tmp_path / "big.ppm")
+    p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "big.ppm"), str(tmp_path / "big.png")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    im = Image.open(tmp_path / "big.png")
+    im.verify()                                                            # chunk CRCs
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "big.png").convert("RGB")), big)       # zlib stream incl. the combined Adler-32
+    p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "big.png"), str(tmp_path / "big2.ppm")], capture_output=True, text=True)
+    assert p.returncode == 0 and np.array_equal(np.asarray(Image.open(tmp_path / "big2.ppm")), big)
     Image.fromarray(a).save(tmp_path / "in.webp", lossless=True)          # WebP decode (lossless source -> exact pixels)
     p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "in.webp"), str(tmp_path / "from_webp.png")], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
