@@ -2160,6 +2160,140 @@ int rife_hip_probe_f16_denorm(int gpuid, float* out) {
     return 0;
 }
 
+// bench-only: what the matrix pipe alone sustains, on random operands, for the instruction mix of one 32 px x 64 ch trunk tile
+// (64 input channels x 10 taps): MIX 0 = today's 80 + 80 v_mfma_f32_32x32x16_f16 (hi + lo), MIX 1 = 80 f16 (hi) + 20
+// v_mfma_scale_f32_32x32x64_f8f6f4 (lo as scaled fp8), MIX 2 = the 80 hi instructions alone, MIX 3 = 80 f16 (hi) + 80 v_mfma_f32_32x32x16_fp8_fp8 (lo).  16 waves per CU like conv_h2b.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+extern "C++" {
+template <int MIX>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bench_mfma_mix(const int* __restrict__ src, float* out, int tiles) {
+    const int tid = threadIdx.x;
+    f16x8 wa[4], xb[4];
+    i32x8 wq[2], xq[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int4 v = reinterpret_cast<const int4*>(src)[(i * 512 + tid) & 4095];
+        wa[i] = *reinterpret_cast<f16x8*>(&v);
+        v = reinterpret_cast<const int4*>(src)[(2048 + i * 512 + tid) & 4095];
+        xb[i] = *reinterpret_cast<f16x8*>(&v);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            wq[i][j] = src[(i * 4096 + j * 512 + tid) & 16383] & 0x7f7f7f7f;      // positive fp8 bytes below NaN
+            xq[i][j] = src[(8192 + i * 4096 + j * 512 + tid) & 16383] & 0x7f7f7f7f;
+        }
+    f32x16 acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+    for (int t = 0; t < tiles; t++) {
+#pragma unroll
+        for (int k = 0; k < 40; k++) {
+#pragma unroll
+            for (int n = 0; n < 2; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[(k + n) & 3], xb[k & 3], acc[n], 0, 0, 0);
+            if (MIX == 0) {
+#pragma unroll
+                for (int n = 0; n < 2; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[(k + n + 1) & 3], xb[(k + 2) & 3], acc[n], 0, 0, 0);
+            }
+            if (MIX == 3) {
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(((long)wq[n][(k & 3) * 2 + 1] << 32) | (unsigned)wq[n][(k & 3) * 2],
+                                                                        ((long)xq[k & 1][((k >> 1) & 3) * 2 + 1] << 32) | (unsigned)xq[k & 1][((k >> 1) & 3) * 2], acc[n], 0, 0, 0);
+            }
+            if (MIX == 1 && (k & 3) == 3) {
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[n], xq[(k >> 2) & 1], acc[n], 0, 0, 0, 127 - 9, 0, 127 - 13);
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) sum += acc[n][r];
+    if (sum == 123.456f) out[0] = sum;
+}
+}  // extern "C++"
+
+// probe: fp8 conventions of gfx950 (OCP e4m3fn expected: 0x38 = 1.0, 0x7e = 448) for the conversion and both fp8 MFMA flavours
+__global__ void k_probe_fp8(float* out) {
+    const int lane = threadIdx.x;
+    const long a1 = 0x3838383838383838L, b2 = 0x4040404040404040L;        // 1.0 x 2.0 in e4m3fn, K = 16 -> 32
+    f32x16 c;
+    for (int r = 0; r < 16; r++) c[r] = 0.f;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b2, c, 0, 0, 0);
+    const int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(1.0f, 448.0f, 0, false);
+    const int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(1000.0f, -0.3f, 0, false);
+    const int p2 = __builtin_amdgcn_cvt_pk_fp8_f32(0.001953125f, 0.0009765625f, 0, false);      // 2^-9 (min subnormal), 2^-10
+    i32x8 a8, b8;
+    for (int j = 0; j < 8; j++) { a8[j] = 0x38383838; b8[j] = 0x40404040; }
+    f32x16 d;
+    for (int r = 0; r < 16; r++) d[r] = 0.f;
+    d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, d, 0, 0, 0, 127 - 3, 0, 127 + 1);        // 64 * 2 * 2^-3 * 2^1 = 32
+    // lane-dependent operands: which k goes with which k (legacy fp8, K = 16): A = 1.0 everywhere, B byte j of lane half g = 2^(j + 8 g - 6)?  too wide:
+    // use B byte j = 1.0 only for j == 3, half 1 -> result must equal A's byte (j = 3, half 1) value for every A pattern
+    long aj = 0, bj = 0;
+    for (int j = 0; j < 8; j++) aj |= (long)(0x30 + 8 * ((j + (lane >> 5) * 3) & 3)) << (8 * j);       // 0.5, 1, 2, 4 patterns
+    if (lane >= 32) bj = 0x38L << 24;
+    f32x16 e;
+    for (int r = 0; r < 16; r++) e[r] = 0.f;
+    e = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(aj, bj, e, 0, 0, 0);
+    if (lane == 0) {
+        out[0] = c[0]; out[1] = (float)(p0 & 0xffff); out[2] = (float)(p1 & 0xffff); out[3] = (float)(p2 & 0xffff); out[4] = d[0]; out[5] = e[0];
+    }
+}
+
+int rife_hip_probe_fp8(int gpuid, float* out6) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    float* d = nullptr;
+    HIPCHK(hipMalloc(&d, 24));
+    hipLaunchKernelGGL(k_probe_fp8, dim3(1), dim3(64), 0, 0, d);
+    HIPCHK(hipMemcpy(out6, d, 24, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
+}
+
+int rife_hip_bench_mfma_mix(int gpuid, int mix, int tiles, int iters, float* ms_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    std::vector<int> h(16384);
+    uint32_t lcg = 777u;
+    for (auto& v : h) {                                  // pairs of f16 in [-1, 1): exponent field 0x30..0x3b, random sign and mantissa
+        uint32_t w = 0;
+        for (int k = 0; k < 2; k++) {
+            lcg = lcg * 1664525u + 1013904223u;
+            const uint32_t e = 0x0c + ((lcg >> 28) % 3), m = (lcg >> 8) & 0x3ff, sg = (lcg >> 27) & 1;
+            w |= ((sg << 15) | (e << 10) | m) << (16 * k);
+        }
+        v = (int)w;
+    }
+    int* d = nullptr; float* o = nullptr;
+    HIPCHK(hipMalloc(&d, h.size() * 4)); HIPCHK(hipMalloc(&o, 4));
+    HIPCHK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto launch = [&]() {
+        if (mix == 0) hipLaunchKernelGGL(k_bench_mfma_mix<0>, dim3(512), dim3(512), 0, 0, d, o, tiles);
+        else if (mix == 1) hipLaunchKernelGGL(k_bench_mfma_mix<1>, dim3(512), dim3(512), 0, 0, d, o, tiles);
+        else if (mix == 3) hipLaunchKernelGGL(k_bench_mfma_mix<3>, dim3(512), dim3(512), 0, 0, d, o, tiles);
+        else hipLaunchKernelGGL(k_bench_mfma_mix<2>, dim3(512), dim3(512), 0, 0, d, o, tiles);
+    };
+    for (int i = 0; i < 3; i++) launch();
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) launch();
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipFree(d); (void)hipFree(o); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
 // bench-only: ablations of the split-f16 trunk kernel (variant bits: 256 no stores, 512 no prefetch loads, 1024 no barriers,
 // 2048 no LDS staging writes after the first chunk; all but 0/256 compute garbage — timing only)
 int rife_hip_bench_h2b(int gpuid, int h, int w, int variant, int iters, float* ms_out) {

@@ -1,0 +1,102 @@
+"""CPU simulation of reduced-precision operand schemes for the trunk convolutions of rife-v4.6.
+
+The HIP trunk kernels feed the f16 matrix pipe with activations split as a = hi + lo (hi = f16(a), lo = f16(a - hi)) and f16 weights
+(exact: the weights are stored as fp16 on disk).  This script asks what happens to the final u8 frame when the `lo` product runs
+at lower precision (fp8 e4m3 / e5m2 operands for BOTH lo and the weights of the lo product), or is dropped, by evaluating the whole
+graph in PyTorch with the operands of every 3x3 stride-1 Cin == Cout trunk convolution rounded accordingly and fp32 accumulation.
+
+usage: python tools/sim_split_precision.py [w h]      (default 640 360: the reference's images tiled / cropped to that size)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch_graph  # noqa: E402
+from tools import gen_frames, gen_models  # noqa: E402
+
+torch.set_num_threads(max(1, os.cpu_count() or 1))
+SCHEME = {"name": "exact"}
+LO_SCALE = 2.0 ** float(os.environ.get("LO_SCALE_LOG2", "11"))          # lo <= 2^-11 |a|, so lo * 2^11 <= |a|: only |a| > 448 saturates e4m3
+
+
+def q8(x, dtype, scale):
+    lim = 448.0 if dtype == torch.float8_e4m3fn else 57344.0
+    return (x * scale).clamp(-lim, lim).to(dtype).float() / scale
+
+
+def trunk_conv(x, w, b, stride=1, padding=0):
+    s = SCHEME["name"]
+    is_trunk = w.shape[0] == w.shape[1] and w.shape[2] == 3 and stride == 1 and w.shape[0] >= 64
+    if s == "exact" or not is_trunk:
+        return REAL_CONV(x, w, b, stride=stride, padding=padding)
+    hi = x.half().float()
+    if s == "hi":
+        return REAL_CONV(hi, w, b, stride=stride, padding=padding)
+    lo = x - hi
+    if s == "gpu_fp8":
+        # what conv_h2c does: f16 weights carry 2^k (k <= 15 so that the identity tap 2^k stays finite), lo * 2^9 and w * 2^(k-9) go
+        # through e4m3, one shared accumulator; the folded skip tap sees hi + lo_q, so the residual stream is rounded too
+        k = min(15, int(np.floor(np.log2(65504.0 / max(float(w.abs().max()), 1.0)))))
+        lo_q = q8(lo, torch.float8_e4m3fn, 2.0 ** 9)
+        w_q = q8(w, torch.float8_e4m3fn, 2.0 ** (k - 9))
+        y = REAL_CONV(hi, w, b, stride=stride, padding=padding) + REAL_CONV(lo_q, w_q, None, stride=stride, padding=padding)
+        x.copy_(hi + lo_q)            # the Split alias that feeds the residual add
+        return y
+    if s == "hi+lo_f16":
+        lo_q, w_q = lo.half().float(), w
+    else:
+        dt = torch.float8_e4m3fn if "e4m3" in s else torch.float8_e5m2
+        lo_q = q8(lo, dt, LO_SCALE)
+        wmax = float(w.abs().max())
+        ws = 2.0 ** np.floor(np.log2((448.0 if dt == torch.float8_e4m3fn else 57344.0) / max(wmax, 1e-30)))     # one power-of-two scale per layer
+        w_q = q8(w, dt, ws) if "w8" in s else w
+    return REAL_CONV(hi, w, b, stride=stride, padding=padding) + REAL_CONV(lo_q, w_q, None, stride=stride, padding=padding)
+
+
+REAL_CONV = F.conv2d
+torch_graph.F.conv2d = trunk_conv
+
+
+def run(net, a, b, t):
+    h, w, _ = a.shape
+    wp, hp = (w + 31) // 32 * 32, (h + 31) // 32 * 32
+
+    def chw(img):
+        x = np.zeros((3, hp, wp), np.float32)
+        x[:, :h, :w] = (img.astype(np.float32) * np.float32(1 / 255.0)).transpose(2, 0, 1)
+        return torch.from_numpy(x)
+    outs = net.run({"in0": chw(a), "in1": chw(b), "in2": torch.full((1, hp, wp), np.float32(t))}, ["flow3", "out0"])
+    o = outs[1][:, :h, :w] * 255.0 + 0.5
+    return outs[0].numpy(), o.to(torch.int32).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()
+
+
+def main():
+    w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (640, 360)
+    d = gen_models.ensure(None, "rife-v4.6")
+    net = torch_graph.TorchNet(os.path.join(d, "flownet.param"), os.path.join(d, "flownet.bin"))
+    pairs = {"F2 smooth": gen_frames.smooth_pair(w, h, 1000), "F3 noise": gen_frames.noise_pair(w, h, 7)}
+    try:
+        pairs["F1 real"] = gen_frames.real_pair(w, h)
+    except Exception:
+        pass
+    schemes = os.environ.get("SCHEMES", "hi,hi+lo_f16,hi+lo_e4m3_w8,gpu_fp8").split(",")
+    for name, (a, b) in pairs.items():
+        for t in (0.5, 0.25):
+            SCHEME["name"] = "exact"
+            f_ref, u_ref = run(net, a, b, t)
+            for s in schemes:
+                SCHEME["name"] = s
+                f, u = run(net, a, b, t)
+                dd = np.abs(u.astype(int) - u_ref.astype(int))
+                print("%-10s t=%.2f %-16s flow max err %.2e   u8: max %d, ==1: %.5f %%, >=2: %d channels" %
+                      (name, t, s, np.abs(f - f_ref).max(), dd.max(), 100.0 * (dd == 1).mean(), int((dd >= 2).sum())), flush=True)
+
+
+if __name__ == "__main__":
+    main()
