@@ -580,21 +580,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// conv_h2b_kernel: conv_h2_kernel re-balanced for two workgroups per CU (16 waves): the input tile is double
+// conv_h2b_kernel: conv_h2_kernel re-balanced for two workgroups per CU (16 waves; ROWS = 4: three workgroups of 4 waves, for
+// layers whose 8-row tiles would leave most CUs empty): the input tile is double
 // buffered, the weight slab is not (2 x 27.2 KB + 20.5 KB = 75 KB), so a second workgroup's matrix work covers this
 // one's load latency, barriers, prologue and epilogue.  One register set; the input prefetch of chunk k+2 is issued
 // as soon as chunk k+1 has been written to LDS (mid-chunk), the weight prefetch right after the weight slab swap.
 // ------------------------------------------------------------------------------------------------------------
-template <int NS, int NTAPS>
-constexpr int convh2b_lds_bytes() { return 2 * 10 * 34 * 80 + NTAPS * 2 * NS * 32 * 16; }
+template <int NS, int NTAPS, int ROWS = 8>
+constexpr int convh2b_lds_bytes() { return 2 * (ROWS + 2) * 34 * 80 + NTAPS * 2 * NS * 32 * 16; }
 
-template <int NS, int NTAPS, int TAG>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_h2b_kernel(ConvArgs a) {
-    constexpr int IH = 10, IW = 34, CC = 16, NT = NS * 32;
+template <int NS, int NTAPS, int TAG, int ROWS = 8>
+__global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_h2b_kernel(ConvArgs a) {
+    constexpr int IH = ROWS + 2, IW = 34, CC = 16, NT = NS * 32;
+    constexpr int NTHR = ROWS * 64;                            // one wave per output row of the tile
     constexpr int PIXB = 80;
     constexpr int IN_F4 = IH * IW * 4;
     constexpr int W_16 = NTAPS * 2 * NT;
-    constexpr int NIN = (IN_F4 + 511) / 512, NW = (W_16 + 511) / 512;
+    constexpr int NIN = (IN_F4 + NTHR - 1) / NTHR, NW = (W_16 + NTHR - 1) / NTHR;
     constexpr int INB = IH * IW * PIXB;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* const lw = ldsb + 2 * INB;
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int L2 = L / a.nsplit;
     const int tile = L2 / a.nz, ntile = L2 - tile * a.nz;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int oy0 = ty * 8, ox0 = tx * 32;
+    const int oy0 = ty * ROWS, ox0 = tx * 32;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const int chunks_per = (a.nchunks + a.nsplit - 1) / a.nsplit;
     const int chb = split * chunks_per;                // first chunk of this slice
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     unsigned inside = 0;
 #pragma unroll
     for (int k = 0; k < NIN; k++) {
-        const int idx = tid + k * 512;
+        const int idx = tid + k * NTHR;
         const int p = idx >> 2, q = idx & 3;
         const int py = p / IW, px = p - py * IW;
         const int gy = iy0 + py, gx = ix0 + px;
@@ -637,12 +639,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     _Pragma("unroll") for (int k = 0; k < NIN; k++) rin[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC);
 #define H2B_ISSUE_W(CH)                                                                                     \
     _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                        \
-        const int idx = tid + k * 512;                                                                      \
-        rw[k] = wsrc[(size_t)(CH) * W_16 + ((W_16 % 512 == 0 || idx < W_16) ? idx : 0)];                    \
+        const int idx = tid + k * NTHR;                                                                      \
+        rw[k] = wsrc[(size_t)(CH) * W_16 + ((W_16 % NTHR == 0 || idx < W_16) ? idx : 0)];                    \
     }
 #define H2B_WRITE_IN(BUFP)                                                                                  \
     _Pragma("unroll") for (int k = 0; k < NIN; k++) {                                                       \
-        const int idx = tid + k * 512;                                                                      \
+        const int idx = tid + k * NTHR;                                                                      \
         const int p = idx >> 2, q = idx & 3;                                                                \
         f16x4 hi4, lo4;                                                                                     \
         _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                     \
@@ -651,15 +653,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             hi4[e] = h;                                                                                     \
             lo4[e] = (_Float16)(v - (float)h);                                                              \
         }                                                                                                   \
-        if (IN_F4 % 512 == 0 || idx < IN_F4) {                                                              \
+        if (IN_F4 % NTHR == 0 || idx < IN_F4) {                                                              \
             *reinterpret_cast<f16x4*>((BUFP) + p * PIXB + q * 8) = hi4;                                     \
             *reinterpret_cast<f16x4*>((BUFP) + p * PIXB + 32 + q * 8) = lo4;                                \
         }                                                                                                   \
     }
 #define H2B_WRITE_W()                                                                                       \
     _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                        \
-        const int idx = tid + k * 512;                                                                      \
-        if (W_16 % 512 == 0 || idx < W_16) reinterpret_cast<f32x4*>(lw)[idx] = rw[k];                       \
+        const int idx = tid + k * NTHR;                                                                      \
+        if (W_16 % NTHR == 0 || idx < W_16) reinterpret_cast<f32x4*>(lw)[idx] = rw[k];                       \
     }
 #define H2B_TAPS(BUFP, T0, T1)                                                                              \
     {                                                                                                       \

@@ -421,6 +421,8 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<1, 10, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, convh2b_lds_bytes<1, 10>()));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb10));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lb10));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (convh2b_lds_bytes<2, 10, 4>())));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 9, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (convh2b_lds_bytes<2, 9, 4>())));
                 bdone[dev] = true;
             }
         }
@@ -435,6 +437,20 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
             a.partial = splitk_workspace(st, (size_t)nsplit * a.Ho * a.Wo * a.cpad);
             if (!a.partial) return fail(RIFE_HIP_EHIP, "split-K workspace allocation failed");
             nbl = nb * nsplit;
+        }
+        // 4-row tiles (4 waves, three workgroups per CU) for layers whose 8-row tiles would occupy only part of the chip: twice the
+        // workgroups, half the latency of each (RIFE_HIP_ROWS4_MAXWG = 8-row workgroup count below which they are used; 0 = never)
+        static const int rows4_max = []() { const char* e = getenv("RIFE_HIP_ROWS4_MAXWG"); return e ? atoi(e) : 400; }();
+        const bool rows4 = g_h2b && L.NS == 2 && nsplit == 1 && nb < rows4_max;
+        if (rows4) {
+            constexpr int l4_9 = convh2b_lds_bytes<2, 9, 4>(), l4_10 = convh2b_lds_bytes<2, 10, 4>();
+            a.ntiles_xy = a.tiles_x * ((a.Ho + 3) / 4);
+            const int nb4 = a.ntiles_xy * a.nz;
+            if (L.skip) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 0, 4>), dim3(nb4), dim3(256), l4_10, st, a);
+            else hipLaunchKernelGGL((conv_h2b_kernel<2, 9, 0, 4>), dim3(nb4), dim3(256), l4_9, st, a);
+            hipError_t e4 = hipGetLastError();
+            if (e4 != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_h2b (4-row) launch: ") + hipGetErrorString(e4));
+            return 0;
         }
         const int nb_saved = nb; (void)nb_saved;
 #define nb nbl
