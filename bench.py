@@ -35,7 +35,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA pea
 HBM_PEAK_TBPS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak
 # dominant kernel per family: (profile class, kernel symbol, channels C of the C->C 3x3 trunk conv, MFMA work factor of the
 # split-f16 scheme = 2 MFMAs per product (+ the identity tap of the folded skip connection for v4: 10/9))
-DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_h2b_kernel<2,10,3> (IFNet block-3 trunk: 3x3 conv 64->64 + skip + LeakyReLU, split-f16)", 64, 2.0 * 10 / 9),
+DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_h2b_kernel<2,10,3,8> (IFNet block-3 trunk: 3x3 conv 64->64 + skip + LeakyReLU, split-f16)", 64, 2.0 * 10 / 9),
             "rife-v2.3": ("v2_flow_trunk_b3", "conv_h2_kernel<3,9,0> (IFNet block-3 trunk: 3x3 conv 96->96 + PReLU, split-f16)", 96, 2.0)}
 
 

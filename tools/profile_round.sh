@@ -16,7 +16,7 @@ for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES
     name=$(echo $pass | cut -d' ' -f1)
     rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$name -- python $ROOT/tools/prof_run.py --workload 4k --pairs 3 > $OUT/pmc_$name.log 2>&1
     f=$(find $OUT/pmc_$name -name '*counter_collection.csv' | head -1)
-    python $ROOT/tools/pmc_summary.py $f "conv_h2b_kernel<2, 10, 3>" > $OUT/pmc_${name}_trunk_b3.txt 2>&1
+    python $ROOT/tools/pmc_summary.py $f "conv_h2b_kernel<2, 10, 3, 8>" > $OUT/pmc_${name}_trunk_b3.txt 2>&1
     python $ROOT/tools/pmc_summary.py $f > $OUT/pmc_${name}_all.txt 2>&1
 done
 # keep only the small summaries (gpurun_out is capped at 64 MiB)
