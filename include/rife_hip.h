@@ -52,7 +52,8 @@ int rife_hip_process(const rife_hip_t* r, const uint8_t* in0_rgb, const uint8_t*
 
 /* Optional throughput entry point: n independent pairs from host memory in one call, spread over internal
  * streams so that the copies of one pair overlap the kernels of the others - what the reference gets from its proc threads
- * (src/main.cpp:849-866).  Same pixels as n rife_hip_process() calls; timestep 0 / 1 entries are copies. */
+ * (src/main.cpp:849-866).  Same pixels as n rife_hip_process() calls; timestep 0 / 1 entries are copies.  A host frame that
+ * appears in several pairs of the batch (in0[i + 1] == in1[i] in a sequence) is uploaded once. */
 int rife_hip_process_batch(const rife_hip_t* r, int n, const uint8_t* const* in0_rgb, const uint8_t* const* in1_rgb, const float* timestep,
                            uint8_t* const* out_rgb, int w, int h);
 

@@ -1837,12 +1837,45 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     if (n == 0) return 0;
     if ((rc = check_device(E->gpuid))) return rc;
     const int K = std::min(n, 2);                          // measured on MI355X + EPYC 9575F: 2 workers beat 1 and 3 (pageable copies contend)
+    // A host frame that serves several pairs of the batch (consecutive pairs of a sequence share one) crosses PCIe once: it becomes a
+    // resident frame on first use and is released after its last (stream mode, below).  Batches without shared frames run as before.
+    struct Shared { std::mutex mu; rife_hip_frame_t* f = nullptr; int left = 0; };
+    std::map<const uint8_t*, std::unique_ptr<Shared>> shared;
+    bool any_shared = false;
+    for (int i = 0; i < n; i++) {
+        if (timestep[i] == 0.f || timestep[i] == 1.f) continue;
+        for (const uint8_t* p : {in0[i], in1[i]}) {
+            auto& sl = shared[p];
+            if (!sl) sl.reset(new Shared);
+            any_shared |= ++sl->left > 1;
+        }
+    }
+    auto resident = [&](const uint8_t* p, rife_hip_frame_t*& f) -> int {
+        Shared& sl = *shared.find(p)->second;
+        std::lock_guard<std::mutex> g(sl.mu);
+        const int r = sl.f ? 0 : rife_hip_frame_upload(E, p, w, h, &sl.f);
+        f = sl.f;
+        return r;
+    };
+    auto retire = [&](const uint8_t* p) {
+        Shared& sl = *shared.find(p)->second;
+        std::lock_guard<std::mutex> g(sl.mu);
+        if (--sl.left == 0) { rife_hip_frame_release(sl.f); sl.f = nullptr; }
+    };
     std::vector<int> rcs(K, 0);
     std::vector<std::string> errs(K);
     auto worker = [&](int k) {
         (void)hipSetDevice(E->gpuid);
         for (int i = k; i < n; i += K) {
-            const int r = rife_hip_process(E, in0[i], in1[i], w, h, timestep[i], out[i]);
+            int r;
+            if (!any_shared || timestep[i] == 0.f || timestep[i] == 1.f) r = rife_hip_process(E, in0[i], in1[i], w, h, timestep[i], out[i]);
+            else {
+                rife_hip_frame_t *f0 = nullptr, *f1 = nullptr;
+                r = resident(in0[i], f0);
+                if (!r) r = resident(in1[i], f1);
+                if (!r) r = rife_hip_process_frames(E, f0, f1, timestep[i], out[i]);
+                retire(in0[i]); retire(in1[i]);
+            }
             if (r) { rcs[k] = r; errs[k] = g_err; return; }     // g_err is thread-local: carry it back to the caller
         }
     };
@@ -1850,6 +1883,7 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     for (int k = 1; k < K; k++) th.emplace_back(worker, k);
     worker(0);
     for (auto& t : th) t.join();
+    for (auto& kv : shared) if (kv.second->f) rife_hip_frame_release(kv.second->f);      // only after an error
     for (int k = 0; k < K; k++) if (rcs[k]) { g_err = errs[k]; return rcs[k]; }
     return 0;
 }
