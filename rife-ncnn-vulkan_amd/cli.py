@@ -205,14 +205,46 @@ def main(argv=None):
             sys.stderr.write("decode image %s failed\n" % path)
             return None
 
+    class SharedFrame:
+        """A decoded frame and its copy in device memory per engine (uploaded by the first proc thread that needs it there): consecutive
+        tasks use the same files, so each is decoded once and crosses PCIe once (the C++ CLI does the same)."""
+
+        def __init__(self, px):
+            self.px, self.lock, self.resident = px, threading.Lock(), {}
+
+        def on(self, r):
+            with self.lock:
+                if id(r) not in self.resident:
+                    self.resident[id(r)] = r.upload(self.px)
+                return self.resident[id(r)]
+
+    cache, cache_lock = [], threading.Lock()          # the last few decoded frames: [(path, SharedFrame)]
+
+    def frame(path):
+        with cache_lock:
+            for p, f in cache:
+                if p == path:
+                    return f
+        px = decode(path)
+        if px is None:
+            return None
+        with cache_lock:
+            for p, f in cache:
+                if p == path:
+                    return f
+            f = SharedFrame(px)
+            cache.append((path, f))
+            del cache[:-6]
+            return f
+
     def load():
         while True:
             try:
                 t = jobs.get_nowait()
             except queue.Empty:
                 return
-            a, b = decode(t[0]), decode(t[1])
-            if a is None or b is None or a.shape != b.shape:
+            a, b = frame(t[0]), frame(t[1])
+            if a is None or b is None or a.px.shape != b.px.shape:
                 continue
             toproc.put((t, a, b))
 
@@ -222,7 +254,10 @@ def main(argv=None):
             if item is END:
                 return
             t, a, b = item
-            tosave.put((t, r.process(a, b, t[2])))
+            if t[2] == 0.0 or t[2] == 1.0:                      # rife.cpp:2470-2480: an input frame, unchanged
+                tosave.put((t, a.px if t[2] == 0.0 else b.px))
+            else:
+                tosave.put((t, r.process_frames(a.on(r), b.on(r), t[2])))
 
     def save():
         while True:
@@ -256,6 +291,7 @@ def main(argv=None):
         tosave.put(END)
     for th in savers:
         th.join()
+    del cache[:]                                           # resident frames go before their engines
     return 0
 
 
