@@ -590,7 +590,7 @@ template <int NS, int NTAPS, int ROWS = 8>
 constexpr int convh2b_lds_bytes() { return 2 * (ROWS + 2) * 34 * 80 + NTAPS * 2 * NS * 32 * 16; }
 
 template <int NS, int NTAPS, int TAG, int ROWS = 8>
-__global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_h2b_kernel(ConvArgs a) {
+__global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS == 3 ? 2 : 4, NS == 3 ? 2 : 4))) void conv_h2b_kernel(ConvArgs a) {   // NS = 3: LDS allows 8 waves per CU anyway
     constexpr int IH = ROWS + 2, IW = 34, CC = 16, NT = NS * 32;
     constexpr int NTHR = ROWS * 64;                            // one wave per output row of the tile
     constexpr int PIXB = 80;
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(4, 4)
         for (int j = 0; j < 32 / PPI; j++) {
             const int px = j * PPI + pl;
             const f32x4 v = *reinterpret_cast<const f32x4*>(tl + px * ROWF + chunk * 4);
-            if (oy < a.Ho && ox0 + px < a.Wo) *reinterpret_cast<f32x4*>(orow + (size_t)px * a.out_ld) = v;
+            if ((64 % LPP == 0 || pl < PPI) && oy < a.Ho && ox0 + px < a.Wo) *reinterpret_cast<f32x4*>(orow + (size_t)px * a.out_ld) = v;      // NT = 96: lanes 48-63 idle
         }
     }
 }

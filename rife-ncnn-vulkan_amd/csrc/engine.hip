@@ -423,6 +423,8 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lb10));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (convh2b_lds_bytes<2, 10, 4>())));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 9, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (convh2b_lds_bytes<2, 9, 4>())));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<3, 10, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (convh2b_lds_bytes<3, 10, 4>())));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<3, 9, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (convh2b_lds_bytes<3, 9, 4>())));
                 bdone[dev] = true;
             }
         }
@@ -441,12 +443,15 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         // 4-row tiles (4 waves, three workgroups per CU) for layers whose 8-row tiles would occupy only part of the chip: twice the
         // workgroups, half the latency of each (RIFE_HIP_ROWS4_MAXWG = 8-row workgroup count below which they are used; 0 = never)
         static const int rows4_max = []() { const char* e = getenv("RIFE_HIP_ROWS4_MAXWG"); return e ? atoi(e) : 400; }();
-        const bool rows4 = g_h2b && L.NS == 2 && nsplit == 1 && nb < rows4_max;
+        const bool rows4 = g_h2b && (L.NS == 2 || L.NS == 3) && nsplit == 1 && nb < rows4_max;
         if (rows4) {
             constexpr int l4_9 = convh2b_lds_bytes<2, 9, 4>(), l4_10 = convh2b_lds_bytes<2, 10, 4>();
+            constexpr int l43_9 = convh2b_lds_bytes<3, 9, 4>(), l43_10 = convh2b_lds_bytes<3, 10, 4>();      // 96-wide N-tiles: 63 KB, two workgroups per CU
             a.ntiles_xy = a.tiles_x * ((a.Ho + 3) / 4);
             const int nb4 = a.ntiles_xy * a.nz;
-            if (L.skip) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 0, 4>), dim3(nb4), dim3(256), l4_10, st, a);
+            if (L.NS == 3 && L.skip) hipLaunchKernelGGL((conv_h2b_kernel<3, 10, 0, 4>), dim3(nb4), dim3(256), l43_10, st, a);
+            else if (L.NS == 3) hipLaunchKernelGGL((conv_h2b_kernel<3, 9, 0, 4>), dim3(nb4), dim3(256), l43_9, st, a);
+            else if (L.skip) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 0, 4>), dim3(nb4), dim3(256), l4_10, st, a);
             else hipLaunchKernelGGL((conv_h2b_kernel<2, 9, 0, 4>), dim3(nb4), dim3(256), l4_9, st, a);
             hipError_t e4 = hipGetLastError();
             if (e4 != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_h2b (4-row) launch: ") + hipGetErrorString(e4));
