@@ -2,7 +2,8 @@
 // it through stb_image_write at quality 100 (src/main.cpp:123-229, 215); neither library nor libjpeg headers exist in this image,
 // so this is a from-scratch codec of the subset that matters for frame sequences:
 //   decode: baseline sequential DCT (SOF0 / SOF1 with 8-bit samples), Huffman, 1 or 3 components, any sampling factors up to 2x2
-//           (4:4:4, 4:2:2, 4:2:0, ...), restart intervals, JFIF YCbCr -> RGB; progressive / arithmetic / 12-bit files are refused;
+//           (4:4:4, 4:2:2, 4:2:0, ...), restart intervals, JFIF YCbCr -> RGB; progressive DCT (SOF2: spectral selection and successive
+//           approximation) and sequential files with one scan per component as well; arithmetic / lossless / 12-bit files are refused;
 //   encode: baseline, 4:4:4, all-ones quantisation tables (what "quality 100" means), standard Huffman tables.
 // Floating-point IDCT / FDCT (separable, exact to rounding), so decoded pixels agree with libjpeg's to within +-1..2 levels.
 #pragma once
@@ -93,9 +94,183 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
     if (d.size() < 4 || d[0] != 0xFF || d[1] != 0xD8) return fail("not a JPEG");
     uint16_t qt[4][64]; bool have_qt[4] = {false, false, false, false};
     Huff dc[4], ac[4];
-    struct Comp { int id, hs, vs, tq, td, ta; int bw, bh; std::vector<uint8_t> plane; int pred; } comp[3];
+    struct Comp {
+        int id, hs, vs, tq, td, ta; int bw, bh; std::vector<uint8_t> plane; int pred;
+        // multi-scan files (progressive, or sequential with one scan per component): all coefficients are kept until the last scan
+        std::vector<int16_t> coef; int nbx = 0, nby = 0;      // block grid padded to whole MCUs
+        int cbw = 0, cbh = 0;                                 // blocks that cover the component itself (the grid of a non-interleaved scan)
+    } comp[3];
     int ncomp = 0, hmax = 1, vmax = 1, restart = 0;
-    bool have_sof = false;
+    bool have_sof = false, progressive = false, multi = false;
+    // chroma upsampling and colour conversion of the decoded planes (shared by the single-scan and the multi-scan path)
+    auto finish = [&]() -> bool {
+        // chroma upsampling: libjpeg's "fancy" triangle filters for the two common layouts (h2v1 = 4:2:2, h2v2 = 4:2:0; the same
+        // 3:1 weights stb_image uses), replication for anything else; then JFIF YCbCr -> RGB
+        std::vector<uint8_t> full[3];
+        for (int c = 0; c < ncomp; c++) {
+            full[c].resize((size_t)w * h);
+            const Comp& C = comp[c];
+            const int cw = (w * C.hs + hmax - 1) / hmax, chh = (h * C.vs + vmax - 1) / vmax;      // valid samples of this component
+            auto S = [&](int yy, int xx) -> int { return C.plane[(size_t)std::min(std::max(yy, 0), chh - 1) * C.bw + std::min(std::max(xx, 0), cw - 1)]; };
+            const bool h2 = hmax == 2 && C.hs == 1, v2 = vmax == 2 && C.vs == 1;
+            if (C.hs == hmax && C.vs == vmax) {
+                for (int y = 0; y < h; y++) std::memcpy(&full[c][(size_t)y * w], &C.plane[(size_t)y * C.bw], (size_t)w);
+            } else if (h2 && !v2 && C.vs == vmax) {                                                 // h2v1
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) {
+                        const int i = x >> 1;
+                        int v;
+                        if (cw == 1) v = S(y, 0);
+                        else if (x == 0) v = S(y, 0);
+                        else if (x == 2 * cw - 1) v = S(y, cw - 1);
+                        else v = (x & 1) ? (S(y, i) * 3 + S(y, i + 1) + 2) >> 2 : (S(y, i) * 3 + S(y, i - 1) + 1) >> 2;
+                        full[c][(size_t)y * w + x] = (uint8_t)v;
+                    }
+            } else if (h2 && v2) {                                                                  // h2v2
+                for (int y = 0; y < h; y++) {
+                    const int r = y >> 1, rn = (y & 1) ? r + 1 : r - 1;                             // nearer / farther input row (edges replicate)
+                    for (int x = 0; x < w; x++) {
+                        const int i = x >> 1;
+                        const int cs = S(r, i) * 3 + S(rn, i);
+                        int v;
+                        if (cw == 1) v = (cs * 4 + 8) >> 4;
+                        else if (x == 0) v = (cs * 4 + 8) >> 4;
+                        else if (x == 2 * cw - 1) v = (cs * 4 + 7) >> 4;
+                        else if (x & 1) v = (cs * 3 + S(r, i + 1) * 3 + S(rn, i + 1) + 7) >> 4;
+                        else v = (cs * 3 + S(r, i - 1) * 3 + S(rn, i - 1) + 8) >> 4;
+                        full[c][(size_t)y * w + x] = (uint8_t)v;
+                    }
+                }
+            } else {
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) full[c][(size_t)y * w + x] = (uint8_t)S(y * C.vs / vmax, x * C.hs / hmax);
+            }
+        }
+        rgb.resize((size_t)w * h * 3);
+        for (size_t i = 0; i < (size_t)w * h; i++) {
+            unsigned char* o = &rgb[i * 3];
+            if (ncomp == 1) { o[0] = o[1] = o[2] = full[0][i]; continue; }
+            const float Y = full[0][i], cb = (float)full[1][i] - 128.f, cr = (float)full[2][i] - 128.f;
+            const int ri = (int)std::lround(Y + 1.402f * cr), gi = (int)std::lround(Y - 0.344136f * cb - 0.714136f * cr), bi = (int)std::lround(Y + 1.772f * cb);
+            o[0] = (uint8_t)(ri < 0 ? 0 : ri > 255 ? 255 : ri); o[1] = (uint8_t)(gi < 0 ? 0 : gi > 255 ? 255 : gi); o[2] = (uint8_t)(bi < 0 ? 0 : bi > 255 ? 255 : bi);
+        }
+        return true;
+    };
+    // ---- multi-scan files: coefficient store, one decoder for every kind of scan, reconstruction at the end ----
+    auto setup_geometry = [&]() {
+        const int mx = (w + 8 * hmax - 1) / (8 * hmax), my = (h + 8 * vmax - 1) / (8 * vmax);
+        for (int c = 0; c < ncomp; c++) {
+            Comp& C = comp[c];
+            C.nbx = mx * C.hs; C.nby = my * C.vs;
+            C.bw = C.nbx * 8; C.bh = C.nby * 8;
+            C.cbw = ((w * C.hs + hmax - 1) / hmax + 7) / 8; C.cbh = ((h * C.vs + vmax - 1) / vmax + 7) / 8;
+        }
+    };
+    // Sequential scans are the case Ss = 0, Se = 63, Ah = Al = 0 of the progressive ones (an EOB is an EOB run of one block).
+    auto decode_scan = [&](const int* sc, int ns, int Ss, int Se, int Ah, int Al, const uint8_t* start) -> bool {
+        BitReader br{start, d.data() + d.size()};
+        int eobrun = 0, count = 0;
+        for (int k = 0; k < ns; k++) comp[sc[k]].pred = 0;
+        const int p1 = 1 << Al, m1 = -(1 << Al);
+        auto block = [&](Comp& C, int bx, int by) -> bool {
+            int16_t* q = &C.coef[((size_t)by * C.nbx + bx) * 64];
+            int k = Ss;
+            if (Ss == 0) {
+                if (Ah == 0) {
+                    const int t = decode_symbol(br, dc[C.td]);
+                    if (t < 0 || t > 15) return false;
+                    C.pred += t ? extend(br.bits(t), t) : 0;
+                    q[0] = (int16_t)(C.pred * p1);
+                } else if (br.bit()) q[0] = (int16_t)(q[0] | p1);
+                k = 1;
+            }
+            if (Se == 0) return true;
+            if (Ah == 0) {                                     // first pass over these coefficients
+                if (eobrun > 0) { eobrun--; return true; }
+                for (; k <= Se; k++) {
+                    const int rs = decode_symbol(br, ac[C.ta]);
+                    if (rs < 0) return false;
+                    const int r = rs >> 4, sz = rs & 15;
+                    if (sz == 0) {
+                        if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += br.bits(r); break; }
+                        k += 15;
+                    } else {
+                        k += r;
+                        if (k > 63) return false;
+                        q[ZIGZAG[k]] = (int16_t)(extend(br.bits(sz), sz) * p1);
+                    }
+                }
+                return true;
+            }
+            // refinement pass: one more bit for the coefficients that are already non-zero, new +-1 coefficients in between
+            if (eobrun == 0) {
+                for (; k <= Se; k++) {
+                    const int rs = decode_symbol(br, ac[C.ta]);
+                    if (rs < 0) return false;
+                    int r = rs >> 4, sz = rs & 15, val = 0;
+                    if (sz == 0) {
+                        if (r < 15) { eobrun = 1 << r; if (r) eobrun += br.bits(r); break; }      // counts this block too
+                    } else val = br.bit() ? p1 : m1;
+                    for (; k <= Se; k++) {
+                        int16_t& cf = q[ZIGZAG[k]];
+                        if (cf != 0) {
+                            if (br.bit() && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+                        } else if (--r < 0) break;
+                    }
+                    if (val && k <= Se) q[ZIGZAG[k]] = (int16_t)val;
+                }
+            }
+            if (eobrun > 0) {
+                for (; k <= Se; k++) {
+                    int16_t& cf = q[ZIGZAG[k]];
+                    if (cf != 0 && br.bit() && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+                }
+                eobrun--;
+            }
+            return true;
+        };
+        auto at_restart = [&]() {
+            if (!(restart && count && count % restart == 0)) return;
+            br.align();
+            while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) br.p++;
+            if (br.p + 1 < br.end) br.p += 2;
+            br.marker = false; br.n = 0;
+            for (int k = 0; k < ns; k++) comp[sc[k]].pred = 0;
+            eobrun = 0;
+        };
+        if (ns == 1) {                                         // non-interleaved: the component's own block grid, row by row
+            Comp& C = comp[sc[0]];
+            for (int by = 0; by < C.cbh; by++)
+                for (int bx = 0; bx < C.cbw; bx++) { at_restart(); count++; if (!block(C, bx, by)) return false; }
+            return true;
+        }
+        const int mx = comp[0].nbx / comp[0].hs, my = comp[0].nby / comp[0].vs;
+        for (int yy = 0; yy < my; yy++)
+            for (int xx = 0; xx < mx; xx++) {
+                at_restart(); count++;
+                for (int k = 0; k < ns; k++) {
+                    Comp& C = comp[sc[k]];
+                    for (int by = 0; by < C.vs; by++)
+                        for (int bx = 0; bx < C.hs; bx++) if (!block(C, xx * C.hs + bx, yy * C.vs + by)) return false;
+                }
+            }
+        return true;
+    };
+    auto reconstruct = [&]() -> bool {
+        for (int c = 0; c < ncomp; c++) {
+            Comp& C = comp[c];
+            if (!have_qt[C.tq]) return fail("missing quantisation table");
+            C.plane.assign((size_t)C.bw * C.bh, 0);
+            for (int by = 0; by < C.nby; by++)
+                for (int bx = 0; bx < C.nbx; bx++) {
+                    const int16_t* q = &C.coef[((size_t)by * C.nbx + bx) * 64];
+                    float blk[64];
+                    for (int k = 0; k < 64; k++) blk[k] = (float)(q[k] * (int)qt[C.tq][k]);
+                    idct8x8(blk, &C.plane[(size_t)by * 8 * C.bw + bx * 8], C.bw);
+                }
+        }
+        return finish();
+    };
     size_t pos = 2;
     while (pos + 4 <= d.size()) {
         if (d[pos] != 0xFF) { pos++; continue; }
@@ -125,7 +300,8 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
                 (tc ? ac[th] : dc[th]).build(&s[i + 1], &s[i + 17], total);
                 i += 17 + total;
             }
-        } else if (m == 0xC0 || m == 0xC1) {
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+            progressive = m == 0xC2;
             if (n < 6 || s[0] != 8) return fail("only 8-bit samples are supported");
             h = (s[1] << 8) | s[2]; w = (s[3] << 8) | s[4]; ncomp = s[5];
             if ((ncomp != 1 && ncomp != 3) || n < 6 + 3 * (size_t)ncomp || w <= 0 || h <= 0) return fail("unsupported component count");
@@ -135,13 +311,41 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
                 hmax = std::max(hmax, comp[c].hs); vmax = std::max(vmax, comp[c].vs);
             }
             have_sof = true;
-        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-            return fail("progressive / lossless / arithmetic JPEG is not supported (baseline only)");
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return fail("lossless / hierarchical / arithmetic-coded JPEG is not supported");
         } else if (m == 0xDD) {
             if (n >= 2) restart = (s[0] << 8) | s[1];
         } else if (m == 0xDA) {
             if (!have_sof) return fail("SOS before SOF");
-            if (n < 1 || s[0] != ncomp || n < 1 + 2 * (size_t)ncomp + 3) return fail("multi-scan files are not supported");
+            if (n < 1 || s[0] < 1 || s[0] > ncomp || n < 1 + 2 * (size_t)s[0] + 3) return fail("bad SOS");
+            if (progressive || multi || s[0] != ncomp) {
+                // one of several scans: decode it into the coefficient store, then go on with the marker after its entropy-coded data
+                const int ns = s[0];
+                int sc[3];
+                if (!multi) {
+                    setup_geometry();
+                    for (int c = 0; c < ncomp; c++) comp[c].coef.assign((size_t)comp[c].nbx * comp[c].nby * 64, 0);
+                    multi = true;
+                }
+                for (int k = 0; k < ns; k++) {
+                    int ci = -1;
+                    for (int c = 0; c < ncomp; c++) if (comp[c].id == s[1 + 2 * k]) ci = c;
+                    if (ci < 0) return fail("bad scan component");
+                    comp[ci].td = s[2 + 2 * k] >> 4; comp[ci].ta = s[2 + 2 * k] & 15;
+                    sc[k] = ci;
+                }
+                const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+                if (Ss > Se || Se > 63 || Al > 13 || (Ss > 0 && ns != 1) || (!progressive && (Ss != 0 || Se != 63 || Ah || Al))) return fail("bad scan parameters");
+                for (int k = 0; k < ns; k++) {
+                    if (Ss == 0 && Ah == 0 && !dc[comp[sc[k]].td].ok) return fail("missing table");
+                    if (Se > 0 && !ac[comp[sc[k]].ta].ok) return fail("missing table");
+                }
+                if (!decode_scan(sc, ns, Ss, Se, Ah, Al, &d[pos + len])) return fail("corrupt scan data");
+                size_t q = pos + len;                        // next marker that is not a restart marker or a stuffed 0xFF
+                while (q + 1 < d.size() && !(d[q] == 0xFF && d[q + 1] != 0x00 && d[q + 1] != 0xFF && !(d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7))) q++;
+                pos = q;
+                continue;
+            }
             for (int k = 0; k < ncomp; k++) {
                 int ci = -1;
                 for (int c = 0; c < ncomp; c++) if (comp[c].id == s[1 + 2 * k]) ci = c;
@@ -193,60 +397,11 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
                                 idct8x8(blk, &comp[c].plane[(size_t)py * comp[c].bw + px], comp[c].bw);
                             }
                 }
-            // chroma upsampling: libjpeg's "fancy" triangle filters for the two common layouts (h2v1 = 4:2:2, h2v2 = 4:2:0; the same
-            // 3:1 weights stb_image uses), replication for anything else; then JFIF YCbCr -> RGB
-            std::vector<uint8_t> full[3];
-            for (int c = 0; c < ncomp; c++) {
-                full[c].resize((size_t)w * h);
-                const Comp& C = comp[c];
-                const int cw = (w * C.hs + hmax - 1) / hmax, chh = (h * C.vs + vmax - 1) / vmax;      // valid samples of this component
-                auto S = [&](int yy, int xx) -> int { return C.plane[(size_t)std::min(std::max(yy, 0), chh - 1) * C.bw + std::min(std::max(xx, 0), cw - 1)]; };
-                const bool h2 = hmax == 2 && C.hs == 1, v2 = vmax == 2 && C.vs == 1;
-                if (C.hs == hmax && C.vs == vmax) {
-                    for (int y = 0; y < h; y++) std::memcpy(&full[c][(size_t)y * w], &C.plane[(size_t)y * C.bw], (size_t)w);
-                } else if (h2 && !v2 && C.vs == vmax) {                                                 // h2v1
-                    for (int y = 0; y < h; y++)
-                        for (int x = 0; x < w; x++) {
-                            const int i = x >> 1;
-                            int v;
-                            if (cw == 1) v = S(y, 0);
-                            else if (x == 0) v = S(y, 0);
-                            else if (x == 2 * cw - 1) v = S(y, cw - 1);
-                            else v = (x & 1) ? (S(y, i) * 3 + S(y, i + 1) + 2) >> 2 : (S(y, i) * 3 + S(y, i - 1) + 1) >> 2;
-                            full[c][(size_t)y * w + x] = (uint8_t)v;
-                        }
-                } else if (h2 && v2) {                                                                  // h2v2
-                    for (int y = 0; y < h; y++) {
-                        const int r = y >> 1, rn = (y & 1) ? r + 1 : r - 1;                             // nearer / farther input row (edges replicate)
-                        for (int x = 0; x < w; x++) {
-                            const int i = x >> 1;
-                            const int cs = S(r, i) * 3 + S(rn, i);
-                            int v;
-                            if (cw == 1) v = (cs * 4 + 8) >> 4;
-                            else if (x == 0) v = (cs * 4 + 8) >> 4;
-                            else if (x == 2 * cw - 1) v = (cs * 4 + 7) >> 4;
-                            else if (x & 1) v = (cs * 3 + S(r, i + 1) * 3 + S(rn, i + 1) + 7) >> 4;
-                            else v = (cs * 3 + S(r, i - 1) * 3 + S(rn, i - 1) + 8) >> 4;
-                            full[c][(size_t)y * w + x] = (uint8_t)v;
-                        }
-                    }
-                } else {
-                    for (int y = 0; y < h; y++)
-                        for (int x = 0; x < w; x++) full[c][(size_t)y * w + x] = (uint8_t)S(y * C.vs / vmax, x * C.hs / hmax);
-                }
-            }
-            rgb.resize((size_t)w * h * 3);
-            for (size_t i = 0; i < (size_t)w * h; i++) {
-                unsigned char* o = &rgb[i * 3];
-                if (ncomp == 1) { o[0] = o[1] = o[2] = full[0][i]; continue; }
-                const float Y = full[0][i], cb = (float)full[1][i] - 128.f, cr = (float)full[2][i] - 128.f;
-                const int ri = (int)std::lround(Y + 1.402f * cr), gi = (int)std::lround(Y - 0.344136f * cb - 0.714136f * cr), bi = (int)std::lround(Y + 1.772f * cb);
-                o[0] = (uint8_t)(ri < 0 ? 0 : ri > 255 ? 255 : ri); o[1] = (uint8_t)(gi < 0 ? 0 : gi > 255 ? 255 : gi); o[2] = (uint8_t)(bi < 0 ? 0 : bi > 255 ? 255 : bi);
-            }
-            return true;
+            return finish();
         }
         pos += len;
     }
+    if (multi) return reconstruct();
     return fail("no scan found");
 }
 

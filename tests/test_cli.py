@@ -193,7 +193,24 @@ def test_cpp_cli_jpeg_codec_against_libjpeg(tmp_path):
         assert p.returncode == 0, p.stderr
         d = np.abs(np.asarray(Image.open(tmp_path / "enc.jpg").convert("RGB")).astype(int) - a.astype(int))
         assert d.max() <= 4 and d.mean() < 1.0, (w, int(d.max()), float(d.mean()))
-    a, _ = gen_frames.smooth_pair(64, 48, 3)
-    Image.fromarray(a).save(tmp_path / "prog.jpg", progressive=True)
-    p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "prog.jpg"), str(tmp_path / "prog.png")], capture_output=True, text=True)
-    assert p.returncode == 1 and "progressive" in p.stderr
+    # progressive DCT (spectral selection + successive approximation, what stb_image in the reference also reads)
+    for (w, h) in ((203, 117), (64, 48), (17, 9), (640, 360)):
+        a = gen_frames.smooth_pair(w, h, 5)[0] if w < 600 else (np.kron(gen_frames.smooth_pair(160, 90, 6)[0], np.ones((4, 4, 1), np.uint8)) + gen_frames.noise_pair(w, h, 7)[0] % 32)
+        variants = {"p95_420": dict(quality=95), "p100_444": dict(quality=100, subsampling=0), "p85_422": dict(quality=85, subsampling=1),
+                    "p60_opt": dict(quality=60, optimize=True), "pgray": dict(quality=90),
+                    "p90_rst": dict(quality=90, restart_marker_blocks=3), "p90_rst_444": dict(quality=90, restart_marker_rows=1, subsampling=0)}
+        for name, kw in variants.items():
+            src = tmp_path / ("%s_%d.jpg" % (name, w))
+            (Image.fromarray(a).convert("L") if name == "pgray" else Image.fromarray(a)).save(src, progressive=True, **kw)
+            dst = tmp_path / ("%s_%d.png" % (name, w))
+            p = subprocess.run([RIFE_HIP, "--transcode", str(src), str(dst)], capture_output=True, text=True)
+            assert p.returncode == 0, (name, w, p.stderr)
+            d = np.abs(np.asarray(Image.open(dst).convert("RGB")).astype(int) - np.asarray(Image.open(src).convert("RGB")).astype(int))
+            assert d.max() <= 3 and d.mean() < 0.1, (name, w, int(d.max()), float(d.mean()))
+    # arithmetic-coded / lossless files are still refused with a message
+    bad = bytearray(open(tmp_path / "p95_420_64.jpg", "rb").read())
+    i = bad.find(b"\xff\xc2")
+    bad[i + 1] = 0xC9
+    open(tmp_path / "arith.jpg", "wb").write(bytes(bad))
+    p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "arith.jpg"), str(tmp_path / "arith.png")], capture_output=True, text=True)
+    assert p.returncode == 1 and "not supported" in p.stderr
