@@ -82,43 +82,115 @@ static bool decode_png(const std::vector<unsigned char>& d, int& w, int& h, std:
         else if (!memcmp(typ, "IEND", 4)) break;
         pos += 12 + (size_t)len;
     }
-    if (w <= 0 || h <= 0 || depth != 8 || interlace != 0) return false;
+    // every colour type / bit depth / interlace mode stb_image reads in the reference (1-, 2-, 4-, 8-, 16-bit; Adam7); like stb with
+    // 3 requested channels: 16-bit samples keep their high byte, low-depth grey is scaled to 0..255, alpha (and tRNS) is dropped
+    if (w <= 0 || h <= 0 || interlace > 1) return false;
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch || (ctype == 3 && pal.empty())) return false;
-    const size_t stride = (size_t)w * ch;
-    std::vector<unsigned char> raw((stride + 1) * h);
+    if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))) || (ctype == 3 && depth == 16)) return false;
+    const int bpp = depth * ch, fb = std::max(1, bpp / 8);               // bits per pixel, bytes per filter unit
+    auto row_bytes = [&](int pw) { return ((size_t)pw * bpp + 7) / 8; };
+    // pass geometry: one pass for non-interlaced files, the seven Adam7 passes otherwise
+    static const int X0[7] = {0, 4, 0, 2, 0, 1, 0}, Y0[7] = {0, 0, 4, 0, 2, 0, 1}, DX[7] = {8, 8, 4, 4, 2, 2, 1}, DY[7] = {8, 8, 8, 4, 4, 2, 2};
+    const int npass = interlace ? 7 : 1;
+    size_t total = 0;
+    for (int p = 0; p < npass; p++) {
+        const int pw = interlace ? (w - X0[p] + DX[p] - 1) / DX[p] : w, ph = interlace ? (h - Y0[p] + DY[p] - 1) / DY[p] : h;
+        if (pw > 0 && ph > 0) total += (row_bytes(pw) + 1) * ph;
+    }
+    std::vector<unsigned char> raw(total);
     uLongf rawlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;
-    std::vector<unsigned char> img(stride * h);
-    for (int y = 0; y < h; y++) {
-        const unsigned char* src = &raw[(stride + 1) * y];
-        unsigned char* cur = &img[stride * y];
-        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
-        const int ft = src[0];
-        for (size_t x = 0; x < stride; x++) {
-            const int a = x >= (size_t)ch ? cur[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
-            int v = src[1 + x];
-            switch (ft) {
-                case 0: break;
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) >> 1; break;
-                case 4: v += paeth(a, b, c); break;
-                default: return false;
+    rgb.assign((size_t)w * h * 3, 0);
+    const int gscale = depth == 1 ? 255 : depth == 2 ? 85 : depth == 4 ? 17 : 1;
+    size_t off = 0;
+    for (int p = 0; p < npass; p++) {
+        const int pw = interlace ? (w - X0[p] + DX[p] - 1) / DX[p] : w, ph = interlace ? (h - Y0[p] + DY[p] - 1) / DY[p] : h;
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t stride = row_bytes(pw);
+        std::vector<unsigned char> img(stride * ph);
+        for (int y = 0; y < ph; y++) {
+            const unsigned char* src = &raw[off + (stride + 1) * y];
+            unsigned char* cur = &img[stride * y];
+            const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
+            const int ft = src[0];
+            for (size_t x = 0; x < stride; x++) {
+                const int a = x >= (size_t)fb ? cur[x - fb] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)fb) ? up[x - fb] : 0;
+                int v = src[1 + x];
+                switch (ft) {
+                    case 0: break;
+                    case 1: v += a; break;
+                    case 2: v += b; break;
+                    case 3: v += (a + b) >> 1; break;
+                    case 4: v += paeth(a, b, c); break;
+                    default: return false;
+                }
+                cur[x] = (unsigned char)v;
             }
-            cur[x] = (unsigned char)v;
         }
+        off += (stride + 1) * ph;
+        for (int y = 0; y < ph; y++)
+            for (int x = 0; x < pw; x++) {
+                const unsigned char* row = &img[stride * y];
+                auto sample = [&](int c) -> int {          // channel c of pixel x as 8 bits (index for palette images)
+                    if (depth == 8) return row[(size_t)x * ch + c];
+                    if (depth == 16) return row[((size_t)x * ch + c) * 2];
+                    const int per = 8 / depth, sh = (per - 1 - x % per) * depth;
+                    return (row[x / per] >> sh) & ((1 << depth) - 1);
+                };
+                const int ox = interlace ? X0[p] + x * DX[p] : x, oy = interlace ? Y0[p] + y * DY[p] : y;
+                unsigned char* o = &rgb[((size_t)oy * w + ox) * 3];
+                if (ctype == 2 || ctype == 6) { o[0] = (unsigned char)sample(0); o[1] = (unsigned char)sample(1); o[2] = (unsigned char)sample(2); }
+                else if (ctype == 0 || ctype == 4) { o[0] = o[1] = o[2] = (unsigned char)(sample(0) * (depth < 8 ? gscale : 1)); }
+                else {
+                    const size_t k = (size_t)sample(0) * 3;
+                    if (k + 2 >= pal.size()) return false;
+                    o[0] = pal[k]; o[1] = pal[k + 1]; o[2] = pal[k + 2];
+                }
+            }
+    }
+    return true;
+}
+
+// BMP as stb_image reads it in the reference: uncompressed 24- / 32-bit (BI_RGB, or BI_BITFIELDS with the standard masks) and 8-bit palette
+static bool decode_bmp(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgb) {
+    if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') return false;
+    auto le32 = [&](size_t o) { return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8) | ((uint32_t)d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24); };
+    const uint32_t dataoff = le32(10), hsz = le32(14);
+    if (hsz < 40 || 14 + (size_t)hsz > d.size()) return false;
+    const int bw = (int)le32(18), bh = (int)le32(22), bits = d[28] | (d[29] << 8);
+    const uint32_t comp = le32(30);
+    if (bw <= 0 || bh == 0 || (d[26] | (d[27] << 8)) != 1) return false;
+    if (!((bits == 24 && comp == 0) || (bits == 32 && (comp == 0 || comp == 3)) || (bits == 8 && comp == 0))) return false;
+    const bool flip = bh > 0;                                 // positive height = bottom-up rows
+    w = bw; h = bh > 0 ? bh : -bh;
+    const size_t stride = ((size_t)w * bits / 8 + 3) & ~(size_t)3;
+    if ((size_t)dataoff + stride * h > d.size()) return false;
+    const unsigned char* pal = &d[14 + hsz];
+    uint32_t ncol = le32(46);
+    if (bits == 8) { if (!ncol) ncol = 256; if (14 + (size_t)hsz + 4 * (size_t)ncol > d.size()) return false; }
+    int rs = 16, gs = 8, bs = 0;                              // 32-bit BI_RGB is B, G, R, X
+    if (bits == 32 && comp == 3) {
+        if (hsz < 52 && 14 + (size_t)hsz + 12 > d.size()) return false;
+        const uint32_t rm = le32(54), gm = le32(58), bm = le32(62);
+        auto shift_of = [](uint32_t m) { int sft = 0; while (m && !(m & 1)) { m >>= 1; sft++; } return m == 0xff ? sft : -1; };
+        rs = shift_of(rm); gs = shift_of(gm); bs = shift_of(bm);
+        if (rs < 0 || gs < 0 || bs < 0) return false;
     }
     rgb.resize((size_t)w * h * 3);
-    for (size_t i = 0; i < (size_t)w * h; i++) {
-        const unsigned char* p = &img[i * ch];
-        unsigned char* o = &rgb[i * 3];
-        if (ctype == 2 || ctype == 6) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
-        else if (ctype == 0 || ctype == 4) { o[0] = o[1] = o[2] = p[0]; }
-        else {
-            const size_t k = (size_t)p[0] * 3;
-            if (k + 2 >= pal.size()) return false;
-            o[0] = pal[k]; o[1] = pal[k + 1]; o[2] = pal[k + 2];
+    for (int y = 0; y < h; y++) {
+        const unsigned char* row = &d[dataoff + stride * (size_t)(flip ? h - 1 - y : y)];
+        unsigned char* o = &rgb[(size_t)y * w * 3];
+        for (int x = 0; x < w; x++, o += 3) {
+            if (bits == 24) { o[0] = row[3 * x + 2]; o[1] = row[3 * x + 1]; o[2] = row[3 * x]; }
+            else if (bits == 32) {
+                const uint32_t v = (uint32_t)row[4 * x] | ((uint32_t)row[4 * x + 1] << 8) | ((uint32_t)row[4 * x + 2] << 16) | ((uint32_t)row[4 * x + 3] << 24);
+                o[0] = (unsigned char)(v >> rs); o[1] = (unsigned char)(v >> gs); o[2] = (unsigned char)(v >> bs);
+            } else {
+                if (row[x] >= ncol) return false;
+                const unsigned char* e = pal + 4 * (size_t)row[x];
+                o[0] = e[2]; o[1] = e[1]; o[2] = e[0];
+            }
         }
     }
     return true;
@@ -211,7 +283,8 @@ static bool encode_png(const std::string& path, int w, int h, const unsigned cha
 }
 
 static bool decode_ppm(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgb) {
-    if (d.size() < 7 || d[0] != 'P' || d[1] != '6') return false;
+    if (d.size() < 7 || d[0] != 'P' || (d[1] != '6' && d[1] != '5')) return false;      // P6 = rgb, P5 = grey (stb_image's pnm reader takes both)
+    const bool grey = d[1] == '5';
     size_t pos = 2;
     int vals[3], n = 0;
     while (n < 3 && pos < d.size()) {
@@ -224,8 +297,10 @@ static bool decode_ppm(const std::vector<unsigned char>& d, int& w, int& h, std:
     if (n != 3 || vals[2] != 255 || pos >= d.size()) return false;
     pos++;                                       // the single whitespace after maxval
     w = vals[0]; h = vals[1];
-    if (w <= 0 || h <= 0 || d.size() - pos < (size_t)w * h * 3) return false;
-    rgb.assign(d.begin() + pos, d.begin() + pos + (size_t)w * h * 3);
+    if (w <= 0 || h <= 0 || d.size() - pos < (size_t)w * h * (grey ? 1 : 3)) return false;
+    if (!grey) { rgb.assign(d.begin() + pos, d.begin() + pos + (size_t)w * h * 3); return true; }
+    rgb.resize((size_t)w * h * 3);
+    for (size_t i = 0; i < (size_t)w * h; i++) rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = d[pos + i];
     return true;
 }
 
@@ -281,7 +356,7 @@ static std::string ext_of(const std::string& p) {
 static bool decode_image(const std::string& path, int& w, int& h, std::vector<unsigned char>& rgb) {
     std::vector<unsigned char> d;
     if (!read_file(path, d)) return false;
-    if (decode_png(d, w, h, rgb) || decode_ppm(d, w, h, rgb) || decode_webp(d, w, h, rgb)) return true;
+    if (decode_png(d, w, h, rgb) || decode_ppm(d, w, h, rgb) || decode_webp(d, w, h, rgb) || decode_bmp(d, w, h, rgb)) return true;
     std::string why;
     if (jpeg::decode(d, w, h, rgb, &why)) return true;
     if (d.size() > 2 && d[0] == 0xFF && d[1] == 0xD8) fprintf(stderr, "%s: %s\n", path.c_str(), why.c_str());
@@ -381,9 +456,9 @@ static void print_usage() {
     fprintf(stderr, "       rife-hip -i indir -o outdir [options]...\n\n");
     fprintf(stderr, "  -h                   show this help\n");
     fprintf(stderr, "  -v                   verbose output\n");
-    fprintf(stderr, "  -0 input0-path       input image0 path (jpg/png/webp/ppm)\n");
-    fprintf(stderr, "  -1 input1-path       input image1 path (jpg/png/webp/ppm)\n");
-    fprintf(stderr, "  -i input-path        input image directory (jpg/png/webp/ppm)\n");
+    fprintf(stderr, "  -0 input0-path       input image0 path (jpg/png/webp/bmp/pnm)\n");
+    fprintf(stderr, "  -1 input1-path       input image1 path (jpg/png/webp/bmp/pnm)\n");
+    fprintf(stderr, "  -i input-path        input image directory (jpg/png/webp/bmp/pnm)\n");
     fprintf(stderr, "  -o output-path       output image path (jpg/png/webp/ppm) or directory\n");
     fprintf(stderr, "  -n num-frame         target frame count (default=N*2)\n");
     fprintf(stderr, "  -s time-step         time step (0~1, default=0.5)\n");

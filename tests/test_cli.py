@@ -214,3 +214,77 @@ def test_cpp_cli_jpeg_codec_against_libjpeg(tmp_path):
     open(tmp_path / "arith.jpg", "wb").write(bytes(bad))
     p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "arith.jpg"), str(tmp_path / "arith.png")], capture_output=True, text=True)
     assert p.returncode == 1 and "not supported" in p.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(RIFE_HIP), reason="rife-hip is not built")
+def test_cpp_cli_reads_every_input_format_of_the_reference(tmp_path):
+    """The reference decodes inputs with stb_image (jpeg, png, bmp, pnm enabled: src/main.cpp:14-20): low-depth / 16-bit / Adam7 PNGs,
+    24- / 32-bit / palette BMPs and P5 greymaps must read like stb reads them (3 channels, 16 -> 8 bits by the high byte, no alpha)."""
+    import struct
+    import subprocess
+    import zlib
+    from PIL import Image
+    from tools import gen_frames
+    a = gen_frames.smooth_pair(61, 37, 3)[0]
+    h, w, _ = a.shape
+
+    def transcode(src):
+        dst = tmp_path / "o.ppm"
+        p = subprocess.run([RIFE_HIP, "--transcode", str(src), str(dst)], capture_output=True, text=True)
+        assert p.returncode == 0, (src, p.stderr)
+        return np.asarray(Image.open(dst))
+
+    def via_pil(name, im, **kw):
+        src = tmp_path / name
+        im.save(src, **kw)
+        assert np.array_equal(transcode(src), np.asarray(Image.open(src).convert("RGB"))), name
+    via_pil("b1.png", Image.fromarray(a).convert("1"))
+    via_pil("p4.png", Image.fromarray(a).convert("P", palette=Image.ADAPTIVE, colors=16), bits=4)
+    via_pil("p2.png", Image.fromarray(a).convert("P", palette=Image.ADAPTIVE, colors=4), bits=2)
+    via_pil("t24.bmp", Image.fromarray(a))
+    via_pil("t32.bmp", Image.fromarray(a).convert("RGBA"))
+    via_pil("t8.bmp", Image.fromarray(a).convert("P", palette=Image.ADAPTIVE, colors=200))
+    via_pil("t.pgm", Image.fromarray(a).convert("L"))
+    g16 = a[:, :, 0].astype(np.uint16) * 257 + 13
+    Image.fromarray(g16).save(tmp_path / "g16.png")
+    assert np.array_equal(transcode(tmp_path / "g16.png")[:, :, 0], (g16 >> 8).astype(np.uint8))
+
+    # hand-made files for what PIL cannot write: Adam7 interlace, 16-bit colour, 4-bit grey
+    def png(depth, ctype, interlace, raw):
+        def chunk(t, b):
+            return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xffffffff)
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace)) + chunk(b"IDAT", zlib.compress(raw)) +
+                chunk(b"IEND", b""))
+
+    def rows(img, depth):
+        out = b""
+        for row in img:
+            if depth == 8:
+                b = row.astype(np.uint8).tobytes()
+            elif depth == 16:
+                b = row.astype(">u2").tobytes()
+            else:
+                flat = row.reshape(-1)
+                per = 8 // depth
+                flat = np.concatenate([flat, np.zeros((-len(flat)) % per, int)])
+                b = bytes(int(sum(int(v) << ((per - 1 - i) * depth) for i, v in enumerate(flat[k:k + per]))) for k in range(0, len(flat), per))
+            out += b"\x00" + b
+        return out
+
+    def adam7(img, depth):
+        x0, y0, dx, dy = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+        out = b""
+        for p in range(7):
+            sub = img[y0[p]::dy[p], x0[p]::dx[p]]
+            if sub.shape[0] and sub.shape[1]:
+                out += rows(sub, depth)
+        return out
+    a16 = a.astype(int) * 257
+    g4 = (a[:, :, :1] >> 4).astype(int)
+    cases = {"i8.png": (png(8, 2, 1, adam7(a.astype(int), 8)), a), "i16.png": (png(16, 2, 1, adam7(a16, 16)), a),
+             "rgba16.png": (png(16, 6, 0, rows(np.concatenate([a16, np.full((h, w, 1), 65535)], 2), 16)), a),
+             "g4.png": (png(4, 0, 0, rows(g4, 4)), np.repeat(g4 * 17, 3, axis=2)), "g4i.png": (png(4, 0, 1, adam7(g4, 4)), np.repeat(g4 * 17, 3, axis=2))}
+    for name, (data, want) in cases.items():
+        (tmp_path / name).write_bytes(data)
+        assert np.array_equal(transcode(tmp_path / name), want.astype(np.uint8)), name
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "i8.png").convert("RGB")), a)          # the generator itself is a valid PNG writer
