@@ -587,7 +587,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // as soon as chunk k+1 has been written to LDS (mid-chunk), the weight prefetch right after the weight slab swap.
 // ------------------------------------------------------------------------------------------------------------
 template <int NS, int NTAPS, int ROWS = 8>
-constexpr int convh2b_lds_bytes() { return 2 * (ROWS + 2) * 34 * 80 + NTAPS * 2 * NS * 32 * 16; }
+constexpr int convh2b_lds_bytes() { return 2 * (ROWS + 2) * 34 * 80 + NTAPS * 2 * NS * 32 * 16 + 2 * NS * 32 * 4; }      // + bias and slopes of the N-tile
 
 template <int NS, int NTAPS, int TAG, int ROWS = 8>
 __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS == 3 ? 2 : 4, NS == 3 ? 2 : 4))) void conv_h2b_kernel(ConvArgs a) {   // NS = 3: LDS allows 8 waves per CU anyway
@@ -600,9 +600,21 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
     constexpr int INB = IH * IW * PIXB;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* const lw = ldsb + 2 * INB;
+    // bias and activation slopes of this N-tile wait in LDS from the prologue on: fetched from global memory in the epilogue they cost
+    // every wave a full memory round trip (~4 us of a 22 us workgroup under load, tools/h2b_phase_trace.py) right when nothing else runs
+    float* const lbs = reinterpret_cast<float*>(lw + W_16 * 16);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
+    // bench-only (TAG & 32768): wave 0 of every workgroup records the shader clock at its phase boundaries into a.partial
+    // ([workgroup][16] 64-bit slots: 0 start, 8 index math done, 9 first loads issued, 10 first chunk in LDS, 1 prologue barrier passed,
+    // 2..5 one per chunk, 6 epilogue barrier passed, 7 tile in LDS, 13 stores issued, 14 stores done, 15 HW_ID | XCC_ID << 32)
+#define H2B_STAMP(SLOT)                                                                                      \
+    if ((TAG & 32768) && tid == 0) reinterpret_cast<long long*>(a.partial)[(size_t)blockIdx.x * 16 + (SLOT)] = (long long)__builtin_readcyclecounter();
+    H2B_STAMP(0)
+    if ((TAG & 32768) && tid == 0)
+        reinterpret_cast<long long*>(a.partial)[(size_t)blockIdx.x * 16 + 15] =
+            (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     const int half = lane >> 5, li = lane & 31;
     int L;
     {
@@ -687,12 +699,17 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
 
+    H2B_STAMP(8)
     H2B_ISSUE_IN(0)
     H2B_ISSUE_W(0)
+    H2B_STAMP(9)
+    if (tid < NT) { lbs[tid] = a.bias[ntile * NT + tid]; lbs[NT + tid] = a.slope[ntile * NT + tid]; }
     H2B_WRITE_IN(ldsb)
     H2B_WRITE_W()
+    H2B_STAMP(10)
     if (nch > 1) { H2B_ISSUE_IN(1) H2B_ISSUE_W(1) }
     __syncthreads();
+    H2B_STAMP(1)
     for (int ch = 0; ch < nch; ch++) {
         unsigned char* cur = ldsb + (ch & 1) * INB;
         unsigned char* oth = ldsb + ((ch & 1) ^ 1) * INB;
@@ -706,6 +723,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
             if (!(TAG & 512) && ch + 2 < nch) { H2B_ISSUE_W(ch + 2) }
             if (!(TAG & 1024)) __syncthreads();
         }
+        if (ch < 11) { H2B_STAMP(2 + ch) }
     }
 #undef H2B_ISSUE_IN
 #undef H2B_ISSUE_W
@@ -721,6 +739,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
     constexpr int ROWF = NT + 4;                               // floats per pixel row of the transpose tile (odd number of 16-B slots)
     const bool via_lds = a.nsplit == 1 && !(TAG & 256) && a.out_ld == NT && a.Cout == NT && a.nz == 1;
     if (via_lds) __syncthreads();                              // every wave is done reading the staging buffers
+    H2B_STAMP(6)
     float* const tl = reinterpret_cast<float*>(ldsb) + wv * 32 * ROWF;
 #pragma unroll
     for (int n = 0; n < NS; n++) {
@@ -728,8 +747,8 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
         for (int q = 0; q < 4; q++) {
             const int c0 = ntile * NT + n * 32 + 8 * q + 4 * half;
             const bool ok = pok && c0 < a.Cout;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbs + n * 32 + 8 * q + 4 * half);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(lbs + NT + n * 32 + 8 * q + 4 * half);
             f32x4 v;
             if (a.nsplit > 1) {                             // raw partial sums; bias / activation happen in k_splitk_reduce
 #pragma unroll
@@ -746,6 +765,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
             else if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
         }
     }
+    H2B_STAMP(7)
     if (via_lds) {
         constexpr int LPP = NT / 4;                            // lanes (16-byte chunks) per pixel
         constexpr int PPI = 64 / LPP;                          // pixels per store instruction
@@ -758,6 +778,9 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
             if ((64 % LPP == 0 || pl < PPI) && oy < a.Ho && ox0 + px < a.Wo) *reinterpret_cast<f32x4*>(orow + (size_t)px * a.out_ld) = v;      // NT = 96: lanes 48-63 idle
         }
     }
+    H2B_STAMP(13)
+    if (TAG & 32768) { __builtin_amdgcn_s_waitcnt(0); H2B_STAMP(14) }
+#undef H2B_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -2392,6 +2392,22 @@ int rife_hip_bench_h2b(int gpuid, int h, int w, int variant, int iters, float* m
         *ms_out = t / iters;
         return 0;
     };
+    if (variant == 32768) {          // phase stamps: one launch on an idle GPU, [workgroup][16] 64-bit slots copied to ms_out's neighbour buffer
+        long long* stamps = nullptr;
+        const size_t nst = (size_t)a.ntiles_xy * 16;
+        HIPCHK(hipMalloc(&stamps, nst * 8));
+        HIPCHK(hipMemset(stamps, 0, nst * 8));
+        a.partial = reinterpret_cast<float*>(stamps);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 4096 + 32768>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 4096 + 32768>), dim3(a.ntiles_xy), dim3(512), lds, 0, a);
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<long long> hs(nst);
+        HIPCHK(hipMemcpy(hs.data(), stamps, nst * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen("gpurun_out/h2b_stamps.bin", "wb")) { fwrite(hs.data(), 8, nst, f); fclose(f); }
+        *ms_out = (float)a.ntiles_xy;
+        (void)hipFree(stamps); (void)hipFree(x); (void)hipFree(y); free_layer(L);
+        return 0;
+    }
     switch (variant) {
         case 8192: rc = run(conv_h2b_kernel<2, 10, 4096>); break;
         case 0: rc = run(conv_h2b_kernel<2, 10, 4096>); break;
