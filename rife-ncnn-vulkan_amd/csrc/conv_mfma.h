@@ -646,21 +646,24 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk) + ((size_t)ntile * a.nchunks + chb) * W_16;
 
-    f32x4 rin[NIN], rw[NW];
-#define H2B_ISSUE_IN(CH)                                                                                    \
-    _Pragma("unroll") for (int k = 0; k < NIN; k++) rin[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC);
+    // two input register sets, one per chunk parity: the loads of chunk k + 3 are issued as soon as chunk k + 1 has left its set
+    // (mid-chunk k), i.e. two chunks before they are needed - one chunk ahead was not enough for the memory latency under load
+    // (tools/h2b_phase_trace.py: chunks 0..2 took 4.3 / 3.2 / 2.5 us against 1.6 us for the last one, which waits for nothing)
+    f32x4 rinA[NIN], rinB[NIN], rw[NW];
+#define H2B_ISSUE_IN(CH, RIN)                                                                               \
+    _Pragma("unroll") for (int k = 0; k < NIN; k++) RIN[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC);
 #define H2B_ISSUE_W(CH)                                                                                     \
     _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                        \
         const int idx = tid + k * NTHR;                                                                      \
         rw[k] = wsrc[(size_t)(CH) * W_16 + ((W_16 % NTHR == 0 || idx < W_16) ? idx : 0)];                    \
     }
-#define H2B_WRITE_IN(BUFP)                                                                                  \
+#define H2B_WRITE_IN(BUFP, RIN)                                                                                \
     _Pragma("unroll") for (int k = 0; k < NIN; k++) {                                                       \
         const int idx = tid + k * NTHR;                                                                      \
         const int p = idx >> 2, q = idx & 3;                                                                \
         f16x4 hi4, lo4;                                                                                     \
         _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                     \
-            const float v = ((inside >> k) & 1u) ? rin[k][e] : 0.f;                                         \
+            const float v = ((inside >> k) & 1u) ? RIN[k][e] : 0.f;                                         \
             const _Float16 h = (_Float16)v;                                                                 \
             hi4[e] = h;                                                                                     \
             lo4[e] = (_Float16)(v - (float)h);                                                              \
@@ -700,31 +703,40 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
         for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
 
     H2B_STAMP(8)
-    H2B_ISSUE_IN(0)
+    H2B_ISSUE_IN(0, rinA)
     H2B_ISSUE_W(0)
+    if (nch > 1) { H2B_ISSUE_IN(1, rinB) }
     H2B_STAMP(9)
     if (tid < NT) { lbs[tid] = a.bias[ntile * NT + tid]; lbs[NT + tid] = a.slope[ntile * NT + tid]; }
-    H2B_WRITE_IN(ldsb)
+    H2B_WRITE_IN(ldsb, rinA)
     H2B_WRITE_W()
     H2B_STAMP(10)
-    if (nch > 1) { H2B_ISSUE_IN(1) H2B_ISSUE_W(1) }
+    if (nch > 1) { H2B_ISSUE_W(1) }
+    if (!(TAG & 512) && nch > 2) { H2B_ISSUE_IN(2, rinA) }
     __syncthreads();
     H2B_STAMP(1)
-    for (int ch = 0; ch < nch; ch++) {
-        unsigned char* cur = ldsb + (ch & 1) * INB;
-        unsigned char* oth = ldsb + ((ch & 1) ^ 1) * INB;
-        H2B_TAPS(cur, 0, NTAPS / 2)
-        if (!(TAG & 2048) && ch + 1 < nch) { H2B_WRITE_IN(oth) }   // input of chunk ch+1 (issued half a chunk + ago)
-        if (!(TAG & 512) && ch + 2 < nch) { H2B_ISSUE_IN(ch + 2) }
-        H2B_TAPS(cur, NTAPS / 2, NTAPS)
-        if (ch + 1 < nch) {
-            if (!(TAG & 1024)) __syncthreads();                 // everyone is done with the weight slab of chunk ch
-            if (!(TAG & 2048)) { H2B_WRITE_W() }
-            if (!(TAG & 512) && ch + 2 < nch) { H2B_ISSUE_W(ch + 2) }
-            if (!(TAG & 1024)) __syncthreads();
-        }
-        if (ch < 11) { H2B_STAMP(2 + ch) }
+    // one chunk: RIN is the register set that holds chunk CH + 1 on entry and receives chunk CH + 3
+#define H2B_CHUNK(CH, RIN)                                                                                  \
+    {                                                                                                       \
+        unsigned char* cur = ldsb + ((CH) & 1) * INB;                                                       \
+        unsigned char* oth = ldsb + (((CH) & 1) ^ 1) * INB;                                                 \
+        H2B_TAPS(cur, 0, NTAPS / 2)                                                                         \
+        if (!(TAG & 2048) && (CH) + 1 < nch) { H2B_WRITE_IN(oth, RIN) }                                     \
+        if (!(TAG & 512) && (CH) + 3 < nch) { H2B_ISSUE_IN((CH) + 3, RIN) }                                 \
+        H2B_TAPS(cur, NTAPS / 2, NTAPS)                                                                     \
+        if ((CH) + 1 < nch) {                                                                               \
+            if (!(TAG & 1024)) __syncthreads();                 /* everyone is done with the weight slab of chunk CH */ \
+            if (!(TAG & 2048)) { H2B_WRITE_W() }                                                            \
+            if (!(TAG & 512) && (CH) + 2 < nch) { H2B_ISSUE_W((CH) + 2) }                                   \
+            if (!(TAG & 1024)) __syncthreads();                                                             \
+        }                                                                                                   \
+        if ((CH) < 11) { H2B_STAMP(2 + (CH)) }                                                              \
     }
+    for (int ch = 0; ch < nch; ch += 2) {
+        H2B_CHUNK(ch, rinB)
+        if (ch + 1 < nch) H2B_CHUNK(ch + 1, rinA)
+    }
+#undef H2B_CHUNK
 #undef H2B_ISSUE_IN
 #undef H2B_ISSUE_W
 #undef H2B_WRITE_IN
