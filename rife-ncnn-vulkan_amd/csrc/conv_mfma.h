@@ -410,7 +410,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 template <int NS, int NTAPS>
-constexpr int convh2_lds_bytes() { return 2 * (10 * 34 * 80 + NTAPS * 2 * NS * 32 * 16); }
+constexpr int convh2_lds_bytes() { return 2 * (10 * 34 * 80 + NTAPS * 2 * NS * 32 * 16) + 2 * NS * 32 * 4; }      // + bias and slopes (see conv_h2b_kernel)
 
 template <int NS, int NTAPS, int TAG>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h2_kernel(ConvArgs a) {
@@ -511,6 +511,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned char* buf0 = ldsb; unsigned char* buf1 = ldsb + BUFB;
     H2_ISSUE(rinA, rwA, 0)
     if (nch > 1) H2_ISSUE(rinB, rwB, 1)
+    float* const lbs = reinterpret_cast<float*>(ldsb + 2 * BUFB);      // bias and slopes of the N-tile, fetched while the first chunks are in flight
+    if (tid < NT) { lbs[tid] = a.bias[ntile * NT + tid]; lbs[NT + tid] = a.slope[ntile * NT + tid]; }
     H2_WRITE(rinA, rwA, buf0)
     if (nch > 2) H2_ISSUE(rinA, rwA, 2)
     __syncthreads();
@@ -548,8 +550,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < 4; q++) {
             const int c0 = ntile * NT + n * 32 + 8 * q + 4 * half;
             const bool ok = pok && c0 < a.Cout;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbs + n * 32 + 8 * q + 4 * half);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(lbs + NT + n * 32 + 8 * q + 4 * half);
             f32x4 v;
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = acc[n][4 * q + k] + b4[k];
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
 //   single LDS buffer, next chunk prefetched into registers (issue early / write late); two workgroups per CU.
 // ------------------------------------------------------------------------------------------------------------
 template <int NS>
-constexpr int convh2s2_lds_bytes() { return 9 * 65 * 80 + 9 * 2 * NS * 32 * 16; }
+constexpr int convh2s2_lds_bytes() { return 9 * 65 * 80 + 9 * 2 * NS * 32 * 16 + 2 * NS * 32 * 4; }      // + bias and slopes
 
 template <int NS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h2s2_kernel(ConvArgs a) {
@@ -881,6 +883,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned char* bb = lw + (half * NT + li) * 16;
 
     S2_ISSUE(0)
+    float* const lbs = reinterpret_cast<float*>(ldsb + 9 * 65 * 80 + 9 * 2 * NT * 16);
+    if (tid < NT) { lbs[tid] = a.bias[ntile * NT + tid]; lbs[NT + tid] = a.slope[ntile * NT + tid]; }
     S2_WRITE()
     __syncthreads();
     for (int ch = 0; ch < a.nchunks; ch++) {
@@ -916,8 +920,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < 4; q++) {
             const int c0 = ntile * NT + n * 32 + 8 * q + 4 * half;
             const bool ok = pok && c0 < a.Cout;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbs + n * 32 + 8 * q + 4 * half);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(lbs + NT + n * 32 + 8 * q + 4 * half);
             f32x4 v;
 #pragma unroll
             for (int k = 0; k < 4; k++) { v[k] = acc[n][4 * q + k] + b4[k]; v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k]; }

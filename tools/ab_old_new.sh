@@ -8,7 +8,7 @@ for rep in 1 2; do
   for v in new old; do
     if [ $v = old ]; then cp rife-ncnn-vulkan_amd/librife_hip.so /tmp/new.so; cp rife-ncnn-vulkan_amd/librife_hip_old.so rife-ncnn-vulkan_amd/librife_hip.so; fi
     python bench.py --no-cpu-baseline --steps 30 | python -c "
-import json,sys; d=json.load(sys.stdin); e=d['extra']['per_class_ms_per_pair']; print('$v', d['value'], d['extra']['frames_per_s_with_1_pair_in_flight'], {k:e[k] for k in ('trunk_b3','trunk_b2','trunk_b0')})"
+import json,sys; d=json.load(sys.stdin); e=d['extra']['per_class_ms_per_pair']; print('$v', d['value'], d['extra']['frames_per_s_with_1_pair_in_flight'], {k:e[k] for k in ('trunk_b3','trunk_b2','stem1_b3','stem1_b2')})"
     if [ $v = old ]; then cp /tmp/new.so rife-ncnn-vulkan_amd/librife_hip.so; fi
   done
 done
