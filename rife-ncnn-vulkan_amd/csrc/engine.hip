@@ -770,7 +770,11 @@ static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scra
     for (int b = 0; b < 4; b++) {
         const size_t n = P / (sc[b] * sc[b]) * 8;
         if ((rc = dalloc(c, c.flow[b], n))) return rc;
-        HIPCHK(hipMemset(c.flow[b], 0, n * 4));
+        // on the workspace's own stream, not the legacy stream: a synchronous hipMemset from one caller thread while others create
+        // streams / launch on theirs makes the runtime fail intermittently ("legacy stream depend on a capturing blocking stream", then
+        // every later call of the process reports a capture error) - tools/reentrancy_stress.py, ~1 in 100 concurrent calls
+        if (c.stream) HIPCHK(hipMemsetAsync(c.flow[b], 0, n * 4, c.stream));
+        else HIPCHK(hipMemset(c.flow[b], 0, n * 4));
     }
     if ((rc = dalloc(c, c.F, P))) return rc;
     if ((rc = dalloc(c, c.M, P))) return rc;
@@ -1942,8 +1946,17 @@ int rife_hip_process_frames(const rife_hip_t* E, const rife_hip_frame_t* f0, con
     if (f0->gpuid != E->gpuid || f1->gpuid != E->gpuid) return fail(RIFE_HIP_EINVAL, "frame was uploaded to another device");
     if ((rc = check_device(E->gpuid))) return rc;
     const size_t nbytes = (size_t)w * h * 3;
-    if (timestep == 0.f || timestep == 1.f) {                 // rife.cpp:2470-2480
-        HIPCHK(hipMemcpy(out, timestep == 0.f ? f0->d : f1->d, nbytes, hipMemcpyDeviceToHost));
+    if (timestep == 0.f || timestep == 1.f) {                 // rife.cpp:2470-2480 (a copy stream of the pool, never the legacy stream)
+        hipStream_t st = nullptr;
+        {
+            std::lock_guard<std::mutex> g(E->mu);
+            if (!E->upload_streams.empty()) { st = E->upload_streams.back(); E->upload_streams.pop_back(); }
+        }
+        hipError_t e = st ? hipSuccess : hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemcpyAsync(out, timestep == 0.f ? f0->d : f1->d, nbytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (st) { std::lock_guard<std::mutex> g(E->mu); E->upload_streams.push_back(st); }
+        if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("frame download: ") + hipGetErrorString(e));
         return 0;
     }
     std::unique_ptr<Ctx> c;
