@@ -1,0 +1,316 @@
+// Measurement and probe entry points of librife_hip.so - not part of the product path (nothing in include/rife_hip.h declares them;
+// tools/*.py and tests/test_gpu_kernels.py bind them by name): kernel ablation benches, the matrix-pipe instruction-mix benchmark, the
+// f16-subnormal and fp8 probes, the phase-stamp trace of the dominant kernel.  Included by engine.hip inside its extern "C" block.
+// bench-only: time the 8-wave trunk kernel on a synthetic (h x w x c) -> c layer; variant bits: 256 no stores,
+// 512 no global loads after chunk 1, 1024 no barriers (the last two compute garbage; timing ablations only)
+int rife_hip_bench_conv8(int gpuid, int c, int h, int w, int variant, int iters, float* ms_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    if (c != 64) return fail(RIFE_HIP_EINVAL, "bench supports c = 64");
+    std::vector<float> wts((size_t)c * c * 9, 0.01f), bias(c, 0.f);
+    ConvLayer L; L.cin = c; L.cout = c; L.stride = 1; L.epi = EPI_STORE;
+    if ((rc = upload_layer(L, wts.data(), bias.data(), nullptr, 0.2f))) return rc;
+    float *x = nullptr, *y = nullptr;
+    HIPCHK(hipMalloc(&x, (size_t)h * w * c * 4)); HIPCHK(hipMalloc(&y, (size_t)h * w * c * 4));
+    HIPCHK(hipMemset(x, 0, (size_t)h * w * c * 4));
+    ConvArgs a;
+    a.in = x; a.in_ld = c; a.in_coff = 0; a.H = h; a.W = w; a.out = y; a.out_ld = c; a.out_coff = 0;
+    a.wpk = L.d_w8; a.bias = L.d_bias; a.slope = L.d_slope; a.res = nullptr; a.res_ld = 0; a.res_coff = 0;
+    a.Ho = h; a.Wo = w; a.Cout = c; a.nchunks = L.nchunks8; a.nz = 1; a.tiles_x = (w + 31) / 32; a.ntiles_xy = a.tiles_x * ((h + 7) / 8);
+    constexpr int lds = conv8_lds_bytes<2, 8>();
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](auto kfn) -> int {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(a.ntiles_xy), dim3(512), lds, 0, a);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kfn, dim3(a.ntiles_xy), dim3(512), lds, 0, a);
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    switch (variant) {
+        case 0: rc = run(conv_mfma8_kernel<2, 8, 4, 4096>); break;
+        case 256: rc = run(conv_mfma8_kernel<2, 8, 4, 4096 + 256>); break;
+        case 512: rc = run(conv_mfma8_kernel<2, 8, 4, 4096 + 512>); break;
+        case 1024: rc = run(conv_mfma8_kernel<2, 8, 4, 4096 + 1024>); break;
+        case 768: rc = run(conv_mfma8_kernel<2, 8, 4, 4096 + 768>); break;
+        case 1792: rc = run(conv_mfma8_kernel<2, 8, 4, 4096 + 1792>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    (void)hipFree(x); (void)hipFree(y); free_layer(L);
+    return rc;
+}
+
+// hardware probe: does v_mfma_f32_32x32x16_f16 keep f16 subnormal inputs?  out[0] = sum over k of a_k*b_k with
+// a_k = 2^-20 (f16 subnormal), b_k = 1  -> 16 * 2^-20 = 1.52587890625e-05 if preserved, 0 if flushed.
+__global__ void k_probe_f16_denorm(float* out) {
+    f16x8 a, b;
+    for (int e = 0; e < 8; e++) { a[e] = (_Float16)9.5367431640625e-07f; b[e] = (_Float16)1.0f; }
+    f32x16 c;
+    for (int r = 0; r < 16; r++) c[r] = 0.f;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    if (threadIdx.x == 0) out[0] = c[0];
+}
+
+int rife_hip_probe_f16_denorm(int gpuid, float* out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    float* d = nullptr;
+    HIPCHK(hipMalloc(&d, 4));
+    hipLaunchKernelGGL(k_probe_f16_denorm, dim3(1), dim3(64), 0, 0, d);
+    HIPCHK(hipMemcpy(out, d, 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
+}
+
+// bench-only: what the matrix pipe alone sustains, on random operands, for the instruction mix of one 32 px x 64 ch trunk tile
+// (64 input channels x 10 taps): MIX 0 = today's 80 + 80 v_mfma_f32_32x32x16_f16 (hi + lo), MIX 1 = 80 f16 (hi) + 20
+// v_mfma_scale_f32_32x32x64_f8f6f4 (lo as scaled fp8), MIX 2 = the 80 hi instructions alone, MIX 3 = 80 f16 (hi) + 80 v_mfma_f32_32x32x16_fp8_fp8 (lo).  16 waves per CU like conv_h2b.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+extern "C++" {
+template <int MIX>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bench_mfma_mix(const int* __restrict__ src, float* out, int tiles) {
+    const int tid = threadIdx.x;
+    f16x8 wa[4], xb[4];
+    i32x8 wq[2], xq[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int4 v = reinterpret_cast<const int4*>(src)[(i * 512 + tid) & 4095];
+        wa[i] = *reinterpret_cast<f16x8*>(&v);
+        v = reinterpret_cast<const int4*>(src)[(2048 + i * 512 + tid) & 4095];
+        xb[i] = *reinterpret_cast<f16x8*>(&v);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            wq[i][j] = src[(i * 4096 + j * 512 + tid) & 16383] & 0x7f7f7f7f;      // positive fp8 bytes below NaN
+            xq[i][j] = src[(8192 + i * 4096 + j * 512 + tid) & 16383] & 0x7f7f7f7f;
+        }
+    f32x16 acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+    for (int t = 0; t < tiles; t++) {
+#pragma unroll
+        for (int k = 0; k < 40; k++) {
+#pragma unroll
+            for (int n = 0; n < 2; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[(k + n) & 3], xb[k & 3], acc[n], 0, 0, 0);
+            if (MIX == 0) {
+#pragma unroll
+                for (int n = 0; n < 2; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[(k + n + 1) & 3], xb[(k + 2) & 3], acc[n], 0, 0, 0);
+            }
+            if (MIX == 3) {
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(((long)wq[n][(k & 3) * 2 + 1] << 32) | (unsigned)wq[n][(k & 3) * 2],
+                                                                        ((long)xq[k & 1][((k >> 1) & 3) * 2 + 1] << 32) | (unsigned)xq[k & 1][((k >> 1) & 3) * 2], acc[n], 0, 0, 0);
+            }
+            if (MIX == 1 && (k & 3) == 3) {
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[n], xq[(k >> 2) & 1], acc[n], 0, 0, 0, 127 - 9, 0, 127 - 13);
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) sum += acc[n][r];
+    if (sum == 123.456f) out[0] = sum;
+}
+}  // extern "C++"
+
+// probe: fp8 conventions of gfx950 (OCP e4m3fn expected: 0x38 = 1.0, 0x7e = 448) for the conversion and both fp8 MFMA flavours
+__global__ void k_probe_fp8(float* out) {
+    const int lane = threadIdx.x;
+    const long a1 = 0x3838383838383838L, b2 = 0x4040404040404040L;        // 1.0 x 2.0 in e4m3fn, K = 16 -> 32
+    f32x16 c;
+    for (int r = 0; r < 16; r++) c[r] = 0.f;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b2, c, 0, 0, 0);
+    const int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(1.0f, 448.0f, 0, false);
+    const int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(1000.0f, -0.3f, 0, false);
+    const int p2 = __builtin_amdgcn_cvt_pk_fp8_f32(0.001953125f, 0.0009765625f, 0, false);      // 2^-9 (min subnormal), 2^-10
+    i32x8 a8, b8;
+    for (int j = 0; j < 8; j++) { a8[j] = 0x38383838; b8[j] = 0x40404040; }
+    f32x16 d;
+    for (int r = 0; r < 16; r++) d[r] = 0.f;
+    d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, d, 0, 0, 0, 127 - 3, 0, 127 + 1);        // 64 * 2 * 2^-3 * 2^1 = 32
+    // lane-dependent operands: which k goes with which k (legacy fp8, K = 16): A = 1.0 everywhere, B byte j of lane half g = 2^(j + 8 g - 6)?  too wide:
+    // use B byte j = 1.0 only for j == 3, half 1 -> result must equal A's byte (j = 3, half 1) value for every A pattern
+    long aj = 0, bj = 0;
+    for (int j = 0; j < 8; j++) aj |= (long)(0x30 + 8 * ((j + (lane >> 5) * 3) & 3)) << (8 * j);       // 0.5, 1, 2, 4 patterns
+    if (lane >= 32) bj = 0x38L << 24;
+    f32x16 e;
+    for (int r = 0; r < 16; r++) e[r] = 0.f;
+    e = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(aj, bj, e, 0, 0, 0);
+    if (lane == 0) {
+        out[0] = c[0]; out[1] = (float)(p0 & 0xffff); out[2] = (float)(p1 & 0xffff); out[3] = (float)(p2 & 0xffff); out[4] = d[0]; out[5] = e[0];
+    }
+}
+
+int rife_hip_probe_fp8(int gpuid, float* out6) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    float* d = nullptr;
+    HIPCHK(hipMalloc(&d, 24));
+    hipLaunchKernelGGL(k_probe_fp8, dim3(1), dim3(64), 0, 0, d);
+    HIPCHK(hipMemcpy(out6, d, 24, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
+}
+
+int rife_hip_bench_mfma_mix(int gpuid, int mix, int tiles, int iters, float* ms_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    std::vector<int> h(16384);
+    uint32_t lcg = 777u;
+    for (auto& v : h) {                                  // pairs of f16 in [-1, 1): exponent field 0x30..0x3b, random sign and mantissa
+        uint32_t w = 0;
+        for (int k = 0; k < 2; k++) {
+            lcg = lcg * 1664525u + 1013904223u;
+            const uint32_t e = 0x0c + ((lcg >> 28) % 3), m = (lcg >> 8) & 0x3ff, sg = (lcg >> 27) & 1;
+            w |= ((sg << 15) | (e << 10) | m) << (16 * k);
+        }
+        v = (int)w;
+    }
+    int* d = nullptr; float* o = nullptr;
+    HIPCHK(hipMalloc(&d, h.size() * 4)); HIPCHK(hipMalloc(&o, 4));
+    HIPCHK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto launch = [&]() {
+        if (mix == 0) hipLaunchKernelGGL(k_bench_mfma_mix<0>, dim3(512), dim3(512), 0, 0, d, o, tiles);
+        else if (mix == 1) hipLaunchKernelGGL(k_bench_mfma_mix<1>, dim3(512), dim3(512), 0, 0, d, o, tiles);
+        else if (mix == 3) hipLaunchKernelGGL(k_bench_mfma_mix<3>, dim3(512), dim3(512), 0, 0, d, o, tiles);
+        else hipLaunchKernelGGL(k_bench_mfma_mix<2>, dim3(512), dim3(512), 0, 0, d, o, tiles);
+    };
+    for (int i = 0; i < 3; i++) launch();
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) launch();
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipFree(d); (void)hipFree(o); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
+// bench-only: ablations of the split-f16 trunk kernel (variant bits: 256 no stores, 512 no prefetch loads, 1024 no barriers,
+// 2048 no LDS staging writes after the first chunk; all but 0/256 compute garbage — timing only)
+int rife_hip_bench_h2b(int gpuid, int h, int w, int variant, int iters, float* ms_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    const int c = 64;
+    // realistic operands (fp16-exact random weights, random activations): the matrix pipe clocks down under real data, an
+    // all-zero tensor flatters the kernel by ~20 %
+    std::vector<float> wts((size_t)c * c * 9), bias(c, 0.f);
+    uint32_t lcg = 12345u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((int)(lcg >> 9) - (1 << 22)) / (float)(1 << 22); };   // [-1, 1)
+    for (auto& v : wts) v = (float)(_Float16)(rnd() * 0.03f);
+    ConvLayer L; L.cin = c; L.cout = c; L.stride = 1; L.epi = EPI_STORE; L.skip = true;
+    if ((rc = upload_layer(L, wts.data(), bias.data(), nullptr, 0.2f))) return rc;
+    float *x = nullptr, *y = nullptr;
+    HIPCHK(hipMalloc(&x, (size_t)h * w * c * 4)); HIPCHK(hipMalloc(&y, (size_t)h * w * c * 4));
+    if (variant & 16384) { HIPCHK(hipMemset(x, 0, (size_t)h * w * c * 4)); variant &= ~16384; }
+    else {
+        std::vector<float> hx((size_t)h * w * c);
+        for (auto& v : hx) v = rnd();
+        HIPCHK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    }
+    ConvArgs a;
+    a.in = x; a.in_ld = c; a.in_coff = 0; a.H = h; a.W = w; a.out = y; a.out_ld = c; a.out_coff = 0;
+    a.wpk = reinterpret_cast<const float*>(L.d_wh); a.bias = L.d_bias; a.slope = L.d_slope; a.res = nullptr; a.res_ld = 0; a.res_coff = 0;
+    a.Ho = h; a.Wo = w; a.Cout = c; a.nchunks = L.nchunksh; a.nz = 1; a.tiles_x = (w + 31) / 32; a.ntiles_xy = a.tiles_x * ((h + 7) / 8);
+    constexpr int lds = convh2b_lds_bytes<2, 10>();
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    const bool pingpong = variant == 8192;
+    auto run = [&](auto kfn) -> int {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(a.ntiles_xy), dim3(512), lds, 0, a);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) {
+            if (pingpong) { a.in = (i & 1) ? y : x; a.out = (i & 1) ? x : y; }     // like consecutive trunk layers: read what the last launch wrote
+            hipLaunchKernelGGL(kfn, dim3(a.ntiles_xy), dim3(512), lds, 0, a);
+        }
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    if (variant == 32768) {          // phase stamps: one launch on an idle GPU, [workgroup][16] 64-bit slots copied to ms_out's neighbour buffer
+        long long* stamps = nullptr;
+        const size_t nst = (size_t)a.ntiles_xy * 16;
+        HIPCHK(hipMalloc(&stamps, nst * 8));
+        HIPCHK(hipMemset(stamps, 0, nst * 8));
+        a.partial = reinterpret_cast<float*>(stamps);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2b_kernel<2, 10, 4096 + 32768>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 4096 + 32768>), dim3(a.ntiles_xy), dim3(512), lds, 0, a);
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<long long> hs(nst);
+        HIPCHK(hipMemcpy(hs.data(), stamps, nst * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen("gpurun_out/h2b_stamps.bin", "wb")) { fwrite(hs.data(), 8, nst, f); fclose(f); }
+        *ms_out = (float)a.ntiles_xy;
+        (void)hipFree(stamps); (void)hipFree(x); (void)hipFree(y); free_layer(L);
+        return 0;
+    }
+    switch (variant) {
+        case 8192: rc = run(conv_h2b_kernel<2, 10, 4096>); break;
+        case 0: rc = run(conv_h2b_kernel<2, 10, 4096>); break;
+        case 256: rc = run(conv_h2b_kernel<2, 10, 4096 + 256>); break;
+        case 512: rc = run(conv_h2b_kernel<2, 10, 4096 + 512>); break;
+        case 1024: rc = run(conv_h2b_kernel<2, 10, 4096 + 1024>); break;
+        case 2048: rc = run(conv_h2b_kernel<2, 10, 4096 + 2048>); break;
+        case 2560: rc = run(conv_h2b_kernel<2, 10, 4096 + 2560>); break;
+        case 2816: rc = run(conv_h2b_kernel<2, 10, 4096 + 2816>); break;
+        case 3840: rc = run(conv_h2b_kernel<2, 10, 4096 + 3840>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    (void)hipFree(x); (void)hipFree(y); free_layer(L);
+    return rc;
+}
+
+// bench-only: ablations of stem0_fused_kernel<1,1> on a wp x hp frame (variant = ABL bits, see stem_fused.h)
+int rife_hip_bench_stemf(int gpuid, int wp, int hp, int variant, int iters, float* ms_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    const size_t P = (size_t)wp * hp;
+    uint32_t *i0 = nullptr, *i1 = nullptr; float4* F = nullptr; float *M = nullptr, *out = nullptr, *bias = nullptr; void* wh = nullptr;
+    HIPCHK(hipMalloc(&i0, P * 4)); HIPCHK(hipMalloc(&i1, P * 4)); HIPCHK(hipMalloc(&F, P * 16)); HIPCHK(hipMalloc(&M, P * 4));
+    HIPCHK(hipMalloc(&out, P / 4 * 32 * 4)); HIPCHK(hipMalloc(&bias, 64 * 4)); HIPCHK(hipMalloc(&wh, 9 * 2 * 32 * 16));
+    HIPCHK(hipMemset(i0, 0x40, P * 4)); HIPCHK(hipMemset(i1, 0x60, P * 4)); HIPCHK(hipMemset(F, 0, P * 16)); HIPCHK(hipMemset(M, 0, P * 4));
+    HIPCHK(hipMemset(bias, 0, 256)); HIPCHK(hipMemset(wh, 0, 9 * 2 * 32 * 16));
+    StemFusedArgs fa;
+    fa.img0 = i0; fa.img1 = i1; fa.F = F; fa.M = M; fa.wpk = wh; fa.bias = bias; fa.slope = bias; fa.out = out; fa.timestep = 0.5f; fa.tsp = nullptr;
+    fa.wp = wp; fa.hp = hp; fa.Ho = hp / 2; fa.Wo = wp / 2; fa.out_ld = 32; fa.Cout = 32; fa.tiles_x = (fa.Wo + 31) / 32;
+    const int nb = fa.tiles_x * ((fa.Ho + 3) / 4);
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](auto kfn) -> int {
+        for (int i = 0; i < 2; i++) hipLaunchKernelGGL(kfn, dim3(nb), dim3(512), stemf_lds_bytes<1>(), 0, fa);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kfn, dim3(nb), dim3(512), stemf_lds_bytes<1>(), 0, fa);
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    switch (variant) {
+        case 0: rc = run(stem0_fused_kernel<1, 1, 0>); break;
+        case 1: rc = run(stem0_fused_kernel<1, 1, 1>); break;
+        case 2: rc = run(stem0_fused_kernel<1, 1, 2>); break;
+        case 3: rc = run(stem0_fused_kernel<1, 1, 3>); break;
+        case 16: rc = run(stem0_fused_kernel<1, 1, 16>); break;
+        case 32: rc = run(stem0_fused_kernel<1, 1, 32>); break;
+        case 64: rc = run(stem0_fused_kernel<1, 1, 64>); break;
+        case 128: rc = run(stem0_fused_kernel<1, 1, 128>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    (void)hipFree(i0); (void)hipFree(i1); (void)hipFree(F); (void)hipFree(M); (void)hipFree(out); (void)hipFree(bias); (void)hipFree(wh);
+    return rc;
+}
+
