@@ -305,6 +305,8 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
             if (n < 6 || s[0] != 8) return fail("only 8-bit samples are supported");
             h = (s[1] << 8) | s[2]; w = (s[3] << 8) | s[4]; ncomp = s[5];
             if ((ncomp != 1 && ncomp != 3) || n < 6 + 3 * (size_t)ncomp || w <= 0 || h <= 0) return fail("unsupported component count");
+            // every 8x8 block costs at least a few bits of entropy-coded data: a header that promises far more blocks than the file can hold is corrupt
+            if ((size_t)w * h > ((size_t)1 << 28) || (size_t)w * h / 64 > d.size() * 16 + 4096) return fail("image size does not fit the file");
             for (int c = 0; c < ncomp; c++) {
                 comp[c].id = s[6 + 3 * c]; comp[c].hs = s[7 + 3 * c] >> 4; comp[c].vs = s[7 + 3 * c] & 15; comp[c].tq = s[8 + 3 * c];
                 if (comp[c].hs < 1 || comp[c].hs > 2 || comp[c].vs < 1 || comp[c].vs > 2 || comp[c].tq > 3) return fail("unsupported sampling factors");
@@ -332,6 +334,7 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
                     for (int c = 0; c < ncomp; c++) if (comp[c].id == s[1 + 2 * k]) ci = c;
                     if (ci < 0) return fail("bad scan component");
                     comp[ci].td = s[2 + 2 * k] >> 4; comp[ci].ta = s[2 + 2 * k] & 15;
+                    if (comp[ci].td > 3 || comp[ci].ta > 3) return fail("bad table selector");
                     sc[k] = ci;
                 }
                 const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
@@ -351,6 +354,7 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
                 for (int c = 0; c < ncomp; c++) if (comp[c].id == s[1 + 2 * k]) ci = c;
                 if (ci < 0) return fail("bad scan component");
                 comp[ci].td = s[2 + 2 * k] >> 4; comp[ci].ta = s[2 + 2 * k] & 15;
+                if (comp[ci].td > 3 || comp[ci].ta > 3) return fail("bad table selector");
                 if (!dc[comp[ci].td].ok || !ac[comp[ci].ta].ok || !have_qt[comp[ci].tq]) return fail("missing table");
             }
             const int mcuw = 8 * hmax, mcuh = 8 * vmax;

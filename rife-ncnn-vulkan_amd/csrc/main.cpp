@@ -98,6 +98,9 @@ static bool decode_png(const std::vector<unsigned char>& d, int& w, int& h, std:
         const int pw = interlace ? (w - X0[p] + DX[p] - 1) / DX[p] : w, ph = interlace ? (h - Y0[p] + DY[p] - 1) / DY[p] : h;
         if (pw > 0 && ph > 0) total += (row_bytes(pw) + 1) * ph;
     }
+    // a header that promises more pixels than the compressed data can hold (deflate expands at most ~1032 : 1) or than any frame has
+    // (2^28 pixels = 16K x 16K) is refused before anything of that size is allocated
+    if ((size_t)w * h > ((size_t)1 << 28) || total > idat.size() * 1100 + 65536) return false;
     std::vector<unsigned char> raw(total);
     uLongf rawlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;

@@ -288,3 +288,33 @@ def test_cpp_cli_reads_every_input_format_of_the_reference(tmp_path):
         (tmp_path / name).write_bytes(data)
         assert np.array_equal(transcode(tmp_path / name), want.astype(np.uint8)), name
     assert np.array_equal(np.asarray(Image.open(tmp_path / "i8.png").convert("RGB")), a)          # the generator itself is a valid PNG writer
+
+
+@pytest.mark.skipif(not os.path.exists(RIFE_HIP), reason="rife-hip is not built")
+def test_cpp_cli_decoders_survive_corrupt_files(tmp_path):
+    """Truncated and bit-flipped png / jpg (baseline + progressive) / bmp / pnm inputs: decode either works or fails with exit code 1 -
+    no crash, no hang, no giant allocation from a lying header (found with an ASan build of main.cpp, kept as a regression net)."""
+    import random
+    import struct
+    import subprocess
+    from PIL import Image
+    from tools import gen_frames
+    a = gen_frames.smooth_pair(97, 61, 3)[0]
+    files = {"a.png": {}, "a.jpg": dict(quality=90), "p.jpg": dict(quality=90, progressive=True), "a.bmp": {}, "a.ppm": {}}
+    rng = random.Random(7)
+    for name, kw in files.items():
+        Image.fromarray(a).save(tmp_path / name, **kw)
+        data = (tmp_path / name).read_bytes()
+        cases = [data[:k] for k in (0, 1, 2, 8, 20, 40, len(data) // 3, len(data) // 2, len(data) - 5, len(data) - 1)]
+        for _ in range(25):
+            b = bytearray(data)
+            for _ in range(rng.choice((1, 1, 2, 4, 8))):
+                i = rng.randrange(min(len(b), 700)) if rng.random() < 0.6 else rng.randrange(len(b))      # mostly headers: that is where the structure is
+                b[i] = rng.randrange(256)
+            cases.append(bytes(b))
+        if name == "a.png":       # the case that used to hang: a width of 167 million pixels
+            cases.append(data[:16] + struct.pack(">I", 167772257) + data[20:])
+        for k, c in enumerate(cases):
+            (tmp_path / "t.bin").write_bytes(c)
+            p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "t.bin"), str(tmp_path / "o.ppm")], capture_output=True, text=True, timeout=30)
+            assert p.returncode in (0, 1), (name, k, p.returncode, p.stderr[-200:])
