@@ -1668,7 +1668,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
 
 void rife_hip_destroy(rife_hip_t* r) { delete r; }
 
-int rife_hip_load(rife_hip_t* E, const char* modeldir) {
+static int rife_hip_load_impl(rife_hip_t* E, const char* modeldir) {
     if (!E || !modeldir) return fail(RIFE_HIP_EINVAL, "null argument");
     int rc;
     if ((rc = check_device(E->gpuid))) return rc;
@@ -1764,6 +1764,11 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {
     E->loaded = true;
     return 0;
 }
+int rife_hip_load(rife_hip_t* E, const char* modeldir) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_load_impl(E, modeldir); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_load: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_load: unknown exception"); }
+}
 
 static int process_common(const rife_hip* E, int w, int h, float timestep) {
     if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
@@ -1816,7 +1821,7 @@ static int enqueue_host_pair(const rife_hip* E, Ctx& c, const uint8_t* in0, cons
     return 0;
 }
 
-int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, uint8_t* out) {
+static int rife_hip_process_impl(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, uint8_t* out) {
     int rc;
     if ((rc = process_common(E, w, h, timestep))) return rc;
     if (!in0 || !in1 || !out) return fail(RIFE_HIP_EINVAL, "null frame pointer");
@@ -1831,6 +1836,11 @@ int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1
     if (c && hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(RIFE_HIP_EHIP, "stream sync failed");
     if (c) release_ctx(E, c);
     return rc;
+}
+int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, uint8_t* out) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_process_impl(E, in0, in1, w, h, timestep, out); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_process: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_process: unknown exception"); }
 }
 
 // n independent frame pairs from host memory in one call.  Copies from / to pageable host memory block the thread that issues
@@ -1905,7 +1915,7 @@ struct rife_hip_frame {
     std::shared_ptr<FramePool> pool;
 };
 
-int rife_hip_frame_upload(const rife_hip_t* E, const uint8_t* rgb, int w, int h, rife_hip_frame_t** frame) {
+static int rife_hip_frame_upload_impl(const rife_hip_t* E, const uint8_t* rgb, int w, int h, rife_hip_frame_t** frame) {
     if (frame) *frame = nullptr;
     if (!E || !rgb || !frame) return fail(RIFE_HIP_EINVAL, "null argument");
     if (w <= 0 || h <= 0) return fail(RIFE_HIP_EINVAL, "bad frame size");
@@ -1930,6 +1940,11 @@ int rife_hip_frame_upload(const rife_hip_t* E, const uint8_t* rgb, int w, int h,
     *frame = f.release();
     return 0;
 }
+int rife_hip_frame_upload(const rife_hip_t* E, const uint8_t* rgb, int w, int h, rife_hip_frame_t** frame) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_frame_upload_impl(E, rgb, w, h, frame); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_frame_upload: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_frame_upload: unknown exception"); }
+}
 
 void rife_hip_frame_release(rife_hip_frame_t* f) {
     if (!f) return;
@@ -1937,7 +1952,7 @@ void rife_hip_frame_release(rife_hip_frame_t* f) {
     delete f;
 }
 
-int rife_hip_process_frames(const rife_hip_t* E, const rife_hip_frame_t* f0, const rife_hip_frame_t* f1, float timestep, uint8_t* out) {
+static int rife_hip_process_frames_impl(const rife_hip_t* E, const rife_hip_frame_t* f0, const rife_hip_frame_t* f1, float timestep, uint8_t* out) {
     if (!f0 || !f1 || !out) return fail(RIFE_HIP_EINVAL, "null frame pointer");
     if (f0->w != f1->w || f0->h != f1->h) return fail(RIFE_HIP_EINVAL, "the two frames differ in size");
     const int w = f0->w, h = f0->h;
@@ -1976,8 +1991,13 @@ int rife_hip_process_frames(const rife_hip_t* E, const rife_hip_frame_t* f0, con
     if (c) release_ctx(E, c);
     return rc;
 }
+int rife_hip_process_frames(const rife_hip_t* E, const rife_hip_frame_t* f0, const rife_hip_frame_t* f1, float timestep, uint8_t* out) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_process_frames_impl(E, f0, f1, timestep, out); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_process_frames: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_process_frames: unknown exception"); }
+}
 
-int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* d_in1, int w, int h, float timestep, void* d_out, void* hip_stream) {
+static int rife_hip_process_device_impl(const rife_hip_t* E, const void* d_in0, const void* d_in1, int w, int h, float timestep, void* d_out, void* hip_stream) {
     int rc;
     if ((rc = process_common(E, w, h, timestep))) return rc;
     if (!d_in0 || !d_in1 || !d_out) return fail(RIFE_HIP_EINVAL, "null frame pointer");
@@ -2018,6 +2038,11 @@ int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* 
     }
     if (!hip_stream) HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
+}
+int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* d_in1, int w, int h, float timestep, void* d_out, void* hip_stream) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_process_device_impl(E, d_in0, d_in1, w, h, timestep, d_out, hip_stream); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_process_device: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_process_device: unknown exception"); }
 }
 
 int rife_hip_profile_enable(rife_hip_t* E, int on) {
@@ -2085,10 +2110,15 @@ int rife_hip_v4_extract_flow(const rife_hip_t* E, const uint8_t* in0, const uint
     return 0;
 }
 
-int rife_hip_graph_check(const char* base) {
+static int rife_hip_graph_check_impl(const char* base) {
     if (!base) return fail(RIFE_HIP_EINVAL, "null argument");
     GraphNet n;
     return graph_load(n, base, true);
+}
+int rife_hip_graph_check(const char* base) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_graph_check_impl(base); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_graph_check: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_graph_check: unknown exception"); }
 }
 
 int rife_hip_v4_flow_dims(const rife_hip_t* E, int w, int h, int fi, int* channels, int* fh, int* fw) {
@@ -2167,11 +2197,16 @@ int rife_hip_op_warp(int gpuid, const float* image, const float* flow, int c, in
 #include "bench_hooks.h"      // bench-only / probe entry points (tools/*.py)
 
 // tooling: structural hash of a named blob of a .param file (used to derive / test the compiled-in constants)
-int rife_hip_param_hash(const char* param_path, const char* blob, uint64_t* out) {
+static int rife_hip_param_hash_impl(const char* param_path, const char* blob, uint64_t* out) {
     NcnnModel m;
     if (!m.load_param(param_path)) return fail(RIFE_HIP_EIO, m.error);
     *out = m.structural_hash(blob);
     return *out ? 0 : fail(RIFE_HIP_EMODEL, "no such blob");
+}
+int rife_hip_param_hash(const char* param_path, const char* blob, uint64_t* out) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_param_hash_impl(param_path, blob, out); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_param_hash: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_param_hash: unknown exception"); }
 }
 
 }  // extern "C"

@@ -83,6 +83,12 @@ static int graph_load(GraphNet& N, const std::string& base, bool check_only = fa
         const std::string& t = nl.type;
         L.out_blob = L.tops.empty() ? -1 : L.tops[0];
         auto bad = [&](const std::string& why) { return fail(RIFE_HIP_EMODEL, base + ".param: layer " + nl.name + " (" + t + "): " + why); };
+        {   // arity first: everything below indexes bottoms / tops by position
+            const size_t nb = L.bottoms.size(), nt = L.tops.size();
+            const bool ok = t == "Input" ? (nb == 0 && nt >= 1) : t == "Split" ? (nb == 1 && nt >= 1) : t == "Concat" ? (nb >= 1 && nt == 1)
+                          : t == "BinaryOp" ? ((nb == 1 || nb == 2) && nt == 1) : (t == "Eltwise" || t == "rife.Warp") ? (nb == 2 && nt == 1) : (nb == 1 && nt == 1);
+            if (!ok) return bad("unexpected number of inputs / outputs");
+        }
         if (t == "Input") L.kind = G_INPUT;
         else if (t == "Split") L.kind = G_SPLIT;
         else if (t == "Concat") L.kind = G_CONCAT;

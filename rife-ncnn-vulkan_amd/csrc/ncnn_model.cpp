@@ -5,6 +5,7 @@
 #include <cstring>
 #include <fstream>
 #include <functional>
+#include <set>
 #include <sstream>
 
 namespace rife {
@@ -22,9 +23,11 @@ bool NcnnModel::load_param(const std::string& path) {
         std::istringstream ss(line);
         NcnnLayer L; int nin = 0, nout = 0;
         if (!(ss >> L.type >> L.name >> nin >> nout)) continue;
+        if (nin < 0 || nout < 0 || nin > 4096 || nout > 4096) { error = path + ": implausible blob count in layer " + L.name; return false; }
         L.bottoms.resize(nin); L.tops.resize(nout);
         for (auto& b : L.bottoms) ss >> b;
         for (auto& t : L.tops) ss >> t;
+        if (!ss) { error = path + ": layer line of " + L.name + " ends before its blob names"; return false; }
         std::string kv;
         while (ss >> kv) {
             const size_t eq = kv.find('=');
@@ -68,6 +71,7 @@ bool NcnnModel::load_bin(const std::string& path) {
     for (NcnnLayer& L : layers) {
         if (L.type == "Convolution" || L.type == "Deconvolution") {
             const int n = L.geti(6, 0), outc = L.geti(0, 0);
+            if (n < 0 || outc < 0 || (size_t)n > total || (size_t)outc > total) { error = path + ": weight count of " + L.name + " exceeds the file"; return false; }
             if (!have(4)) { error = path + ": truncated"; return false; }
             uint32_t tag; std::memcpy(&tag, &raw[pos], 4); pos += 4;
             L.weight.resize(n);
@@ -78,21 +82,25 @@ bool NcnnModel::load_bin(const std::string& path) {
                 pos += bytes;
             } else if (tag == 0) {               // raw fp32
                 if (!have((size_t)n * 4)) { error = path + ": truncated"; return false; }
-                std::memcpy(L.weight.data(), &raw[pos], (size_t)n * 4); pos += (size_t)n * 4;
+                if (n) std::memcpy(L.weight.data(), &raw[pos], (size_t)n * 4);
+                pos += (size_t)n * 4;
             } else { error = path + ": unsupported weight storage tag"; return false; }
             L.bias.assign(outc, 0.f);
             if (L.geti(5, 0)) {
                 if (!have((size_t)outc * 4)) { error = path + ": truncated"; return false; }
-                std::memcpy(L.bias.data(), &raw[pos], (size_t)outc * 4); pos += (size_t)outc * 4;
+                if (outc) std::memcpy(L.bias.data(), &raw[pos], (size_t)outc * 4);
+                pos += (size_t)outc * 4;
             }
         } else if (L.type == "PReLU") {
             const int n = L.geti(0, 0);
-            if (!have((size_t)n * 4)) { error = path + ": truncated"; return false; }
+            if (n < 0 || !have((size_t)n * 4)) { error = path + ": truncated"; return false; }
             L.slope.resize(n);
-            std::memcpy(L.slope.data(), &raw[pos], (size_t)n * 4); pos += (size_t)n * 4;
+            if (n) std::memcpy(L.slope.data(), &raw[pos], (size_t)n * 4);
+            pos += (size_t)n * 4;
         } else if (L.type == "InnerProduct") {
             // 0 = num_output, 1 = bias_term, 2 = weight_data_size (SE blocks of the v1 family, models/rife/flownet.param:15-16)
             const int n = L.geti(2, 0), outc = L.geti(0, 0);
+            if (n < 0 || outc < 0 || (size_t)n > total || (size_t)outc > total) { error = path + ": weight count of " + L.name + " exceeds the file"; return false; }
             if (!have(4)) { error = path + ": truncated"; return false; }
             uint32_t tag; std::memcpy(&tag, &raw[pos], 4); pos += 4;
             L.weight.resize(n);
@@ -103,12 +111,14 @@ bool NcnnModel::load_bin(const std::string& path) {
                 pos += bytes;
             } else if (tag == 0) {
                 if (!have((size_t)n * 4)) { error = path + ": truncated"; return false; }
-                std::memcpy(L.weight.data(), &raw[pos], (size_t)n * 4); pos += (size_t)n * 4;
+                if (n) std::memcpy(L.weight.data(), &raw[pos], (size_t)n * 4);
+                pos += (size_t)n * 4;
             } else { error = path + ": unsupported weight storage tag"; return false; }
             L.bias.assign(outc, 0.f);
             if (L.geti(1, 0)) {
                 if (!have((size_t)outc * 4)) { error = path + ": truncated"; return false; }
-                std::memcpy(L.bias.data(), &raw[pos], (size_t)outc * 4); pos += (size_t)outc * 4;
+                if (outc) std::memcpy(L.bias.data(), &raw[pos], (size_t)outc * 4);
+                pos += (size_t)outc * 4;
             }
         }
     }
@@ -140,14 +150,16 @@ uint64_t NcnnModel::structural_hash(const std::string& blob) const {
         for (size_t t = 0; t < L.tops.size(); t++) producer[L.tops[t]] = {(int)li, (int)t};
     }
     std::map<std::string, uint64_t> memo;
+    std::set<std::string> open_blobs;                      // blobs on the current path: a malformed file may contain a cycle
     std::function<uint64_t(const std::string&)> H = [&](const std::string& b) -> uint64_t {
         auto mi = memo.find(b);
         if (mi != memo.end()) return mi->second;
         auto pi = producer.find(b);
         if (pi == producer.end()) return 0;
+        if (!open_blobs.insert(b).second || open_blobs.size() > 4096) return 0;      // cycle, or deeper than any real graph: no valid hash
         const NcnnLayer& L = layers[pi->second.first];
         uint64_t h = 14695981039346656037ull;
-        if (L.type == "Split") h = H(L.bottoms[0]);
+        if (L.type == "Split") h = L.bottoms.empty() ? 0 : H(L.bottoms[0]);
         else if (L.type == "Input") h = fnv_s(fnv_s(h, "Input"), b);
         else {
             char tmp[64];
@@ -161,6 +173,7 @@ uint64_t NcnnModel::structural_hash(const std::string& blob) const {
             }
             for (const std::string& x : L.bottoms) { uint64_t hx = H(x); h = fnv(h, &hx, 8); }
         }
+        open_blobs.erase(b);
         memo[b] = h;
         return h;
     };

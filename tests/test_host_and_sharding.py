@@ -134,3 +134,31 @@ def test_graph_executor_covers_the_reference_model_zoo():
             base = os.path.join(REFERENCE, "models", fam, net)
             if os.path.exists(base + ".param"):
                 amd.graph_check(base)
+
+
+def test_malformed_param_files_are_refused_not_fatal(modeldirs, tmp_path):
+    """A damaged .param must come back as an error through the C-ABI (never an exception or a crash across it): cyclic graphs, layer lines
+    that end early, shifted fields, absurd counts - found by fuzzing rife_hip_graph_check / NcnnModel under ASan; seeded mutations here."""
+    import random
+    ok = refused = 0
+    for fam, net in (("rife", "flownet"), ("rife-HD", "fusionnet"), ("rife-v4.6", "flownet"), ("rife-v2.3", "contextnet")):
+        txt = open(os.path.join(modeldirs[fam], net + ".param"), "rb").read()
+        rng = random.Random(len(txt))
+        cases = []
+        for _ in range(60):
+            b = bytearray(txt)
+            for _ in range(rng.choice((1, 2, 4, 8))):
+                b[rng.randrange(len(b))] = rng.choice(b"0123456789 -=\n,.ae")
+            cases.append(bytes(b))
+        lines = txt.split(b"\n")
+        cases.append(b"\n".join(lines[:2] + [lines[5].replace(lines[5].split()[-1 - sum(b"=" in t for t in lines[5].split())], lines[5].split()[4])] + lines[2:]))   # a layer that feeds itself
+        cases.append(b"\n".join(l[: len(l) // 2] if i == 7 else l for i, l in enumerate(lines)))                                                             # a line cut in half
+        cases.append(txt.replace(b" 1 1 ", b" 1000000000 1 ", 1))                                                                                             # absurd input count
+        for c in cases:
+            (tmp_path / "g.param").write_bytes(c)
+            try:
+                amd.graph_check(str(tmp_path / "g"))
+                ok += 1
+            except amd.RifeError:
+                refused += 1
+    assert refused > 100 and ok + refused == 4 * 63
