@@ -23,13 +23,20 @@ struct Huff {
     // canonical code tables: for each length 1..16 the first code, first symbol index and count
     int mincode[17], maxcode[18], valptr[17];
     uint8_t vals[256];
+    uint16_t lut[512];        // the next 9 bits -> (length << 8) | symbol for codes of up to 9 bits, 0 = longer code
     bool ok = false;
     void build(const uint8_t* counts, const uint8_t* symbols, int nsym) {
         std::memcpy(vals, symbols, (size_t)nsym);
+        std::memset(lut, 0, sizeof lut);
         int code = 0, k = 0;
         for (int l = 1; l <= 16; l++) {
             valptr[l] = k; mincode[l] = code;
-            code += counts[l - 1]; k += counts[l - 1];
+            for (int i = 0; i < counts[l - 1]; i++, k++, code++)
+                if (l <= 9 && k < nsym)
+                    for (int f = 0; f < (1 << (9 - l)); f++) {
+                        const int idx = (code << (9 - l)) | f;
+                        if (idx < 512) lut[idx] = (uint16_t)((l << 8) | vals[k]);
+                    }
             maxcode[l] = counts[l - 1] ? code - 1 : -1;
             code <<= 1;
         }
@@ -38,61 +45,99 @@ struct Huff {
     }
 };
 
+// Entropy-coded segment reader: a 64-bit window refilled bytewise (0xFF 0x00 unstuffed); at a marker it stops consuming (`p` stays on the
+// 0xFF) and feeds zero bits until the caller has dealt with the marker.
 struct BitReader {
     const uint8_t* p; const uint8_t* end;
-    uint32_t acc = 0; int n = 0; bool marker = false;
-    int bit() {
-        if (n == 0) {
+    uint64_t acc = 0; int n = 0; bool marker = false;
+    void fill() {
+        while (n <= 56) {
             int b = 0;
             if (p < end && !marker) {
                 b = *p++;
                 if (b == 0xFF) {
                     if (p < end && *p == 0) p++;               // stuffed zero
-                    else { marker = true; b = 0; p--; }        // a marker: feed zeros until the caller handles it
+                    else { marker = true; b = 0; p--; }        // a marker: zeros from here on
                 }
             }
-            acc = (uint32_t)b; n = 8;
+            acc |= (uint64_t)b << (56 - n);
+            n += 8;
         }
-        n--;
-        return (acc >> n) & 1;
     }
-    int bits(int k) { int v = 0; while (k--) v = (v << 1) | bit(); return v; }
-    void align() { n = 0; }
+    int peek(int k) { if (n < k) fill(); return (int)(acc >> (64 - k)); }                 // 1 <= k <= 16
+    void skip(int k) { acc <<= k; n -= k; }
+    int bit() { const int v = peek(1); skip(1); return v; }
+    int bits(int k) { if (k == 0) return 0; const int v = peek(k); skip(k); return v; }
+    void align() { const int r = n & 7; acc <<= r; n -= r; }                              // drop the pad bits before a marker
 };
 
 static inline int decode_symbol(BitReader& br, const Huff& h) {
-    int code = 0;
-    for (int l = 1; l <= 16; l++) {
-        code = (code << 1) | br.bit();
-        if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    const int look = br.peek(16);
+    const int e = h.lut[look >> 7];
+    if (e) { br.skip(e >> 8); return e & 0xff; }
+    for (int l = 10; l <= 16; l++) {
+        const int code = look >> (16 - l);
+        if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) { br.skip(l); return h.vals[h.valptr[l] + code - h.mincode[l]]; }
     }
     return -1;
 }
 
 static inline int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
 
-// 8x8 inverse DCT (separable, double precision cosine table), level shift + clamp to u8
-static inline void idct8x8(const float* in, uint8_t* out, int stride) {
-    static float C[8][8]; static bool init = false;
-    if (!init) {
-        for (int x = 0; x < 8; x++) for (int u = 0; u < 8; u++) C[x][u] = (float)((u == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * u * M_PI / 16.0));
-        init = true;
+// 8x8 inverse DCT, level shift + clamp to u8: the AAN factorisation libjpeg's float decoder uses (5 multiplies per 1-D pass; the per-
+// frequency scale factors and the 1/8 are folded into the dequantisation table, `idct_scale`), columns whose AC terms are all zero are a
+// copy.  Agrees with the textbook separable IDCT to 1e-3 of a level on coefficients of +-1000.
+static inline float idct_scale(int natural_index) {
+    static const float AAN[8] = {1.0f, 1.387039845f, 1.306562965f, 1.175875602f, 1.0f, 0.785694958f, 0.541196100f, 0.275899379f};
+    return AAN[natural_index >> 3] * AAN[natural_index & 7] * 0.125f;
+}
+static inline void idct_1d(const float* i0, int is, float* o0, int os) {
+    float tmp0 = i0[0 * is], tmp1 = i0[2 * is], tmp2 = i0[4 * is], tmp3 = i0[6 * is];
+    float tmp10 = tmp0 + tmp2, tmp11 = tmp0 - tmp2;
+    float tmp13 = tmp1 + tmp3, tmp12 = (tmp1 - tmp3) * 1.414213562f - tmp13;
+    tmp0 = tmp10 + tmp13; tmp3 = tmp10 - tmp13; tmp1 = tmp11 + tmp12; tmp2 = tmp11 - tmp12;
+    float tmp4 = i0[1 * is], tmp5 = i0[3 * is], tmp6 = i0[5 * is], tmp7 = i0[7 * is];
+    const float z13 = tmp6 + tmp5, z10 = tmp6 - tmp5, z11 = tmp4 + tmp7, z12 = tmp4 - tmp7;
+    tmp7 = z11 + z13;
+    tmp11 = (z11 - z13) * 1.414213562f;
+    const float z5 = (z10 + z12) * 1.847759065f;
+    tmp10 = 1.082392200f * z12 - z5;
+    tmp12 = -2.613125930f * z10 + z5;
+    tmp6 = tmp12 - tmp7; tmp5 = tmp11 - tmp6; tmp4 = tmp10 + tmp5;
+    o0[0 * os] = tmp0 + tmp7; o0[7 * os] = tmp0 - tmp7;
+    o0[1 * os] = tmp1 + tmp6; o0[6 * os] = tmp1 - tmp6;
+    o0[2 * os] = tmp2 + tmp5; o0[5 * os] = tmp2 - tmp5;
+    o0[4 * os] = tmp3 + tmp4; o0[3 * os] = tmp3 - tmp4;
+}
+static inline void idct8x8(const float* in /* coefficients x idct_scale, natural order */, uint8_t* out, int stride) {
+    float t[64];
+    bool dc_only = true;
+    for (int u = 0; u < 8; u++) {
+        if (in[8 + u] == 0.f && in[16 + u] == 0.f && in[24 + u] == 0.f && in[32 + u] == 0.f && in[40 + u] == 0.f && in[48 + u] == 0.f && in[56 + u] == 0.f) {
+            for (int v = 0; v < 8; v++) t[v * 8 + u] = in[u];
+            if (u && in[u] != 0.f) dc_only = false;
+        } else { idct_1d(in + u, 8, t + u, 8); dc_only = false; }
     }
-    float tmp[64];
-    for (int v = 0; v < 8; v++)            // rows: over u
-        for (int x = 0; x < 8; x++) { float s = 0; for (int u = 0; u < 8; u++) s += C[x][u] * in[v * 8 + u]; tmp[v * 8 + x] = s; }
-    for (int x = 0; x < 8; x++)
-        for (int y = 0; y < 8; y++) {
-            float s = 0; for (int v = 0; v < 8; v++) s += C[y][v] * tmp[v * 8 + x];
-            const int q = (int)std::lround(s + 128.f);
-            out[y * stride + x] = (uint8_t)(q < 0 ? 0 : q > 255 ? 255 : q);
+    if (dc_only) {
+        const float r = in[0] + 128.5f;                    // round half up (same as lround wherever the clamp does not decide)
+        const uint8_t px = (uint8_t)(r < 0.f ? 0 : r >= 255.f ? 255 : (int)r);
+        for (int y = 0; y < 8; y++) std::memset(out + y * stride, px, 8);
+        return;
+    }
+    for (int v = 0; v < 8; v++) {
+        float row[8];
+        idct_1d(t + v * 8, 1, row, 1);
+        for (int x = 0; x < 8; x++) {
+            const float r = row[x] + 128.5f;
+            out[v * stride + x] = (uint8_t)(r < 0.f ? 0 : r >= 255.f ? 255 : (int)r);
         }
+    }
 }
 
 inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgb, std::string* why = nullptr) {
     auto fail = [&](const char* m) { if (why) *why = m; return false; };
     if (d.size() < 4 || d[0] != 0xFF || d[1] != 0xD8) return fail("not a JPEG");
-    uint16_t qt[4][64]; bool have_qt[4] = {false, false, false, false};
+    float qt[4][64]; bool have_qt[4] = {false, false, false, false};      // natural order, pre-multiplied by idct_scale
     Huff dc[4], ac[4];
     struct Comp {
         int id, hs, vs, tq, td, ta; int bw, bh; std::vector<uint8_t> plane; int pred;
@@ -116,29 +161,30 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
             if (C.hs == hmax && C.vs == vmax) {
                 for (int y = 0; y < h; y++) std::memcpy(&full[c][(size_t)y * w], &C.plane[(size_t)y * C.bw], (size_t)w);
             } else if (h2 && !v2 && C.vs == vmax) {                                                 // h2v1
-                for (int y = 0; y < h; y++)
-                    for (int x = 0; x < w; x++) {
-                        const int i = x >> 1;
-                        int v;
-                        if (cw == 1) v = S(y, 0);
-                        else if (x == 0) v = S(y, 0);
-                        else if (x == 2 * cw - 1) v = S(y, cw - 1);
-                        else v = (x & 1) ? (S(y, i) * 3 + S(y, i + 1) + 2) >> 2 : (S(y, i) * 3 + S(y, i - 1) + 1) >> 2;
-                        full[c][(size_t)y * w + x] = (uint8_t)v;
-                    }
-            } else if (h2 && v2) {                                                                  // h2v2
                 for (int y = 0; y < h; y++) {
-                    const int r = y >> 1, rn = (y & 1) ? r + 1 : r - 1;                             // nearer / farther input row (edges replicate)
+                    const uint8_t* p = &C.plane[(size_t)std::min(y, chh - 1) * C.bw];
+                    uint8_t* o = &full[c][(size_t)y * w];
                     for (int x = 0; x < w; x++) {
                         const int i = x >> 1;
-                        const int cs = S(r, i) * 3 + S(rn, i);
+                        o[x] = (uint8_t)((cw == 1 || x == 0 || x == 2 * cw - 1) ? p[std::min(i, cw - 1)] : (x & 1) ? (p[i] * 3 + p[i + 1] + 2) >> 2 : (p[i] * 3 + p[i - 1] + 1) >> 2);
+                    }
+                }
+            } else if (h2 && v2) {                                                                  // h2v2
+                std::vector<int> cs(cw);                                                            // 3 * nearer row + farther row, per chroma column
+                for (int y = 0; y < h; y++) {
+                    const int r = std::min(y >> 1, chh - 1), rn = std::min(std::max((y & 1) ? r + 1 : r - 1, 0), chh - 1);      // edges replicate
+                    const uint8_t* p0 = &C.plane[(size_t)r * C.bw];
+                    const uint8_t* p1 = &C.plane[(size_t)rn * C.bw];
+                    for (int i = 0; i < cw; i++) cs[i] = p0[i] * 3 + p1[i];
+                    uint8_t* o = &full[c][(size_t)y * w];
+                    for (int x = 0; x < w; x++) {
+                        const int i = x >> 1;
                         int v;
-                        if (cw == 1) v = (cs * 4 + 8) >> 4;
-                        else if (x == 0) v = (cs * 4 + 8) >> 4;
-                        else if (x == 2 * cw - 1) v = (cs * 4 + 7) >> 4;
-                        else if (x & 1) v = (cs * 3 + S(r, i + 1) * 3 + S(rn, i + 1) + 7) >> 4;
-                        else v = (cs * 3 + S(r, i - 1) * 3 + S(rn, i - 1) + 8) >> 4;
-                        full[c][(size_t)y * w + x] = (uint8_t)v;
+                        if (cw == 1 || x == 0) v = (cs[0] * 4 + 8) >> 4;
+                        else if (x == 2 * cw - 1) v = (cs[cw - 1] * 4 + 7) >> 4;
+                        else if (x & 1) v = (cs[i] * 3 + cs[i + 1] + 7) >> 4;
+                        else v = (cs[i] * 3 + cs[i - 1] + 8) >> 4;
+                        o[x] = (uint8_t)v;
                     }
                 }
             } else {
@@ -150,8 +196,9 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
         for (size_t i = 0; i < (size_t)w * h; i++) {
             unsigned char* o = &rgb[i * 3];
             if (ncomp == 1) { o[0] = o[1] = o[2] = full[0][i]; continue; }
-            const float Y = full[0][i], cb = (float)full[1][i] - 128.f, cr = (float)full[2][i] - 128.f;
-            const int ri = (int)std::lround(Y + 1.402f * cr), gi = (int)std::lround(Y - 0.344136f * cb - 0.714136f * cr), bi = (int)std::lround(Y + 1.772f * cb);
+            // JFIF YCbCr -> RGB in 16-bit fixed point (libjpeg's constants); the arithmetic shift floors, + 32768 rounds
+            const int Y = full[0][i], cb = (int)full[1][i] - 128, cr = (int)full[2][i] - 128;
+            const int ri = Y + ((91881 * cr + 32768) >> 16), gi = Y - ((22554 * cb + 46802 * cr + 32768) >> 16), bi = Y + ((116130 * cb + 32768) >> 16);
             o[0] = (uint8_t)(ri < 0 ? 0 : ri > 255 ? 255 : ri); o[1] = (uint8_t)(gi < 0 ? 0 : gi > 255 ? 255 : gi); o[2] = (uint8_t)(bi < 0 ? 0 : bi > 255 ? 255 : bi);
         }
         return true;
@@ -234,7 +281,7 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
             br.align();
             while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) br.p++;
             if (br.p + 1 < br.end) br.p += 2;
-            br.marker = false; br.n = 0;
+            br.marker = false; br.n = 0; br.acc = 0;
             for (int k = 0; k < ns; k++) comp[sc[k]].pred = 0;
             eobrun = 0;
         };
@@ -265,7 +312,7 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
                 for (int bx = 0; bx < C.nbx; bx++) {
                     const int16_t* q = &C.coef[((size_t)by * C.nbx + bx) * 64];
                     float blk[64];
-                    for (int k = 0; k < 64; k++) blk[k] = (float)(q[k] * (int)qt[C.tq][k]);
+                    for (int k = 0; k < 64; k++) blk[k] = (float)q[k] * qt[C.tq][k];
                     idct8x8(blk, &C.plane[(size_t)by * 8 * C.bw + bx * 8], C.bw);
                 }
         }
@@ -288,7 +335,7 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
             while (i < n) {
                 const int pq = s[i] >> 4, tq = s[i] & 15; i++;
                 if (tq > 3 || i + (pq ? 128 : 64) > n) return fail("bad DQT");
-                for (int k = 0; k < 64; k++) { qt[tq][ZIGZAG[k]] = pq ? (uint16_t)((s[i] << 8) | s[i + 1]) : s[i]; i += pq ? 2 : 1; }
+                for (int k = 0; k < 64; k++) { qt[tq][ZIGZAG[k]] = (float)(pq ? ((s[i] << 8) | s[i + 1]) : s[i]) * idct_scale(ZIGZAG[k]); i += pq ? 2 : 1; }
                 have_qt[tq] = true;
             }
         } else if (m == 0xC4) {
@@ -373,7 +420,7 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
                         // skip to and over the RSTn marker
                         while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) br.p++;
                         if (br.p + 1 < br.end) br.p += 2;
-                        br.marker = false; br.n = 0;
+                        br.marker = false; br.n = 0; br.acc = 0;
                         for (int c = 0; c < ncomp; c++) comp[c].pred = 0;
                     }
                     count++;
@@ -386,7 +433,7 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
                                 if (t < 0 || t > 11) return fail("bad DC code");
                                 const int diff = t ? extend(br.bits(t), t) : 0;
                                 comp[c].pred += diff;
-                                blk[0] = (float)(comp[c].pred * qt[comp[c].tq][0]);
+                                blk[0] = (float)comp[c].pred * qt[comp[c].tq][0];
                                 for (int k = 1; k < 64;) {
                                     const int rs = decode_symbol(br, ac[comp[c].ta]);
                                     if (rs < 0) return fail("bad AC code");
@@ -394,7 +441,7 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
                                     if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
                                     k += r;
                                     if (k > 63) return fail("AC run past the block");
-                                    blk[ZIGZAG[k]] = (float)(extend(br.bits(sz), sz) * qt[comp[c].tq][ZIGZAG[k]]);
+                                    blk[ZIGZAG[k]] = (float)extend(br.bits(sz), sz) * qt[comp[c].tq][ZIGZAG[k]];
                                     k++;
                                 }
                                 const int px = (xx * comp[c].hs + bx) * 8, py = (yy * comp[c].vs + by) * 8;
