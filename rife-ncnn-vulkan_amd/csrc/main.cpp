@@ -373,7 +373,7 @@ static bool encode_image(const std::string& path, int w, int h, const unsigned c
     const std::string e = ext_of(path);
     if (e == "ppm") return encode_ppm(path, w, h, rgb);
     if (e == "webp") return encode_webp(path, w, h, rgb);
-    if (e == "jpg" || e == "jpeg") return jpeg::encode(path, w, h, rgb);
+    if (e == "jpg" || e == "jpeg") return jpeg::encode(path, w, h, rgb, g_png_helpers);      // same spare cores as the PNG writer
     return encode_png(path, w, h, rgb);
 }
 
