@@ -274,6 +274,78 @@ int rife_hip_bench_h2b(int gpuid, int h, int w, int variant, int iters, float* m
     return rc;
 }
 
+// bench-only: the persistent S16 trunk kernel (conv_t64.h) on an h x w tensor of random records, ping-pong between two tensors like
+// consecutive trunk layers; variant = ablation bits of conv_t64.h (0 = the product kernel); T64_STAMPS writes gpurun_out/t64_stamps.bin
+int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* ms_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    std::vector<float> wts((size_t)64 * 64 * 9), bias(64, 0.f);
+    uint32_t lcg = 12345u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((int)(lcg >> 9) - (1 << 22)) / (float)(1 << 22); };   // [-1, 1)
+    for (auto& v : wts) v = (float)(_Float16)(rnd() * 0.03f);
+    std::vector<unsigned char> img = pack_t64_image(wts.data(), bias.data(), 0.2f);
+    const S16Geom G(h, w);
+    const size_t nb = G.bytes(64);
+    unsigned char *x = nullptr, *y = nullptr, *dimg = nullptr;
+    HIPCHK(hipMalloc(&x, nb)); HIPCHK(hipMalloc(&y, nb)); HIPCHK(hipMalloc(&dimg, img.size()));
+    HIPCHK(hipMemcpy(dimg, img.data(), img.size(), hipMemcpyHostToDevice));
+    {   // random {hi, lo} records in the interior, zero border
+        std::vector<_Float16> hx(nb / 2, (_Float16)0.f);
+        for (int yy = 0; yy < h; yy++)
+            for (int xx = 0; xx < w; xx++) {
+                _Float16* rec = hx.data() + ((size_t)(yy + 1) * G.pitch + xx + 1) * 128;
+                for (int c = 0; c < 4; c++)
+                    for (int e = 0; e < 16; e++) { const float v = rnd(); const _Float16 hh = (_Float16)v; rec[c * 32 + e] = hh; rec[c * 32 + 16 + e] = (_Float16)(v - (float)hh); }
+            }
+        HIPCHK(hipMemcpy(x, hx.data(), nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(y, 0, nb));
+    }
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpuid));
+    T64Args a;
+    a.in = x; a.out = y; a.img = dimg; a.H = h; a.W = w; a.pitch = G.pitch; a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y;
+    const int nwg = std::min(cus / 8 * 8, ((a.ntiles + 1) / 2 + 7) / 8 * 8);
+    a.rounds = (a.ntiles + 2 * nwg - 1) / (2 * nwg);
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](auto kfn) -> int {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, T64_LDS));
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(1024), T64_LDS, 0, a);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) {
+            a.in = (i & 1) ? y : x; a.out = (i & 1) ? x : y;
+            hipLaunchKernelGGL(kfn, dim3(nwg), dim3(1024), T64_LDS, 0, a);
+        }
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    if (variant == T64_STAMPS) {
+        const size_t nst = (size_t)nwg * 16 * 32 * 4;
+        HIPCHK(hipMalloc(&a.stamps, nst * 8));
+        HIPCHK(hipMemset(a.stamps, 0, nst * 8));
+        rc = run(conv_t64_kernel<T64_STAMPS>);
+        std::vector<long long> hs(nst);
+        HIPCHK(hipMemcpy(hs.data(), a.stamps, nst * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen("gpurun_out/t64_stamps.bin", "wb")) { fwrite(hs.data(), 8, nst, f); fclose(f); }
+        (void)hipFree(a.stamps);
+    } else switch (variant) {
+        case 0: rc = run(conv_t64_kernel<0>); break;
+        case T64_NOSTORE: rc = run(conv_t64_kernel<T64_NOSTORE>); break;
+        case T64_NODMA: rc = run(conv_t64_kernel<T64_NODMA>); break;
+        case T64_NOMATH: rc = run(conv_t64_kernel<T64_NOMATH>); break;
+        case T64_NOVMWAIT: rc = run(conv_t64_kernel<T64_NOVMWAIT>); break;
+        case T64_NODMA | T64_NOSTORE: rc = run(conv_t64_kernel<T64_NODMA | T64_NOSTORE>); break;
+        case T64_NOMATH | T64_NOSTORE: rc = run(conv_t64_kernel<T64_NOMATH | T64_NOSTORE>); break;
+        case T64_NOMATH | T64_NODMA: rc = run(conv_t64_kernel<T64_NOMATH | T64_NODMA>); break;
+        case T64_INPHASE: rc = run(conv_t64_kernel<T64_INPHASE>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    (void)hipFree(x); (void)hipFree(y); (void)hipFree(dimg); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
 // bench-only: ablations of stem0_fused_kernel<1,1> on a wp x hp frame (variant = ABL bits, see stem_fused.h)
 int rife_hip_bench_stemf(int gpuid, int wp, int hp, int variant, int iters, float* ms_out) {
     int rc;

@@ -59,6 +59,9 @@ struct ConvArgs {
     int nsplit = 1;        // split-K: the K chunks are divided among nsplit workgroups per (tile, n-tile) ...
     float* partial = nullptr;   // ... which write raw accumulators to partial[split][pixel][Cpad] (reduced by k_splitk_reduce)
     int cpad = 0;
+    // "S16" tensors (conv_t64.h): zero-bordered allocation of s16_pitch pixels per row, pixel (y, x) at (y + 1, x + 1), per pixel
+    // and 16-channel chunk one 64-byte record {hi f16 x 16, lo f16 x 16}.  conv_h2s2_kernel<NS, true> writes one, head_h2_kernel<EPI, true> reads one.
+    int s16_pitch = 0;
 };
 
 template <int STRIDE, int MS, int KS = 3> struct ConvGeom {
@@ -797,6 +800,55 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
 #undef H2B_STAMP
 }
 
+
+// ---- S16 record stores (conv_t64.h) -------------------------------------------------------------------------------------
+// A lane of the permuted-row MFMA layout ends up with one whole 64-byte record {hi x 16, lo x 16} of ITS pixel.  Stored as is,
+// every 16-byte store instruction would touch 64 different cache lines (256-byte pixel stride): measured 45 us for the 134 MB
+// of a 4K trunk tensor, store-issue bound.  A 4 x 4 transpose of the 16-byte quarters inside every quad of lanes (two DPP
+// butterfly stages) turns that into: instruction k writes, per quad, the whole record of pixel quad_base + k - together with
+// the lanes 32 above (the neighbouring 16-channel chunk) one full 128-byte line per quad and instruction.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s16_quad_transpose(i32x4 (&X)[4], int lane) {
+    const bool o1 = lane & 1, o2 = lane & 2;
+#pragma unroll
+    for (int k = 0; k < 4; k += 2)
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int a0 = X[k][d], a1 = X[k + 1][d];                                  // selects, not conditional stores (those end up in scratch)
+            const int recv = __builtin_amdgcn_mov_dpp(o1 ? a0 : a1, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+            X[k][d] = o1 ? recv : a0;
+            X[k + 1][d] = o1 ? a1 : recv;
+        }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int a0 = X[k][d], a2 = X[k + 2][d];
+            const int recv = __builtin_amdgcn_mov_dpp(o2 ? a0 : a2, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
+            X[k][d] = o2 ? recv : a0;
+            X[k + 2][d] = o2 ? a2 : recv;
+        }
+}
+// v[16]: the 16 consecutive channels of this lane's pixel (fp32, activation applied).  qbase: address of the record of the quad's
+// first pixel (pixel li & ~3) for this lane's chunk; ok: the quad lies inside the tensor (W % 4 == 0: uniform per quad).
+__device__ __forceinline__ void s16_store_record(const float (&v)[16], unsigned char* qbase, int lane, bool ok) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 hv[2], lv[2];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const _Float16 hh = (_Float16)v[e];
+        hv[e >> 3][e & 7] = hh;
+        lv[e >> 3][e & 7] = (_Float16)(v[e] - (float)hh);
+    }
+    i32x4 X[4] = {__builtin_bit_cast(i32x4, hv[0]), __builtin_bit_cast(i32x4, hv[1]), __builtin_bit_cast(i32x4, lv[0]), __builtin_bit_cast(i32x4, lv[1])};
+    s16_quad_transpose(X, lane);
+    if (ok) {
+        unsigned char* const o = qbase + (lane & 3) * 16;
+#pragma unroll
+        for (int k = 0; k < 4; k++) *reinterpret_cast<i32x4*>(o + k * 256) = X[k];      // 256 = bytes per pixel of a 64-channel S16 tensor
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // conv_h2s2_kernel: 3x3 stride-2 convolution (the second stem conv of every IFBlock, c/2 -> c) on the split-f16 pipe.
 //   256 threads = 4 waves, tile = 4 x 32 outputs <- 9 x 65 input pixels per 16-channel chunk (46.8 KB) + weight slab;
@@ -805,7 +857,9 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
 template <int NS>
 constexpr int convh2s2_lds_bytes() { return 9 * 65 * 80 + 9 * 2 * NS * 32 * 16 + 2 * NS * 32 * 4; }      // + bias and slopes
 
-template <int NS>
+// S16OUT: the weights were packed with the row permutation s16_row_channel() (conv_t64.h), a lane then holds 16 consecutive
+// channels per accumulator and the epilogue writes whole S16 records into the zero-bordered tensor a.out (a.s16_pitch).
+template <int NS, bool S16OUT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h2s2_kernel(ConvArgs a) {
     constexpr int IH = 9, IW = 65, CC = 16, NT = NS * 32, PIXB = 80;
     constexpr int IN_F4 = IH * IW * 4;
@@ -914,6 +968,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int oy = oy0 + wv, ox = ox0 + li;
     const bool pok = oy < a.Ho && ox < a.Wo;
+    if (S16OUT) {
+        static_assert(!S16OUT || NS == 2, "S16 tensors of this path have 64 channels");
+        unsigned char* const qb = reinterpret_cast<unsigned char*>(a.out) + ((size_t)(oy + 1) * a.s16_pitch + ox0 + (li & ~3) + 1) * 256 + half * 64;
+        const bool qok = oy < a.Ho && ox0 + (li & ~3) < a.Wo;
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbs + n * 32 + 16 * half + 4 * q);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(lbs + NT + n * 32 + 16 * half + 4 * q);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float y = acc[n][4 * q + k] + b4[k];
+                    v[4 * q + k] = y < 0.f ? y * s4[k] : y;
+                }
+            }
+            s16_store_record(v, qb + n * 128, lane, qok);
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NS; n++) {
 #pragma unroll

@@ -26,6 +26,7 @@
 #include "elementwise_v2.h"
 #include "stem_fused.h"
 #include "head_h2.h"
+#include "conv_t64.h"
 #include "graph_kernels.h"
 #include "model_hashes.h"
 #include "ncnn_model.h"
@@ -60,6 +61,11 @@ struct ConvLayer {
     uint16_t* d_wh = nullptr;             // fp16 weights packed for conv_h2_kernel (split-f16 trunk path)
     int nchunksh = 0;
     bool skip = false;                    // layer is x + conv(x): identity folded into the GEMM
+    // S16 trunk path (conv_t64.h): static LDS image of the persistent 64 -> 64 trunk kernel / row-permuted fp16 weights of the
+    // stride-2 stem that writes the first S16 tensor
+    bool want_t64 = false, want_s16out = false;
+    unsigned char* d_t64 = nullptr;
+    uint16_t* d_whp = nullptr;
     double flops_per_pixel = 0;           // algorithmic: 2 * MAC per GEMM-M pixel
     std::string cls;                      // profile class
     int tag = 0;                          // distinct kernel symbol for the profiled layer class
@@ -71,7 +77,9 @@ static void free_layer(ConvLayer& L) {
     if (L.d_slope) (void)hipFree(L.d_slope);
     if (L.d_w8) (void)hipFree(L.d_w8);
     if (L.d_wh) (void)hipFree(L.d_wh);
-    L.d_w = L.d_bias = L.d_slope = L.d_w8 = nullptr; L.d_wh = nullptr;
+    if (L.d_t64) (void)hipFree(L.d_t64);
+    if (L.d_whp) (void)hipFree(L.d_whp);
+    L.d_w = L.d_bias = L.d_slope = L.d_w8 = nullptr; L.d_wh = nullptr; L.d_t64 = nullptr; L.d_whp = nullptr;
 }
 
 // Choose the kernel configuration for a layer (see conv_mfma.h for the meaning of MS / NS / CC).
@@ -162,6 +170,46 @@ static std::vector<uint16_t> pack_weights_h2(const ConvLayer& L, const float* w,
                             out[o] = f2h(v);
                         }
     return out;
+}
+
+// pack_weights_h2 with the output rows of every 32-row MFMA block permuted by s16_row_channel(): conv_h2s2_kernel<NS, true>
+static std::vector<uint16_t> pack_weights_h2_perm(const ConvLayer& L, const float* w) {
+    const int NT = L.NS * 32, nch = (L.cin + 15) / 16;
+    std::vector<uint16_t> out((size_t)nch * 9 * 2 * NT * 8, 0);
+    size_t o = 0;
+    for (int ch = 0; ch < nch; ch++)
+        for (int t = 0; t < 9; t++)
+            for (int half = 0; half < 2; half++)
+                for (int n = 0; n < NT; n++)
+                    for (int e = 0; e < 8; e++, o++) {
+                        const int c = ch * 16 + half * 8 + e, oc = (n & ~31) + s16_row_channel(n & 31);
+                        if (oc < L.cout && c < L.cin) out[o] = f2h(w[((size_t)oc * L.cin + c) * 9 + t]);
+                    }
+    return out;
+}
+
+// Static LDS image of conv_t64_kernel (conv_t64.h): fp16 weights [chunk 4][tap 9][k half 2][row 64][8] with the rows of each
+// 32-row block permuted by s16_row_channel(), the two identity slabs of the skip connection, then bias[64] and slope[64] as fp32.
+static std::vector<unsigned char> pack_t64_image(const float* w, const float* bias, float slope) {
+    std::vector<unsigned char> img(T64_IMG, 0);
+    uint16_t* wh = reinterpret_cast<uint16_t*>(img.data());
+    for (int c = 0; c < 4; c++)
+        for (int t = 0; t < 9; t++)
+            for (int kh = 0; kh < 2; kh++)
+                for (int row = 0; row < 64; row++)
+                    for (int e = 0; e < 8; e++) {
+                        const int oc = (row & ~31) + s16_row_channel(row & 31), ic = 16 * c + 8 * kh + e;
+                        wh[((((size_t)c * 9 + t) * 2 + kh) * 64 + row) * 8 + e] = f2h(w[((size_t)oc * 64 + ic) * 9 + t]);
+                    }
+    uint16_t* id = reinterpret_cast<uint16_t*>(img.data() + T64_WB);
+    for (int hc = 0; hc < 2; hc++)               // chunk c = 2 n + hc carries input channels 32 n + 16 hc .. + 15 = the rows of block n whose s16_row_channel is 16 hc + k
+        for (int kh = 0; kh < 2; kh++)
+            for (int i = 0; i < 32; i++)
+                for (int e = 0; e < 8; e++)
+                    id[((hc * 2 + kh) * 32 + i) * 8 + e] = s16_row_channel(i) == 16 * hc + 8 * kh + e ? 0x3c00 : 0;
+    float* bs = reinterpret_cast<float*>(img.data() + T64_WB + T64_IDB);
+    for (int i = 0; i < 64; i++) { bs[i] = bias ? bias[i] : 0.f; bs[64 + i] = slope; }
+    return img;
 }
 
 // host mirror of head_uses() / the pair order of head_h2.h
@@ -256,6 +304,11 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
             HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
             L.nchunksh = L.cin / 16;
+            if (L.want_s16out && L.ntiles == 1 && L.cout % 32 == 0) {
+                std::vector<uint16_t> pp = pack_weights_h2_perm(L, w_orig);
+                HIPCHK(hipMalloc(&L.d_whp, pp.size() * 2));
+                HIPCHK(hipMemcpy(L.d_whp, pp.data(), pp.size() * 2, hipMemcpyHostToDevice));
+            }
         }
     }
     if (!L.deconv && L.stride == 1 && L.epi == EPI_STORE && L.cin % 16 == 0) {
@@ -273,6 +326,11 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
             HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
             L.nchunksh = L.cin / 16;
+            if (L.want_t64 && L.skip && L.cin == 64 && L.cout == 64 && !slope) {
+                std::vector<unsigned char> img = pack_t64_image(w_orig, bias, uniform_slope);
+                HIPCHK(hipMalloc(&L.d_t64, img.size()));
+                HIPCHK(hipMemcpy(L.d_t64, img.data(), img.size(), hipMemcpyHostToDevice));
+            }
         }
     }
     return 0;
@@ -319,8 +377,11 @@ static const bool g_h2b = []() { const char* e = getenv("RIFE_HIP_H2B"); return 
 static const bool g_use_conv8 = []() { const char* e = getenv("RIFE_HIP_CONV8"); return !(e && e[0] == '0'); }();
 
 // x: NHWC input (H x W), y: output; for deconv layers y has 2H x 2W pixels (or the 4H x 4W flow tensor with EPI_DECONV_PS).
-static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorView y, const TensorView* res, hipStream_t st, const FinalArgs* fin = nullptr) {
+// s16_pitch > 0: the stride-2 stem writes / the head reads an S16 tensor (conv_t64.h) of that row pitch instead of NHWC fp32
+static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorView y, const TensorView* res, hipStream_t st, const FinalArgs* fin = nullptr,
+                       int s16_pitch = 0) {
     ConvArgs a;
+    a.s16_pitch = s16_pitch;
     a.in = x.p; a.in_ld = x.ld; a.in_coff = x.coff; a.H = H; a.W = W;
     a.out = y.p; a.out_ld = y.ld; a.out_coff = y.coff;
     a.wpk = L.d_w; a.bias = L.d_bias; a.slope = L.d_slope;
@@ -350,11 +411,17 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
             std::lock_guard<std::mutex> g(smu);
             if (!sdone[dev]) {
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2s2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, ls2));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2s2_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ls2));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2s2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, ls3));
                 sdone[dev] = true;
             }
         }
-        if (L.NS == 1) hipLaunchKernelGGL(conv_h2s2_kernel<1>, dim3(nb), dim3(256), ls1, st, a);
+        if (s16_pitch > 0) {
+            if (L.NS != 2 || !L.d_whp) return fail(RIFE_HIP_EINVAL, "no S16 variant of this stride-2 layer");
+            a.wpk = reinterpret_cast<const float*>(L.d_whp);
+            hipLaunchKernelGGL((conv_h2s2_kernel<2, true>), dim3(nb), dim3(256), ls2, st, a);
+        }
+        else if (L.NS == 1) hipLaunchKernelGGL(conv_h2s2_kernel<1>, dim3(nb), dim3(256), ls1, st, a);
         else if (L.NS == 2) hipLaunchKernelGGL(conv_h2s2_kernel<2>, dim3(nb), dim3(256), ls2, st, a);
         else hipLaunchKernelGGL(conv_h2s2_kernel<3>, dim3(nb), dim3(256), ls3, st, a);
         hipError_t eh = hipGetLastError();
@@ -376,13 +443,18 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_DECONV>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_DECONV_SIG>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_FINAL>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_FINAL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_h2_kernel<EPI_DECONV_PS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, headh2_lds_bytes()));
                 hdone[dev] = true;
             }
         }
         const int nb = a.ntiles_xy * a.nz;
         if (L.epi == EPI_DECONV_PS && (L.cout != 24 || y.ld != 8 || y.coff != 0))
             return fail(RIFE_HIP_EINVAL, "the PixelShuffle head kernel writes the 6-channel flow tensor [4H][4W][8] only");
-        if (fin && L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_FINAL>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, *fin);
+        if (s16_pitch > 0 && L.epi != EPI_DECONV_PS) return fail(RIFE_HIP_EINVAL, "no S16 variant of this head");
+        if (s16_pitch > 0 && fin) hipLaunchKernelGGL((head_h2_kernel<EPI_FINAL, true>), dim3(nb), dim3(512), headh2_lds_bytes(), st, a, *fin);
+        else if (s16_pitch > 0) hipLaunchKernelGGL((head_h2_kernel<EPI_DECONV_PS, true>), dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
+        else if (fin && L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_FINAL>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, *fin);
         else if (L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_PS>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
         else if (L.epi == EPI_DECONV) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
         else hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_SIG>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
@@ -546,6 +618,41 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
     return 0;
 }
 
+// S16 tensor geometry for an H x W pixel grid (conv_t64.h): 8 x 32 tiles, one pixel of zero border on every side
+struct S16Geom {
+    int tiles_x, tiles_y, pitch, rows;
+    S16Geom(int H, int W) : tiles_x((W + 31) / 32), tiles_y((H + 7) / 8), pitch(tiles_x * 32 + 2), rows(tiles_y * 8 + 2) {}
+    size_t bytes(int C) const { return (size_t)rows * pitch * C * 4; }
+};
+
+// one 64 -> 64 residual trunk convolution, S16 in / S16 out, persistent workgroups (one per CU)
+static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st) {
+    if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_t64 image");
+    int dev = 0; (void)hipGetDevice(&dev);
+    static std::mutex mu; static std::map<int, int> ncu;
+    int cus;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = ncu.find(dev);
+        if (it == ncu.end()) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_t64_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, T64_LDS));
+            int n = 0;
+            HIPCHK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+            it = ncu.emplace(dev, std::max(8, n / 8 * 8)).first;
+        }
+        cus = it->second;
+    }
+    const S16Geom G(H, W);
+    T64Args a;
+    a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y;
+    const int nwg = std::min(cus, ((a.ntiles + 1) / 2 + 7) / 8 * 8);
+    a.rounds = (a.ntiles + 2 * nwg - 1) / (2 * nwg);
+    hipLaunchKernelGGL(conv_t64_kernel<3>, dim3(nwg), dim3(1024), T64_LDS, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_t64 launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // profiler (rife_hip_profile_*): HIP events on the launch stream around every kernel
 // ------------------------------------------------------------------------------------------------
@@ -608,6 +715,7 @@ struct Ctx {
     uint32_t *img0 = nullptr, *img1 = nullptr;                       // padded RGBX u8
     float *X = nullptr, *S1 = nullptr, *T0 = nullptr, *T1 = nullptr; // block input, stem-1 output, trunk ping/pong
     float *T2 = nullptr;                                             // rife-v4 (4.0): stem-1 output kept for the block's residual add
+    unsigned char *P0 = nullptr, *P1 = nullptr;                      // block 3 trunk ping / pong as S16 tensors (conv_t64.h), zero borders
     float* flow[4] = {nullptr, nullptr, nullptr, nullptr};           // [hp/s][wp/s][8]
     float4* F = nullptr; float* M = nullptr;                         // full-resolution flow (4ch) and mask logit
     float4* outf = nullptr;                                          // TTA only: out0 as float, padded
@@ -693,6 +801,9 @@ struct rife_hip {
     // rife-v4 (4.0) variant of the schedule: PReLU, plain trunk + one residual add, 5-channel deconv head at half the block
     // resolution (flow{b} is [hp/2s][wp/2s][8] instead of [hp/s][wp/s][8])
     bool v40 = false;
+    // finest-block trunk on S16 tensors + the persistent conv_t64 kernel (RIFE_HIP_T64=0 at create time keeps conv_h2b: A/B and
+    // the bit-equality test of the two trunk implementations)
+    bool t64 = true;
     int flow_div(int b) const { return v40 ? 2 * blk[b].scale : blk[b].scale; }
     // rife-v2.x schedule (IFNet + ContextNet + FusionNet)
     struct V2Block { ConvLayer stem0, stem1, conv[6], head; int c = 0, scale = 1; } fblk[4];
@@ -740,7 +851,7 @@ static const uint64_t V46_HASH_OUT0 = RIFE_V46_HASH_OUT0;
 // (Re)allocate a workspace for frames of w x h (padded wp x hp).  `scratch` != null: borrow the big per-layer
 // scratch tensors (block input, stem output, trunk ping/pong) from another context of the same pixel count —
 // the TTA passes run one after another on one stream, only flows / F / M / images must persist per pass.
-static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scratch = nullptr, bool own_images = true, bool want_outf = false) {
+static int ensure_ctx_dims_impl(Ctx& c, int w, int h, int wp, int hp, const Ctx* scratch, bool own_images, bool want_outf) {
     if (!c.v2 && c.wp == wp && c.hp == hp && c.w == w && c.h == h && (!want_outf || c.outf)) return 0;
     c.v2 = false;
     if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
@@ -766,6 +877,14 @@ static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scra
         if ((rc = dalloc(c, c.T1, P / 16 * 64))) return rc;
         if ((rc = dalloc(c, c.T2, P / 16 * 64))) return rc;
     }
+    {   // S16 trunk tensors of the finest block; never borrowed: the zero border belongs to THIS geometry
+        const S16Geom G(hp / 4, wp / 4);
+        const size_t nb = G.bytes(64);
+        if ((rc = dalloc(c, c.P0, nb))) return rc;
+        if ((rc = dalloc(c, c.P1, nb))) return rc;
+        if (c.stream) { HIPCHK(hipMemsetAsync(c.P0, 0, nb, c.stream)); HIPCHK(hipMemsetAsync(c.P1, 0, nb, c.stream)); }
+        else { HIPCHK(hipMemset(c.P0, 0, nb)); HIPCHK(hipMemset(c.P1, 0, nb)); }
+    }
     static const int sc[4] = {8, 4, 2, 1};
     for (int b = 0; b < 4; b++) {
         const size_t n = P / (sc[b] * sc[b]) * 8;
@@ -781,6 +900,20 @@ static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scra
     if (!scratch && (rc = dalloc(c, c.d_ts, 4))) return rc;
     if (want_outf && (rc = dalloc(c, c.outf, P))) return rc;
     return 0;
+}
+
+// A workspace whose (re)allocation failed half way is emptied, so that the next call reports the error again instead of taking the
+// "already sized" early return and running on freed memory.
+static void reset_ctx(Ctx& c) {
+    if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
+    for (void* p : c.allocs) (void)hipFree(p);
+    c.allocs.clear();
+    c.w = c.h = c.wp = c.hp = 0; c.v2 = false; c.outf = nullptr; c.d_ts = nullptr; c.g_warm = false; c.P0 = c.P1 = nullptr;
+}
+static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scratch = nullptr, bool own_images = true, bool want_outf = false) {
+    const int rc = ensure_ctx_dims_impl(c, w, h, wp, hp, scratch, own_images, want_outf);
+    if (rc) reset_ctx(c);
+    return rc;
 }
 
 static int ensure_ctx(Ctx& c, int w, int h) {
@@ -847,13 +980,31 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         Timed t(E.prof, B.stem0.cls, B.stem0.flops_per_pixel * (Hb / 2) * (Wb / 2), st);
         if ((rc = launch_conv(B.stem0, {c.X, xin_ld, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, nullptr, st))) return rc;
     }
+    const int Ht = Hb / 4, Wt = Wb / 4;
+    bool s16 = E.t64 && !E.v40 && b == 3 && B.c == 64 && g_trunk_h2 && g_head_h2 && g_s2_h2 && c.P0 && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS;
+    for (int i = 0; i < 8 && s16; i++) s16 = B.res[i].d_t64 != nullptr;
+    if (s16) {
+        // stem-1 writes the first S16 tensor, eight persistent trunk launches ping-pong between the two, the head reads the last one
+        const S16Geom G(Ht, Wt);
+        {
+            Timed t(E.prof, B.stem1.cls, B.stem1.flops_per_pixel * Ht * Wt, st);
+            if ((rc = launch_conv(B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {reinterpret_cast<float*>(c.P0), B.c, 0}, nullptr, st, nullptr, G.pitch))) return rc;
+        }
+        unsigned char *pc = c.P0, *pn = c.P1;
+        for (int i = 0; i < 8; i++) {
+            Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
+            if ((rc = launch_t64(B.res[i], pc, pn, Ht, Wt, st))) return rc;
+            std::swap(pc, pn);
+        }
+        Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);
+        return launch_conv(B.head, {reinterpret_cast<float*>(pc), B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st, fin, G.pitch);
+    }
     float* const stem_out = E.v40 ? c.T2 : c.T0;
     {
         Timed t(E.prof, B.stem1.cls, B.stem1.flops_per_pixel * (Hb / 4) * (Wb / 4), st);
         if ((rc = launch_conv(B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {stem_out, B.c, 0}, nullptr, st))) return rc;
     }
     float* cur = stem_out; float* nxt = E.v40 ? c.T0 : c.T1;
-    const int Ht = Hb / 4, Wt = Wb / 4;
     for (int i = 0; i < 8; i++) {
         Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
         if ((rc = launch_conv(B.res[i], {cur, B.c, 0}, Ht, Wt, {nxt, B.c, 0}, nullptr, st))) return rc;   // v4.6: skip folded into the weights
@@ -1089,7 +1240,7 @@ static int ensure_ctx_v2(Ctx& c, int w, int h, bool uhd, int nori = 1, int ntemp
     c.v2 = true; c.w = w; c.h = h; c.wp = wp; c.hp = hp;
     const size_t P = (size_t)wp * hp;
     int rc;
-#define A_(ptr, n) if ((rc = dalloc(c, ptr, (size_t)(n)))) return rc;
+#define A_(ptr, n) if ((rc = dalloc(c, ptr, (size_t)(n)))) { reset_ctx(c); return rc; }
     A_(c.d_in0, (size_t)w * h * 3) A_(c.d_in1, (size_t)w * h * 3) A_(c.d_out, (size_t)w * h * 3)
     A_(c.img0, P) A_(c.img1, P)
     if (v3) { A_(c.X, P * 16) A_(c.S1, P / 4 * 80) A_(c.T0, P / 16 * 160) A_(c.T1, P / 16 * 160) A_(c.T2, P / 16 * 160) }   // rife-v3.x block 2: 80 / 160 ch at 1/2, 1/4 res
@@ -1377,14 +1528,14 @@ static int ensure_ctx_v1(Ctx& c, int w, int h, int nori, int ntemp) {
     c.h0 = c.h1 = c.acc_s = nullptr; c.T2 = nullptr;
     const size_t P = (size_t)wp * hp;
     int rc;
-    if ((rc = dalloc(c, c.d_in0, (size_t)w * h * 3))) return rc;
-    if ((rc = dalloc(c, c.d_in1, (size_t)w * h * 3))) return rc;
-    if ((rc = dalloc(c, c.d_out, (size_t)w * h * 3))) return rc;
-    if ((rc = dalloc(c, c.img0, P))) return rc;
-    if ((rc = dalloc(c, c.img1, P))) return rc;
+    if ((rc = dalloc(c, c.d_in0, (size_t)w * h * 3))) { reset_ctx(c); return rc; }
+    if ((rc = dalloc(c, c.d_in1, (size_t)w * h * 3))) { reset_ctx(c); return rc; }
+    if ((rc = dalloc(c, c.d_out, (size_t)w * h * 3))) { reset_ctx(c); return rc; }
+    if ((rc = dalloc(c, c.img0, P))) { reset_ctx(c); return rc; }
+    if ((rc = dalloc(c, c.img1, P))) { reset_ctx(c); return rc; }
     c.timg0[0] = c.img0; c.timg1[0] = c.img1;
-    for (int t = 1; t < nori; t++) { if ((rc = dalloc(c, c.timg0[t], P))) return rc; if ((rc = dalloc(c, c.timg1[t], P))) return rc; }
-    if (ens) for (int d = 0; d < ntemp; d++) for (int t = 0; t < nori; t++) if ((rc = dalloc(c, c.toutf[d][t], P))) return rc;
+    for (int t = 1; t < nori; t++) { if ((rc = dalloc(c, c.timg0[t], P))) { reset_ctx(c); return rc; } if ((rc = dalloc(c, c.timg1[t], P))) { reset_ctx(c); return rc; } }
+    if (ens) for (int d = 0; d < ntemp; d++) for (int t = 0; t < nori; t++) if ((rc = dalloc(c, c.toutf[d][t], P))) { reset_ctx(c); return rc; }
     return 0;
 }
 
@@ -1663,6 +1814,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     E->num_threads = num_threads; E->v2 = rife_v2; E->v4 = rife_v4;
     E->frame_pool = std::make_shared<FramePool>();
     E->frame_pool->gpuid = gpuid;
+    { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
     return E;
 }
 
@@ -1749,6 +1901,8 @@ static int rife_hip_load_impl(rife_hip_t* E, const char* modeldir) {
             L.cin = cin; L.cout = cout; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi; L.cls = cls;
             L.tag = std::strcmp(cls, "trunk_b3") == 0 ? 3 : 0;
             L.skip = fold_skip;
+            L.want_t64 = fold_skip && cin == 64 && cout == 64;
+            L.want_s16out = !deconv && stride == 2 && cout == 64 && b == 3;
             return upload_layer(L, nl->weight.data(), nl->bias.data(), nullptr, slope);
         };
         std::snprintf(name, sizeof name, "stem0_b%d", b);

@@ -43,7 +43,8 @@ constexpr int headh2_lds_bytes() { return 2 * 10 * 34 * 80 + 16 * 2 * 32 * 16; }
 
 // EPI: EPI_DECONV_PS (v4 heads: + PixelShuffle scatter, 24 channels), EPI_DECONV (+ per-channel slope, NHWC store at
 // (2y+py, 2x+px)), EPI_DECONV_SIG (sigmoid).  Output channels are tiled by 32 over the grid (a.nz N-tiles per pixel tile).
-template <int EPI>
+// S16IN: the input is an S16 tensor (conv_t64.h; a.s16_pitch pixels per row, zero border): staging is a plain 16-byte copy.
+template <int EPI, bool S16IN = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void head_h2_kernel(ConvArgs a, FinalArgs fa) {
     constexpr int IH = 10, IW = 34, CC = 16, NT = 32;
     constexpr int PIXB = 80;
@@ -77,7 +78,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int py = p / IW, px = p - py * IW;
         const int gy = iy0 + py, gx = ix0 + px;
         const bool ok = idx < IN_F4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        goff[k] = ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff;
+        if (S16IN) goff[k] = idx < IN_F4 ? ((gy + 1) * a.s16_pitch + gx + 1) * a.in_ld + q * 4 : 0;     // the border and the ragged tile edge are stored zeros
+        else goff[k] = ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff;
         inside |= ok ? (1u << k) : 0u;
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk) + (size_t)ntile * a.nchunks * W_16;
@@ -91,6 +93,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     _Pragma("unroll") for (int k = 0; k < NIN; k++) {                                                       \
         const int idx = tid + k * 512;                                                                      \
         const int p = idx >> 2, q = idx & 3;                                                                \
+        if (S16IN) {                                                                                        \
+            if (IN_F4 % 512 == 0 || idx < IN_F4) *reinterpret_cast<f32x4*>((BUFP) + p * PIXB + q * 16) = rin[k]; \
+            continue;                                                                                       \
+        }                                                                                                   \
         f16x4 hi4, lo4;                                                                                     \
         _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                     \
             const float v = ((inside >> k) & 1u) ? rin[k][e] : 0.f;                                         \

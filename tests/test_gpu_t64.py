@@ -1,0 +1,68 @@
+"""The persistent S16 trunk kernel of the finest IFBlock (csrc/conv_t64.h) against the per-tile kernel it replaces.
+
+Both compute the same products in the same order (reference layers: models/rife-v4.6/flownet.param:166-201), so the two
+engines must agree BIT FOR BIT on every output byte wherever the per-tile path does not split K (frames from ~1000x520 up), and
+within summation-order noise below that, at aligned, ragged and tiny frame sizes and through the TTA schedule (whose passes
+borrow scratch tensors but own their S16 tensors).  Parity against the CPU oracle
+is covered by tests/test_gpu_v4.py, which runs on the new path (the default)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from tools import gen_frames
+
+pytestmark = pytest.mark.gpu
+amd = importlib.import_module("rife-ncnn-vulkan_amd")
+
+
+def _engine(modeldir, t64, **kw):
+    old = os.environ.get("RIFE_HIP_T64")
+    os.environ["RIFE_HIP_T64"] = "1" if t64 else "0"      # read by rife_hip_create
+    try:
+        g = amd.RIFE(0, rife_v4=True, **kw)
+    finally:
+        if old is None:
+            del os.environ["RIFE_HIP_T64"]
+        else:
+            os.environ["RIFE_HIP_T64"] = old
+    g.load(modeldir)
+    return g
+
+
+@pytest.fixture(scope="module")
+def pair(modeldirs):
+    d = modeldirs["rife-v4.6"]
+    return _engine(d, True), _engine(d, False)
+
+
+@pytest.mark.parametrize("w,h,t,seed", [(640, 360, 0.5, 1), (256, 192, 0.125, 2), (100, 60, 0.7, 3), (33, 47, 0.9, 4), (1, 1, 0.5, 5),
+                                        (1920, 1080, 0.5, 6), (1000, 520, 0.3, 7), (3840, 2160, 0.5, 8)])
+def test_t64_output_is_bit_identical_to_the_per_tile_trunk(pair, w, h, t, seed):
+    new, old = pair
+    a, b = gen_frames.smooth_pair(w, h, seed) if w * h < 4000000 else [np.kron(f, np.ones((4, 4, 1), np.uint8)) for f in gen_frames.smooth_pair(w // 4, h // 4, seed)]
+    def same(x, y):
+        if w * h >= 1000 * 520:
+            return np.array_equal(x, y)
+        # small frames: the per-tile path splits K over several workgroups for its tiny grids (another summation order)
+        d = np.abs(x.astype(np.int32) - y.astype(np.int32))
+        return d.max() <= 1 and (d > 0).mean() < 1e-3
+    assert same(new.process(a, b, t), old.process(a, b, t))
+    # a second call on the same workspace: the zero borders of the S16 tensors must have survived the first
+    assert same(new.process(b, a, 1.0 - t), old.process(b, a, 1.0 - t))
+
+
+@pytest.mark.parametrize("w,h", [(160, 96), (100, 60)])
+def test_t64_block3_flow_matches(pair, w, h):
+    new, old = pair
+    a, b = gen_frames.noise_pair(w, h, 9)
+    assert np.abs(new.v4_extract_flow(a, b, 0.5, 3) - old.v4_extract_flow(a, b, 0.5, 3)).max() < 1e-4      # split-K in the per-tile path at this size
+
+
+def test_t64_tta_passes_match(modeldirs):
+    d = modeldirs["rife-v4.6"]
+    new, old = _engine(d, True, tta_mode=True, tta_temporal_mode=True), _engine(d, False, tta_mode=True, tta_temporal_mode=True)
+    a, b = gen_frames.smooth_pair(100, 60, 11)
+    d = np.abs(new.process(a, b, 0.4).astype(np.int32) - old.process(a, b, 0.4).astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3

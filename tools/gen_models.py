@@ -612,6 +612,28 @@ def ensure(outdir=None, family="rife-v4.6", seed=0x51FE):
     return outdir
 
 
+# reference model directory -> the generator family with the same three graphs (identical .param files; tests/test_models.py
+# proves the structural equivalence against /root/reference whenever it exists)
+GRAPH_FAMILY = {"rife": "rife", "rife-HD": "rife-HD", "rife-UHD": "rife-HD", "rife-anime": "rife-HD", "rife-v2": "rife-v2.3",
+                "rife-v2.3": "rife-v2.3", "rife-v2.4": "rife-v2.3", "rife-v3.0": "rife-v3.1", "rife-v3.1": "rife-v3.1"}
+REF_FIXTURES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref")
+
+
+def ensure_realctx(ref_family, seed=0x51FE):
+    """Model directory `<ref_family>-realctx`: the graphs of `ref_family` with the reference's REAL trained contextnet.bin
+    (tests/golden/ref/models/<ref_family>/contextnet.bin, copied from the reference by tools/make_ref_fixtures.py) between a
+    seeded synthetic flownet and fusionnet (the trained ones are absent from the reference snapshot)."""
+    fam = GRAPH_FAMILY[ref_family]
+    real = os.path.join(REF_FIXTURES, "models", ref_family, "contextnet.bin")
+    if not os.path.exists(real):
+        raise FileNotFoundError(real)
+    outdir = default_dir(ref_family + "-realctx")
+    need = [os.path.join(outdir, n + e) for n in FAMILIES[fam] for e in (".param", ".bin")]
+    if not all(os.path.exists(p) for p in need) or os.path.getsize(os.path.join(outdir, "contextnet.bin")) != os.path.getsize(real):
+        generate(outdir, fam, seed, real_contextnet=real)
+    return outdir
+
+
 if __name__ == "__main__":
     out = sys.argv[1]
     fam = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else "rife-v4.6"
