@@ -289,31 +289,33 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
     unsigned char *x = nullptr, *y = nullptr, *dimg = nullptr;
     HIPCHK(hipMalloc(&x, nb)); HIPCHK(hipMalloc(&y, nb)); HIPCHK(hipMalloc(&dimg, img.size()));
     HIPCHK(hipMemcpy(dimg, img.data(), img.size(), hipMemcpyHostToDevice));
-    {   // random {hi, lo} records in the interior, zero border
+    {   // random {hi, lo} entries in the interior of every plane, zero border
         std::vector<_Float16> hx(nb / 2, (_Float16)0.f);
+        const size_t pl = G.plane() / 2;                       // f16 elements per plane
         for (int yy = 0; yy < h; yy++)
-            for (int xx = 0; xx < w; xx++) {
-                _Float16* rec = hx.data() + ((size_t)(yy + 1) * G.pitch + xx + 1) * 128;
+            for (int xx = 0; xx < w; xx++)
                 for (int c = 0; c < 4; c++)
-                    for (int e = 0; e < 16; e++) { const float v = rnd(); const _Float16 hh = (_Float16)v; rec[c * 32 + e] = hh; rec[c * 32 + 16 + e] = (_Float16)(v - (float)hh); }
-            }
+                    for (int e = 0; e < 16; e++) {
+                        const float v = rnd(); const _Float16 hh = (_Float16)v;
+                        const size_t px = ((size_t)(yy + 1) * G.pitch + xx + 1) * 16 + e;
+                        hx[(2 * c) * pl + px] = hh; hx[(2 * c + 1) * pl + px] = (_Float16)(v - (float)hh);
+                    }
         HIPCHK(hipMemcpy(x, hx.data(), nb, hipMemcpyHostToDevice));
         HIPCHK(hipMemset(y, 0, nb));
     }
     int cus = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpuid));
     T64Args a;
-    a.in = x; a.out = y; a.img = dimg; a.H = h; a.W = w; a.pitch = G.pitch; a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y;
-    const int nwg = std::min(cus / 8 * 8, ((a.ntiles + 1) / 2 + 7) / 8 * 8);
-    a.rounds = (a.ntiles + 2 * nwg - 1) / (2 * nwg);
+    a.in = x; a.out = y; a.img = dimg; a.H = h; a.W = w; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y;
+    const int nwg = std::min(2 * (cus / 8 * 8), (a.ntiles + 7) / 8 * 8);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     auto run = [&](auto kfn) -> int {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, T64_LDS));
-        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(1024), T64_LDS, 0, a);
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), T64_LDS, 0, a);
         HIPCHK(hipEventRecord(e0, 0));
         for (int i = 0; i < iters; i++) {
             a.in = (i & 1) ? y : x; a.out = (i & 1) ? x : y;
-            hipLaunchKernelGGL(kfn, dim3(nwg), dim3(1024), T64_LDS, 0, a);
+            hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), T64_LDS, 0, a);
         }
         HIPCHK(hipEventRecord(e1, 0));
         HIPCHK(hipEventSynchronize(e1));
@@ -322,7 +324,7 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
         return 0;
     };
     if (variant == T64_STAMPS) {
-        const size_t nst = (size_t)nwg * 16 * 32 * 4;
+        const size_t nst = (size_t)nwg * 8 * 32 * 4;
         HIPCHK(hipMalloc(&a.stamps, nst * 8));
         HIPCHK(hipMemset(a.stamps, 0, nst * 8));
         rc = run(conv_t64_kernel<T64_STAMPS>);
@@ -339,7 +341,6 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
         case T64_NODMA | T64_NOSTORE: rc = run(conv_t64_kernel<T64_NODMA | T64_NOSTORE>); break;
         case T64_NOMATH | T64_NOSTORE: rc = run(conv_t64_kernel<T64_NOMATH | T64_NOSTORE>); break;
         case T64_NOMATH | T64_NODMA: rc = run(conv_t64_kernel<T64_NOMATH | T64_NODMA>); break;
-        case T64_INPHASE: rc = run(conv_t64_kernel<T64_INPHASE>); break;
         default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
     }
     (void)hipFree(x); (void)hipFree(y); (void)hipFree(dimg); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -59,9 +59,11 @@ struct ConvArgs {
     int nsplit = 1;        // split-K: the K chunks are divided among nsplit workgroups per (tile, n-tile) ...
     float* partial = nullptr;   // ... which write raw accumulators to partial[split][pixel][Cpad] (reduced by k_splitk_reduce)
     int cpad = 0;
-    // "S16" tensors (conv_t64.h): zero-bordered allocation of s16_pitch pixels per row, pixel (y, x) at (y + 1, x + 1), per pixel
-    // and 16-channel chunk one 64-byte record {hi f16 x 16, lo f16 x 16}.  conv_h2s2_kernel<NS, true> writes one, head_h2_kernel<EPI, true> reads one.
+    // "S16" tensors (conv_t64.h): planes [16-channel chunk][hi | lo] of 32 bytes per pixel, each a zero-bordered image of
+    // s16_pitch pixels per row (pixel (y, x) at (y + 1, x + 1)), s16_plane bytes per plane.
+    // conv_h2s2_kernel<NS, true> writes one, head_h2_kernel<EPI, true> reads one.
     int s16_pitch = 0;
+    unsigned s16_plane = 0;
 };
 
 template <int STRIDE, int MS, int KS = 3> struct ConvGeom {
@@ -801,51 +803,25 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
 }
 
 
-// ---- S16 record stores (conv_t64.h) -------------------------------------------------------------------------------------
-// A lane of the permuted-row MFMA layout ends up with one whole 64-byte record {hi x 16, lo x 16} of ITS pixel.  Stored as is,
-// every 16-byte store instruction would touch 64 different cache lines (256-byte pixel stride): measured 45 us for the 134 MB
-// of a 4K trunk tensor, store-issue bound.  A 4 x 4 transpose of the 16-byte quarters inside every quad of lanes (two DPP
-// butterfly stages) turns that into: instruction k writes, per quad, the whole record of pixel quad_base + k - together with
-// the lanes 32 above (the neighbouring 16-channel chunk) one full 128-byte line per quad and instruction.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void s16_quad_transpose(i32x4 (&X)[4], int lane) {
-    const bool o1 = lane & 1, o2 = lane & 2;
-#pragma unroll
-    for (int k = 0; k < 4; k += 2)
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const int a0 = X[k][d], a1 = X[k + 1][d];                                  // selects, not conditional stores (those end up in scratch)
-            const int recv = __builtin_amdgcn_mov_dpp(o1 ? a0 : a1, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
-            X[k][d] = o1 ? recv : a0;
-            X[k + 1][d] = o1 ? a1 : recv;
-        }
-#pragma unroll
-    for (int k = 0; k < 2; k++)
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const int a0 = X[k][d], a2 = X[k + 2][d];
-            const int recv = __builtin_amdgcn_mov_dpp(o2 ? a0 : a2, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
-            X[k][d] = o2 ? recv : a0;
-            X[k + 2][d] = o2 ? a2 : recv;
-        }
-}
-// v[16]: the 16 consecutive channels of this lane's pixel (fp32, activation applied).  qbase: address of the record of the quad's
-// first pixel (pixel li & ~3) for this lane's chunk; ok: the quad lies inside the tensor (W % 4 == 0: uniform per quad).
-__device__ __forceinline__ void s16_store_record(const float (&v)[16], unsigned char* qbase, int lane, bool ok) {
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    h8 hv[2], lv[2];
+// ---- S16 tensor stores (conv_t64.h) ---------------------------------------------------------------------------------------
+// v[16]: the 16 consecutive channels (one chunk) of this lane's pixel, fp32, activation applied.  hi_entry: address of the
+// pixel's 32-byte entry in the chunk's hi plane; the lo plane follows `plane` bytes later.  Consecutive lanes hold consecutive
+// pixels, so a store instruction covers 32 x 16 bytes at a 32-byte stride (the other half of every line follows in the next one).
+// (History: with all chunks of a pixel interleaved as 64-byte records the stores ran at a 256-byte lane stride - 45 us for the
+// 134 MB of a 4K trunk tensor, store-issue bound; a 4 x 4 DPP transpose inside lane quads brought that to 21 us, and the planar
+// layout needs neither.)
+__device__ __forceinline__ void s16_store_chunk(const float (&v)[16], unsigned char* hi_entry, unsigned plane, bool ok) {
+    f16x8 hv[2], lv[2];
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         const _Float16 hh = (_Float16)v[e];
         hv[e >> 3][e & 7] = hh;
         lv[e >> 3][e & 7] = (_Float16)(v[e] - (float)hh);
     }
-    i32x4 X[4] = {__builtin_bit_cast(i32x4, hv[0]), __builtin_bit_cast(i32x4, hv[1]), __builtin_bit_cast(i32x4, lv[0]), __builtin_bit_cast(i32x4, lv[1])};
-    s16_quad_transpose(X, lane);
     if (ok) {
-        unsigned char* const o = qbase + (lane & 3) * 16;
-#pragma unroll
-        for (int k = 0; k < 4; k++) *reinterpret_cast<i32x4*>(o + k * 256) = X[k];      // 256 = bytes per pixel of a 64-channel S16 tensor
+        f16x8* const dh = reinterpret_cast<f16x8*>(hi_entry);
+        f16x8* const dl = reinterpret_cast<f16x8*>(hi_entry + plane);
+        dh[0] = hv[0]; dh[1] = hv[1]; dl[0] = lv[0]; dl[1] = lv[1];
     }
 }
 
@@ -970,8 +946,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool pok = oy < a.Ho && ox < a.Wo;
     if (S16OUT) {
         static_assert(!S16OUT || NS == 2, "S16 tensors of this path have 64 channels");
-        unsigned char* const qb = reinterpret_cast<unsigned char*>(a.out) + ((size_t)(oy + 1) * a.s16_pitch + ox0 + (li & ~3) + 1) * 256 + half * 64;
-        const bool qok = oy < a.Ho && ox0 + (li & ~3) < a.Wo;
+        unsigned char* const o = reinterpret_cast<unsigned char*>(a.out) + ((size_t)(2 * half) * a.s16_plane + ((size_t)(oy + 1) * a.s16_pitch + ox + 1) * 32);
 #pragma unroll
         for (int n = 0; n < NS; n++) {
             float v[16];
@@ -985,7 +960,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     v[4 * q + k] = y < 0.f ? y * s4[k] : y;
                 }
             }
-            s16_store_record(v, qb + n * 128, lane, qok);
+            s16_store_chunk(v, o + (size_t)(4 * n) * a.s16_plane, a.s16_plane, pok);
         }
         return;
     }

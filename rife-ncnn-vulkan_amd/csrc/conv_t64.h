@@ -1,24 +1,32 @@
 // conv_t64_kernel: the 64 -> 64 channel residual trunk convolution of the finest IFBlock
 // (reference models/rife-v4.6/flownet.param:169-197: Split, Convolution 3x3 pad 1, BinaryOp add, ReLU slope 0.2; 8 per pair,
-// 44 % of the pair's MACs) as ONE persistent workgroup per CU on the split-f16 matrix path of conv_h2b_kernel.
+// 44 % of the pair's MACs) as persistent workgroups, two per CU, on the split-f16 matrix path of conv_h2b_kernel.
 //
 // What changed against conv_h2b_kernel (whose phase trace showed ~10 of the 21 us of every workgroup in latency-bound prologue /
-// epilogue, two workgroups per CU, matrix pipe 42 % busy):
-//   * "S16" activations: the trunk tensor is stored pre-split, per pixel and 16-channel chunk one 64-byte record
-//     {hi = f16(x) x 16, lo = f16(x - hi) x 16} (the same 4 bytes per element as fp32, and exactly the values the old kernel
-//     computed at LDS-staging time), in a zero-bordered allocation: (rows + 2) x pitch pixels, pixel (y, x) at (y + 1, x + 1).
-//     The halo of a tile is then plain memory: no bounds tests, no conversion, and global_load_lds_dwordx4 can move it.
-//   * the weights of all four K chunks (9 taps x 64 x 64 f16 = 72 KB), the two identity slabs of the skip connection, bias and
-//     slopes are loaded into LDS once per workgroup and stay there; nothing but the halo tiles moves in the steady state.
-//   * 16 waves = two groups of 8, each walking its own sequence of 8-row x 32-column tiles; group 1 runs two K chunks behind
-//     group 0, so one group's epilogue (VALU + stores) and tile switch sit under the other group's matrix work.
-//   * every step (one K chunk of one tile: 38 MFMAs per wave) starts by sending the NEXT step's halo chunk on its way with
-//     LDS-DMA (22 x 1 KiB per group) and ends with vmcnt(0) + one s_barrier; the load has the whole step to land.
+// epilogue, matrix pipe 42 % busy):
+//   * "S16" activations: the trunk tensor is stored pre-split, hi = f16(x) and lo = f16(x - hi) (the same 4 bytes per element as
+//     fp32, and exactly the values the old kernel computed at LDS-staging time), as eight planes [16-channel chunk][hi | lo] of
+//     32 bytes per pixel, each plane a zero-bordered image: rows x pitch pixels, pixel (y, x) at (y + 1, x + 1).  The halo of a
+//     tile is then plain memory (no bounds tests, no conversion), one row of one chunk is 34 x 32 contiguous bytes, and
+//     global_load_lds_dwordx4 moves it 1 KiB at a time touching 8-9 cache lines (per-pixel 64-byte records of all chunks
+//     interleaved touched 32: the loads were address-processing bound).
+//   * persistent: 2 x #CU workgroups of 8 waves walk their own sequences of 8-row x 32-column tiles.  Every step (one 16-channel
+//     K chunk of one tile: 38 MFMAs per wave) starts by sending the NEXT step's halo chunk and weight chunk on their way with
+//     LDS-DMA (22 + 18 pieces of 1 KiB, no registers, no VALU) and ends with vmcnt(0) + one s_barrier: the loads have the whole
+//     step to land, a tile switch costs nothing, and the epilogue (registers -> global, no LDS, no barrier) of tile i runs at the
+//     start of tile i + 1 while the co-resident workgroup has the matrix pipe.
 //   * output channels are permuted inside each 32-row MFMA block (a property of the weight packing only) so that a lane ends
-//     up with 16 CONSECUTIVE channels of one pixel = one whole S16 record: the epilogue needs no LDS transpose and no barrier.
+//     up with 16 CONSECUTIVE channels of one pixel = the pixel's 32 hi and 32 lo bytes of one chunk: consecutive lanes store
+//     consecutive 32-byte entries (s16_store_chunk, conv_mfma.h), no LDS transpose, no barrier.
+//   * the identity tap of the skip connection needs no LDS: its A fragment (a permutation matrix) is built in registers.
+// History (MI355X, 544 x 960 tensor = 3840 x 2160 frame, per launch): conv_h2b 91-95 us; one workgroup per CU with two
+// phase-shifted 8-wave groups behind ONE s_barrier and resident weights 100 us (record stores at 256-byte lane stride: store-issue
+// bound, 45 us for the stores alone), 82-88 us with quad-transposed stores - the workgroup-wide barrier made each group wait
+// for the other group's epilogue (all-wave clock stamps: tools/t64_bench.py); this version: see DESIGN.md.
 // LDS image of a halo chunk: hi plane [340 px][32 B] then lo plane [340 px][32 B]; the two 16-byte halves of a 32-byte entry are
 // swapped when bit 3 of the pixel index is set, which makes the ds_read_b128 fragment reads of 16 consecutive pixels hit 64
-// distinct banks.  The DMA writes LDS lane-linear, so the swap is applied to each lane's SOURCE address (cdna guide, rule 21).
+// distinct banks (SQ_LDS_BANK_CONFLICT = 0).  The DMA writes LDS lane-linear, so the swap is applied to each lane's SOURCE
+// address (cdna guide, rule 21).
 // Arithmetic (products, accumulation order, epilogue) is that of conv_h2b_kernel<2, 10>: results are bit-identical.
 #pragma once
 #include "conv_mfma.h"
@@ -27,29 +35,30 @@ namespace rife {
 
 constexpr int T64_IH = 10, T64_IW = 34, T64_NPX = T64_IH * T64_IW;      // halo tile of an 8 x 32 output tile
 constexpr int T64_PLANE = T64_NPX * 32;                                  // 10,880 B: hi (or lo) halves of one 16-channel chunk
-constexpr int T64_INB = 2 * T64_PLANE;                                   // 21,760 B per chunk buffer
-constexpr int T64_WB = 4 * 9 * 2048;                                     // 73,728 B: [chunk][tap][k half][64 rows][8 f16]
-constexpr int T64_IDB = 2 * 1024;                                        // identity slabs [chunk parity][k half][32 rows][8 f16]
+constexpr int T64_INB = 2 * T64_PLANE;                                   // 21,760 B per halo chunk buffer
+constexpr int T64_WCH = 9 * 2048;                                        // 18,432 B: weights of one K chunk [tap][k half][64 rows][8 f16]
+constexpr int T64_WB = 4 * T64_WCH;                                      // 73,728 B
 constexpr int T64_BSB = 2 * 64 * 4;                                      // bias[64], slope[64]
-constexpr int T64_IMG = T64_WB + T64_IDB + T64_BSB;                      // 76,288 B: static LDS image, built on the host
-constexpr int T64_LDS = T64_IMG + 4 * T64_INB;                           // 163,328 B (limit 163,840)
-static_assert(T64_LDS <= 160 * 1024, "LDS budget");
+constexpr int T64_IMG = T64_WB + T64_BSB;                                // 74,240 B: weight image in global memory, built on the host
+constexpr int T64_LDS_IN = 0, T64_LDS_W = 2 * T64_INB, T64_LDS_BS = T64_LDS_W + 2 * T64_WCH;
+constexpr int T64_LDS = T64_LDS_BS + T64_BSB;                            // 80,896 B: two workgroups per CU (limit 163,840)
+static_assert(2 * T64_LDS <= 160 * 1024, "LDS budget");
 
 // row i of a 32-row MFMA block <-> output channel (within the block): a lane's 16 accumulator registers are 16 consecutive channels
 __host__ __device__ constexpr int s16_row_channel(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
 
 struct T64Args {
-    const unsigned char* in;     // S16 tensor, allocation start (= pixel (-1, -1))
+    const unsigned char* in;     // S16 tensor, allocation start (= pixel (-1, -1) of plane 0)
     unsigned char* out;          // S16 tensor of the same geometry
     const unsigned char* img;    // T64_IMG bytes
     int H, W;                    // valid pixels
-    int pitch;                   // pixels per allocation row (tiles_x * 32 + 2)
+    int pitch;                   // pixels per plane row (tiles_x * 32 + 2)
+    unsigned plane;              // bytes per plane (rows * pitch * 32)
     int tiles_x, ntiles;
-    int rounds;                  // tiles per group stream (ceil(ntiles / (2 * gridDim.x)))
-    long long* stamps = nullptr; // bench builds only (TAG & T64_STAMPS): [workgroup][wave 16][step 32][4] shader-clock stamps
+    long long* stamps = nullptr; // bench builds only (TAG & T64_STAMPS): [workgroup][wave 8][step 32][4] shader-clock stamps
 };
 // bench-only ablation bits of TAG (timing experiments; the results of all but T64_STAMPS are garbage).  The product instantiates TAG = 3.
-enum { T64_NOSTORE = 0x100, T64_NODMA = 0x200, T64_NOMATH = 0x400, T64_NOVMWAIT = 0x800, T64_STAMPS = 0x1000, T64_INPHASE = 0x2000 };
+enum { T64_NOSTORE = 0x100, T64_NODMA = 0x200, T64_NOMATH = 0x400, T64_NOVMWAIT = 0x800, T64_STAMPS = 0x1000 };
 
 typedef __attribute__((address_space(3))) unsigned char t64_lds_u8;
 typedef __attribute__((address_space(1))) const unsigned char t64_glb_u8;
@@ -59,23 +68,15 @@ __device__ __forceinline__ void t64_glds16(const unsigned char* g, unsigned char
 }
 
 template <int TAG>
-__global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_t64_kernel(T64Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* const lds = ldsb;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);            // provably wave-uniform: the barrier counts below depend on it
-    const int g = wv >> 3, r = wv & 7;                                    // group, output row of the group's tile
+    const int r = __builtin_amdgcn_readfirstlane(tid >> 6);              // wave = output row of the tile (wave-uniform by construction)
     const int h = lane >> 5, li = lane & 31;
 
-    // ---- static image: 74.5 KiB, lane-linear
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const int i = wv + 16 * j;
-        if (i * 1024 + lane * 16 < T64_IMG) t64_glds16(a.img + i * 1024 + lane * 16, lds + i * 1024);
-    }
-
     // ---- per-lane constants
-    // DMA: piece i = r + 8 j of the group's chunk buffer covers LDS slots 64 i .. 64 i + 63 (16 bytes each)
+    // halo DMA: piece i = r + 8 j of the chunk buffer covers LDS slots 64 i .. 64 i + 63 (16 bytes each)
     unsigned soff[3];
     bool s2ok;
 #pragma unroll
@@ -85,46 +86,59 @@ __global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
         const int P = min(s1 >> 1, T64_NPX - 1), pos = s1 & 1;
         const int kh = pos ^ ((P >> 3) & 1);
         const int py = P / T64_IW, px = P - py * T64_IW;
-        soff[j] = (unsigned)(py * a.pitch + px) * 256u + (unsigned)(pl * 32 + kh * 16);
+        soff[j] = (unsigned)pl * a.plane + (unsigned)(py * a.pitch + px) * 32u + (unsigned)(kh * 16);
         if (j == 2) s2ok = s < 4 * T64_NPX;
     }
-    unsigned char* const inb = lds + T64_IMG + g * 2 * T64_INB;
     // fragment addresses of the nine taps (hi plane; lo = + T64_PLANE), pixel P = (r + dy) * 34 + li + dx
     const unsigned char* ap[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) {
         const int P = (r + t / 3) * T64_IW + li + t % 3;
-        ap[t] = inb + P * 32 + ((h ^ ((P >> 3) & 1)) << 4);
+        ap[t] = lds + T64_LDS_IN + P * 32 + ((h ^ ((P >> 3) & 1)) << 4);
     }
-    const unsigned char* const wb = lds + h * 1024 + li * 16;
-    const unsigned char* const idb = lds + T64_WB + h * 512 + li * 16;
-    const float* const bs = reinterpret_cast<const float*>(lds + T64_WB + T64_IDB);
+    const unsigned char* const wb = lds + T64_LDS_W + h * 1024 + li * 16;
+    const float* const bs = reinterpret_cast<const float*>(lds + T64_LDS_BS);
+    // identity A fragments of the skip connection: K chunk c = 2 n + hc carries input channels 32 n + 16 hc .. + 15, i.e. the rows
+    // i of block n with s16_row_channel(i) = 16 hc + k; lane (row li, k half h) holds A[li][8 h .. 8 h + 7]
+    f16x8 idf[2];
+    {
+        const int ch = s16_row_channel(li);
+#pragma unroll
+        for (int hc = 0; hc < 2; hc++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) idf[hc][e] = ch == 16 * hc + 8 * h + e ? (_Float16)1.f : (_Float16)0.f;
+    }
 
-    // ---- tile streams: workgroup b runs on XCD b % 8; per round every XCD walks a contiguous band of tiles
+    // ---- tile stream: workgroup b runs on XCD b % 8; per round every XCD walks a contiguous band of tiles
     const int nwg = gridDim.x, b = blockIdx.x;
-    const int per_xcd = (nwg >> 3) * 2;
-    const int slot = (b & 7) * per_xcd + (b >> 3) * 2 + g;
-    const int per_round = nwg * 2;
-
-    // this group's stream: tiles slot, slot + per_round, ... (mine of them exist); the other rounds only keep the barrier count
-    const int mine = a.ntiles > slot ? (a.ntiles - slot + per_round - 1) / per_round : 0;
+    const int slot = (b & 7) * (nwg >> 3) + (b >> 3);
+    const int mine = a.ntiles > slot ? (a.ntiles - slot + nwg - 1) / nwg : 0;
     f32x16 acc[2];
     int oy0 = 0, ox0 = 0;
     unsigned tb = 0;                                                     // byte offset of the tile's halo origin (tensors stay below 4 GB)
-    if (mine > 0) { const int ty = slot / a.tiles_x; oy0 = ty * 8; ox0 = (slot - ty * a.tiles_x) * 32; tb = (unsigned)(oy0 * a.pitch + ox0) * 256u; }
+    if (mine > 0) { const int ty = slot / a.tiles_x; oy0 = ty * 8; ox0 = (slot - ty * a.tiles_x) * 32; tb = (unsigned)(oy0 * a.pitch + ox0) * 32u; }
     int poy0 = 0, pox0 = 0;
 
     int stepno = 0;
 #define T64_STAMP(K)                                                                                         \
     if ((TAG & T64_STAMPS) && lane == 0 && stepno < 32)                                                      \
-        a.stamps[(((size_t)blockIdx.x * 16 + wv) * 32 + stepno) * 4 + (K)] = (long long)__builtin_readcyclecounter();
-#define T64_DMA(TB, C, PAR)                                                                                  \
+        a.stamps[(((size_t)blockIdx.x * 8 + r) * 32 + stepno) * 4 + (K)] = (long long)__builtin_readcyclecounter();
+    // halo chunk C of the tile at TB -> in[PAR]; weight chunk C -> w[PAR]
+#define T64_DMA_IN(TB, C, PAR)                                                                               \
     if (!(TAG & T64_NODMA)) {                                                                                \
-        const unsigned char* src_ = a.in + (TB) + (C) * 64;       /* wave-uniform base + 32-bit lane offset */ \
-        unsigned char* dst_ = inb + (PAR) * T64_INB + r * 1024;                                              \
+        const unsigned char* src_ = a.in + ((TB) + (unsigned)(2 * (C)) * a.plane);       /* wave-uniform base + 32-bit lane offset */ \
+        unsigned char* dst_ = lds + T64_LDS_IN + (PAR) * T64_INB + r * 1024;                                 \
         t64_glds16(src_ + soff[0], dst_);                                                                    \
         t64_glds16(src_ + soff[1], dst_ + 8 * 1024);                                                         \
         if (r < 6 && s2ok) t64_glds16(src_ + soff[2], dst_ + 16 * 1024);                                     \
+    }
+#define T64_DMA_W(C, PAR)                                                                                    \
+    if (!(TAG & T64_NODMA)) {                                                                                \
+        const unsigned char* src_ = a.img + (C) * T64_WCH + r * 1024 + lane * 16;                            \
+        unsigned char* dst_ = lds + T64_LDS_W + (PAR) * T64_WCH + r * 1024;                                  \
+        t64_glds16(src_, dst_);                                                                              \
+        t64_glds16(src_ + 8 * 1024, dst_ + 8 * 1024);                                                        \
+        if (r < 2) t64_glds16(src_ + 16 * 1024, dst_ + 16 * 1024);                                           \
     }
 #define T64_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
 #define T64_TAPS(C, PAR)                                                                                     \
@@ -133,8 +147,8 @@ __global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
         _Pragma("unroll") for (int t = 0; t < 9; t++) {                                                      \
             const f16x8 ah = *reinterpret_cast<const f16x8*>(ap[t] + (PAR) * T64_INB);                       \
             const f16x8 al = *reinterpret_cast<const f16x8*>(ap[t] + (PAR) * T64_INB + T64_PLANE);           \
-            const f16x8 b0 = *reinterpret_cast<const f16x8*>(wb + ((C) * 9 + t) * 2048);                     \
-            const f16x8 b1 = *reinterpret_cast<const f16x8*>(wb + ((C) * 9 + t) * 2048 + 512);               \
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(wb + (PAR) * T64_WCH + t * 2048);               \
+            const f16x8 b1 = *reinterpret_cast<const f16x8*>(wb + (PAR) * T64_WCH + t * 2048 + 512);         \
             acc[0] = T64_MFMA(b0, ah, acc[0]);                                                               \
             acc[1] = T64_MFMA(b1, ah, acc[1]);                                                               \
             acc[0] = T64_MFMA(b0, al, acc[0]);                                                               \
@@ -143,9 +157,8 @@ __global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
         {   /* skip connection: identity on the centre pixel; chunk C only feeds output block C >> 1 */      \
             const f16x8 ah = *reinterpret_cast<const f16x8*>(ap[4] + (PAR) * T64_INB);                       \
             const f16x8 al = *reinterpret_cast<const f16x8*>(ap[4] + (PAR) * T64_INB + T64_PLANE);           \
-            const f16x8 bi = *reinterpret_cast<const f16x8*>(idb + ((C) & 1) * 1024);                        \
-            acc[(C) >> 1] = T64_MFMA(bi, ah, acc[(C) >> 1]);                                                 \
-            acc[(C) >> 1] = T64_MFMA(bi, al, acc[(C) >> 1]);                                                 \
+            acc[(C) >> 1] = T64_MFMA(idf[(C) & 1], ah, acc[(C) >> 1]);                                       \
+            acc[(C) >> 1] = T64_MFMA(idf[(C) & 1], al, acc[(C) >> 1]);                                       \
         }                                                                                                    \
     }
 #define T64_SYNC()                                                                                           \
@@ -157,12 +170,12 @@ __global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
         T64_STAMP(2)                                                                                         \
         stepno++;                                                                                            \
     }
-    // y = slope(acc + bias) -> {hi, lo} records, quad-transposed so that every store instruction writes whole 128-byte lines
+    // y = slope(acc + bias) -> hi / lo entries of chunk 2 n + h, 32 bytes per pixel and plane
 #define T64_EPILOGUE(OY0, OX0)                                                                               \
     {                                                                                                        \
-        const int oy_ = (OY0) + r, oxq_ = (OX0) + (li & ~3);                                                 \
-        const bool ok_ = oy_ < a.H && oxq_ < a.W && (!(TAG & T64_NOSTORE) || acc[0][0] == 123.456f);         /* ablation: (almost) never true, keeps the matrix work alive */ \
-        unsigned char* const o_ = a.out + ((unsigned)((oy_ + 1) * a.pitch + oxq_ + 1) * 256u + (unsigned)(h * 64)); \
+        const int oy_ = (OY0) + r, ox_ = (OX0) + li;                                                         \
+        const bool ok_ = oy_ < a.H && ox_ < a.W && (!(TAG & T64_NOSTORE) || acc[0][0] == 123.456f);          /* ablation: (almost) never true, keeps the matrix work alive */ \
+        unsigned char* const o_ = a.out + ((unsigned)(2 * h) * a.plane + (unsigned)((oy_ + 1) * a.pitch + ox_ + 1) * 32u); \
         _Pragma("unroll") for (int n = 0; n < 2; n++) {                                                      \
             float v_[16];                                                                                    \
             _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                  \
@@ -173,22 +186,26 @@ __global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
                     v_[4 * q + k] = y < 0.f ? y * s4[k] : y;                                                 \
                 }                                                                                            \
             }                                                                                                \
-            s16_store_record(v_, o_ + n * 128, lane, ok_);                                                   \
+            s16_store_chunk(v_, o_ + (unsigned)(4 * n) * a.plane, a.plane, ok_);                             \
         }                                                                                                    \
     }
 
-    if (mine > 0) T64_DMA(tb, 0, 0)
+    // ---- prologue: bias / slopes, weight chunk 0, halo chunk 0 of the first tile
+    if (r == 7 && lane < 32 && !(TAG & T64_NODMA)) t64_glds16(a.img + T64_WB + lane * 16, lds + T64_LDS_BS);
+    if (TAG & T64_NODMA) { for (int i = tid; i < T64_LDS / 16; i += 512) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    T64_DMA_W(0, 0)
+    if (mine > 0) T64_DMA_IN(tb, 0, 0)
     T64_SYNC()
-    if (g == 1 && !(TAG & T64_INPHASE)) { __syncthreads(); __syncthreads(); }      // group 1 runs two steps behind group 0
 
     for (int k = 0; k < mine; k++) {
-        const int Tn = slot + (k + 1) * per_round;
+        const int Tn = slot + (k + 1) * nwg;
         const bool more = k + 1 < mine;
         int oy0n = 0, ox0n = 0;
         unsigned tbn = 0;
-        if (more) { const int ty = Tn / a.tiles_x; oy0n = ty * 8; ox0n = (Tn - ty * a.tiles_x) * 32; tbn = (unsigned)(oy0n * a.pitch + ox0n) * 256u; }
+        if (more) { const int ty = Tn / a.tiles_x; oy0n = ty * 8; ox0n = (Tn - ty * a.tiles_x) * 32; tbn = (unsigned)(oy0n * a.pitch + ox0n) * 32u; }
 
-        T64_DMA(tb, 1, 1)
+        T64_DMA_IN(tb, 1, 1)
+        T64_DMA_W(1, 1)
         if (k > 0) T64_EPILOGUE(poy0, pox0)
 #pragma unroll
         for (int n = 0; n < 2; n++)
@@ -197,15 +214,17 @@ __global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
         T64_TAPS(0, 0)
         T64_SYNC()
 
-        T64_DMA(tb, 2, 0)
+        T64_DMA_IN(tb, 2, 0)
+        T64_DMA_W(2, 0)
         T64_TAPS(1, 1)
         T64_SYNC()
 
-        T64_DMA(tb, 3, 1)
+        T64_DMA_IN(tb, 3, 1)
+        T64_DMA_W(3, 1)
         T64_TAPS(2, 0)
         T64_SYNC()
 
-        if (more) T64_DMA(tbn, 0, 0)
+        if (more) { T64_DMA_IN(tbn, 0, 0) T64_DMA_W(0, 0) }
         T64_TAPS(3, 1)
         T64_SYNC()
 
@@ -213,9 +232,9 @@ __global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
         oy0 = oy0n; ox0 = ox0n; tb = tbn;
     }
     if (mine > 0) T64_EPILOGUE(poy0, pox0)
-    for (int k = mine; k < a.rounds; k++) { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); }
-    if (g == 0 && !(TAG & T64_INPHASE)) { __syncthreads(); __syncthreads(); }
-#undef T64_DMA
+#undef T64_STAMP
+#undef T64_DMA_IN
+#undef T64_DMA_W
 #undef T64_MFMA
 #undef T64_TAPS
 #undef T64_SYNC

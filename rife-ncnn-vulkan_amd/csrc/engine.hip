@@ -188,8 +188,8 @@ static std::vector<uint16_t> pack_weights_h2_perm(const ConvLayer& L, const floa
     return out;
 }
 
-// Static LDS image of conv_t64_kernel (conv_t64.h): fp16 weights [chunk 4][tap 9][k half 2][row 64][8] with the rows of each
-// 32-row block permuted by s16_row_channel(), the two identity slabs of the skip connection, then bias[64] and slope[64] as fp32.
+// Weight image of conv_t64_kernel (conv_t64.h): fp16 weights [chunk 4][tap 9][k half 2][row 64][8] with the rows of each
+// 32-row block permuted by s16_row_channel() (every chunk is one contiguous LDS-DMA source), then bias[64] and slope[64] as fp32.
 static std::vector<unsigned char> pack_t64_image(const float* w, const float* bias, float slope) {
     std::vector<unsigned char> img(T64_IMG, 0);
     uint16_t* wh = reinterpret_cast<uint16_t*>(img.data());
@@ -201,13 +201,7 @@ static std::vector<unsigned char> pack_t64_image(const float* w, const float* bi
                         const int oc = (row & ~31) + s16_row_channel(row & 31), ic = 16 * c + 8 * kh + e;
                         wh[((((size_t)c * 9 + t) * 2 + kh) * 64 + row) * 8 + e] = f2h(w[((size_t)oc * 64 + ic) * 9 + t]);
                     }
-    uint16_t* id = reinterpret_cast<uint16_t*>(img.data() + T64_WB);
-    for (int hc = 0; hc < 2; hc++)               // chunk c = 2 n + hc carries input channels 32 n + 16 hc .. + 15 = the rows of block n whose s16_row_channel is 16 hc + k
-        for (int kh = 0; kh < 2; kh++)
-            for (int i = 0; i < 32; i++)
-                for (int e = 0; e < 8; e++)
-                    id[((hc * 2 + kh) * 32 + i) * 8 + e] = s16_row_channel(i) == 16 * hc + 8 * kh + e ? 0x3c00 : 0;
-    float* bs = reinterpret_cast<float*>(img.data() + T64_WB + T64_IDB);
+    float* bs = reinterpret_cast<float*>(img.data() + T64_WB);
     for (int i = 0; i < 64; i++) { bs[i] = bias ? bias[i] : 0.f; bs[64 + i] = slope; }
     return img;
 }
@@ -379,9 +373,9 @@ static const bool g_use_conv8 = []() { const char* e = getenv("RIFE_HIP_CONV8");
 // x: NHWC input (H x W), y: output; for deconv layers y has 2H x 2W pixels (or the 4H x 4W flow tensor with EPI_DECONV_PS).
 // s16_pitch > 0: the stride-2 stem writes / the head reads an S16 tensor (conv_t64.h) of that row pitch instead of NHWC fp32
 static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorView y, const TensorView* res, hipStream_t st, const FinalArgs* fin = nullptr,
-                       int s16_pitch = 0) {
+                       int s16_pitch = 0, unsigned s16_plane = 0) {
     ConvArgs a;
-    a.s16_pitch = s16_pitch;
+    a.s16_pitch = s16_pitch; a.s16_plane = s16_plane;
     a.in = x.p; a.in_ld = x.ld; a.in_coff = x.coff; a.H = H; a.W = W;
     a.out = y.p; a.out_ld = y.ld; a.out_coff = y.coff;
     a.wpk = L.d_w; a.bias = L.d_bias; a.slope = L.d_slope;
@@ -618,14 +612,15 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
     return 0;
 }
 
-// S16 tensor geometry for an H x W pixel grid (conv_t64.h): 8 x 32 tiles, one pixel of zero border on every side
+// S16 tensor geometry for an H x W pixel grid (conv_t64.h): 8 x 32 tiles, one pixel of zero border on every side of every plane
 struct S16Geom {
     int tiles_x, tiles_y, pitch, rows;
     S16Geom(int H, int W) : tiles_x((W + 31) / 32), tiles_y((H + 7) / 8), pitch(tiles_x * 32 + 2), rows(tiles_y * 8 + 2) {}
-    size_t bytes(int C) const { return (size_t)rows * pitch * C * 4; }
+    unsigned plane() const { return (unsigned)rows * pitch * 32u; }             // one [chunk][hi | lo] plane
+    size_t bytes(int C) const { return (size_t)plane() * (C / 8); }
 };
 
-// one 64 -> 64 residual trunk convolution, S16 in / S16 out, persistent workgroups (one per CU)
+// one 64 -> 64 residual trunk convolution, S16 in / S16 out, persistent workgroups (two per CU)
 static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st) {
     if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_t64 image");
     int dev = 0; (void)hipGetDevice(&dev);
@@ -644,10 +639,9 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
     }
     const S16Geom G(H, W);
     T64Args a;
-    a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y;
-    const int nwg = std::min(cus, ((a.ntiles + 1) / 2 + 7) / 8 * 8);
-    a.rounds = (a.ntiles + 2 * nwg - 1) / (2 * nwg);
-    hipLaunchKernelGGL(conv_t64_kernel<3>, dim3(nwg), dim3(1024), T64_LDS, st, a);
+    a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y;
+    const int nwg = std::min(2 * cus, (a.ntiles + 7) / 8 * 8);            // two resident workgroups per CU (LDS: 79 KB each)
+    hipLaunchKernelGGL(conv_t64_kernel<3>, dim3(nwg), dim3(512), T64_LDS, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_t64 launch: ") + hipGetErrorString(e));
     return 0;
@@ -988,7 +982,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         const S16Geom G(Ht, Wt);
         {
             Timed t(E.prof, B.stem1.cls, B.stem1.flops_per_pixel * Ht * Wt, st);
-            if ((rc = launch_conv(B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {reinterpret_cast<float*>(c.P0), B.c, 0}, nullptr, st, nullptr, G.pitch))) return rc;
+            if ((rc = launch_conv(B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {reinterpret_cast<float*>(c.P0), B.c, 0}, nullptr, st, nullptr, G.pitch, G.plane()))) return rc;
         }
         unsigned char *pc = c.P0, *pn = c.P1;
         for (int i = 0; i < 8; i++) {
@@ -997,7 +991,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
             std::swap(pc, pn);
         }
         Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);
-        return launch_conv(B.head, {reinterpret_cast<float*>(pc), B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st, fin, G.pitch);
+        return launch_conv(B.head, {reinterpret_cast<float*>(pc), B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st, fin, G.pitch, G.plane());
     }
     float* const stem_out = E.v40 ? c.T2 : c.T0;
     {

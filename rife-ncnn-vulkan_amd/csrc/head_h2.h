@@ -78,7 +78,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int py = p / IW, px = p - py * IW;
         const int gy = iy0 + py, gx = ix0 + px;
         const bool ok = idx < IN_F4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        if (S16IN) goff[k] = idx < IN_F4 ? ((gy + 1) * a.s16_pitch + gx + 1) * a.in_ld + q * 4 : 0;     // the border and the ragged tile edge are stored zeros
+        // S16 planes: quarter q of a pixel's chunk = 16 bytes of the hi (q < 2) or lo plane; offsets in floats; border and ragged edge are stored zeros
+        if (S16IN) goff[k] = idx < IN_F4 ? (int)((q >> 1) * (a.s16_plane / 4)) + ((gy + 1) * a.s16_pitch + gx + 1) * 8 + (q & 1) * 4 : 0;
         else goff[k] = ok ? (gy * a.W + gx) * a.in_ld + a.in_coff + q * 4 : a.in_coff;
         inside |= ok ? (1u << k) : 0u;
     }
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     f32x4 rin[NIN], rw[NW];
 #define HD_ISSUE_IN(CH)                                                                                     \
-    _Pragma("unroll") for (int k = 0; k < NIN; k++) rin[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC);
+    _Pragma("unroll") for (int k = 0; k < NIN; k++) rin[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (S16IN ? (size_t)(CH) * (a.s16_plane / 2) : (size_t)(CH) * CC));
 #define HD_ISSUE_W(CH)                                                                                      \
     _Pragma("unroll") for (int k = 0; k < NW; k++) rw[k] = wsrc[(size_t)(CH) * W_16 + tid + k * 512];
 #define HD_WRITE_IN(BUFP)                                                                                   \

@@ -42,15 +42,18 @@ def pair(modeldirs):
 def test_t64_output_is_bit_identical_to_the_per_tile_trunk(pair, w, h, t, seed):
     new, old = pair
     a, b = gen_frames.smooth_pair(w, h, seed) if w * h < 4000000 else [np.kron(f, np.ones((4, 4, 1), np.uint8)) for f in gen_frames.smooth_pair(w // 4, h // 4, seed)]
-    def same(x, y):
-        if w * h >= 1000 * 520:
-            return np.array_equal(x, y)
-        # small frames: the per-tile path splits K over several workgroups for its tiny grids (another summation order)
+    def check(x, y, what):
         d = np.abs(x.astype(np.int32) - y.astype(np.int32))
-        return d.max() <= 1 and (d > 0).mean() < 1e-3
-    assert same(new.process(a, b, t), old.process(a, b, t))
+        report = "%s: %d of %d bytes differ, max %d" % (what, int((d > 0).sum()), d.size, int(d.max()))
+        if w * h >= 1000 * 520:
+            assert d.max() == 0, report
+        else:   # small frames: the per-tile path splits K over several workgroups for its tiny grids (another summation order)
+            assert d.max() <= 1 and (d > 0).mean() < 1e-3, report
+    check(new.process(a, b, t), old.process(a, b, t), "first call")
     # a second call on the same workspace: the zero borders of the S16 tensors must have survived the first
-    assert same(new.process(b, a, 1.0 - t), old.process(b, a, 1.0 - t))
+    check(new.process(b, a, 1.0 - t), old.process(b, a, 1.0 - t), "second call")
+    x = new.process(a, b, t)
+    assert np.array_equal(x, new.process(a, b, t)), "the S16 path is not deterministic"
 
 
 @pytest.mark.parametrize("w,h", [(160, 96), (100, 60)])
