@@ -307,15 +307,15 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpuid));
     T64Args a;
     a.in = x; a.out = y; a.img = dimg; a.H = h; a.W = w; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y;
-    const int nwg = std::min(cus / 8 * 8, (a.ntiles + 7) / 8 * 8);
+    const int nwg = std::min(T64_WG_PER_CU * (cus / 8 * 8), (a.ntiles + 7) / 8 * 8);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     auto run = [&](auto kfn) -> int {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, T64_LDS));
-        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(1024), T64_LDS, 0, a);
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(T64_NTHR), T64_LDS, 0, a);
         HIPCHK(hipEventRecord(e0, 0));
         for (int i = 0; i < iters; i++) {
             a.in = (i & 1) ? y : x; a.out = (i & 1) ? x : y;
-            hipLaunchKernelGGL(kfn, dim3(nwg), dim3(1024), T64_LDS, 0, a);
+            hipLaunchKernelGGL(kfn, dim3(nwg), dim3(T64_NTHR), T64_LDS, 0, a);
         }
         HIPCHK(hipEventRecord(e1, 0));
         HIPCHK(hipEventSynchronize(e1));
@@ -324,7 +324,7 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
         return 0;
     };
     if (variant == T64_STAMPS) {
-        const size_t nst = (size_t)nwg * 16 * 32 * 4;
+        const size_t nst = (size_t)nwg * T64_TH * 32 * 4;
         HIPCHK(hipMalloc(&a.stamps, nst * 8));
         HIPCHK(hipMemset(a.stamps, 0, nst * 8));
         rc = run(conv_t64_kernel<T64_STAMPS>);
@@ -341,10 +341,6 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
         case T64_NODMA | T64_NOSTORE: rc = run(conv_t64_kernel<T64_NODMA | T64_NOSTORE>); break;
         case T64_NOMATH | T64_NOSTORE: rc = run(conv_t64_kernel<T64_NOMATH | T64_NOSTORE>); break;
         case T64_NOMATH | T64_NODMA: rc = run(conv_t64_kernel<T64_NOMATH | T64_NODMA>); break;
-        case T64_NOLDSREAD | T64_NOSTORE: rc = run(conv_t64_kernel<T64_NOLDSREAD | T64_NOSTORE>); break;
-        case T64_NOLDSREAD | T64_NOSTORE | T64_NODMA: rc = run(conv_t64_kernel<T64_NOLDSREAD | T64_NOSTORE | T64_NODMA>); break;
-        case T64_NOMFMA | T64_NOSTORE: rc = run(conv_t64_kernel<T64_NOMFMA | T64_NOSTORE>); break;
-        case T64_NOMFMA | T64_NOSTORE | T64_NODMA: rc = run(conv_t64_kernel<T64_NOMFMA | T64_NOSTORE | T64_NODMA>); break;
         default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
     }
     (void)hipFree(x); (void)hipFree(y); (void)hipFree(dimg); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

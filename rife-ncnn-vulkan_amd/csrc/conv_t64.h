@@ -1,6 +1,6 @@
 // conv_t64_kernel: the 64 -> 64 channel residual trunk convolution of the finest IFBlock
 // (reference models/rife-v4.6/flownet.param:169-197: Split, Convolution 3x3 pad 1, BinaryOp add, ReLU slope 0.2; 8 per pair,
-// 44 % of the pair's MACs) as ONE persistent 16-wave workgroup per CU on the split-f16 matrix path of conv_h2b_kernel.
+// 44 % of the pair's MACs) as persistent workgroups, two per CU, on the split-f16 matrix path of conv_h2b_kernel.
 //
 // What changed against conv_h2b_kernel (whose phase trace showed ~10 of the 21 us of every workgroup in latency-bound prologue /
 // epilogue, matrix pipe 42 % busy):
@@ -10,22 +10,26 @@
 //     tile is then plain memory (no bounds tests, no conversion), one row of one chunk is 34 x 32 contiguous bytes, and
 //     global_load_lds_dwordx4 moves it 1 KiB at a time touching 8-9 cache lines (per-pixel 64-byte records of all chunks
 //     interleaved touched 32: the loads were address-processing bound).
-//   * persistent: #CU workgroups of 16 waves walk their own sequences of 16-row x 32-column tiles (one wave per row).  Every step
-//     (one 16-channel K chunk of one tile: 38 MFMAs per wave) starts by sending the halo chunk of the step AFTER NEXT (ring of
-//     three 38 KB buffers) and the weight chunk of the next step on their way with LDS-DMA (39 + 18 pieces of 1 KiB, no
-//     registers, no VALU), and ends with a COUNTED s_waitcnt vmcnt(pieces this wave issued in this step) + one s_barrier: a halo
-//     chunk has two whole steps to land and the memory system always has a step's worth of bytes in flight (with one step of
-//     lookahead every step waited for a full memory round trip of its own burst: loads, stores and matrix work added up instead
-//     of overlapping - tools/t64_bench.py clock stamps).  A tile switch costs nothing; the epilogue (registers -> global, no
-//     LDS, no barrier) of tile i runs at the start of tile i + 1.
+//   * persistent: 2 x #CU workgroups of 8 waves walk their own sequences of 8-row x 32-column tiles.  Every step (one 16-channel
+//     K chunk of one tile: 38 MFMAs per wave) starts by sending the NEXT step's halo chunk and weight chunk on their way with
+//     LDS-DMA (22 + 18 pieces of 1 KiB, no registers, no VALU) and ends with vmcnt(0) + one s_barrier: the loads have the whole
+//     step to land, a tile switch costs nothing, and the epilogue (registers -> global, no LDS, no barrier) of tile i runs at the
+//     start of tile i + 1 while the co-resident workgroup has the matrix pipe.
 //   * output channels are permuted inside each 32-row MFMA block (a property of the weight packing only) so that a lane ends
 //     up with 16 CONSECUTIVE channels of one pixel = the pixel's 32 hi and 32 lo bytes of one chunk: consecutive lanes store
 //     consecutive 32-byte entries (s16_store_chunk, conv_mfma.h), no LDS transpose, no barrier.
 //   * the identity tap of the skip connection needs no LDS: its A fragment (a permutation matrix) is built in registers.
-// History (MI355X, 544 x 960 tensor = 3840 x 2160 frame, per launch): conv_h2b 91-95 us; one workgroup per CU with two
-// phase-shifted 8-wave groups behind ONE s_barrier and resident weights 100 us (record stores at 256-byte lane stride: store-issue
-// bound, 45 us for the stores alone), 82-88 us with quad-transposed stores - the workgroup-wide barrier made each group wait
-// for the other group's epilogue (all-wave clock stamps: tools/t64_bench.py); this version: see DESIGN.md.
+// Measured (MI355X, 544 x 960 tensor = 3840 x 2160 frame, per launch, tools/t64_bench.py; profiles/r2/): conv_h2b 91-95 us ->
+// this kernel 81-83 us.  Parts, same launch geometry: MFMAs on registers only 40 us (= the matrix floor at the ~1.95 GHz the
+// chip sustains), + LDS fragment reads 43 us, loads alone 22-26 us, stores alone 27 us, loads + stores 49-52 us (= 5.2-5.5 TB/s:
+// the HBM floor of 134 MB in + 134 MB out).  The parts still add up more than they overlap: every VMEM instruction (40 DMA
+// pieces per step, 64 stores per tile) blocks its wave while the memory queue is full, and the waves that wait are the waves
+// that feed the matrix pipe.  Variants measured and dropped (git history): ONE 16-wave workgroup per CU with resident weights
+// and two phase-shifted 8-wave groups behind one s_barrier (100 us with 64-byte per-pixel records stored at a 256-byte lane
+// stride - the stores alone took 45 us, store-issue bound; 82-88 us after a DPP quad transpose made them whole lines: each
+// group waited at the barrier for the other group's epilogue); one 16-wave workgroup, 16 x 32 tiles, ring of three halo
+// buffers with counted vmcnt waits (loads fully hidden, but all 16 epilogues collide: 86-91 us; best frame rate with two pairs
+// in flight, 409 vs 397 frames/s at 4K); 1-byte LDS-DMA "touches" that pull the chunk after next into the L2 (+5 us).
 // LDS image of a halo chunk: hi plane [340 px][32 B] then lo plane [340 px][32 B]; the two 16-byte halves of a 32-byte entry are
 // swapped when bit 3 of the pixel index is set, which makes the ds_read_b128 fragment reads of 16 consecutive pixels hit 64
 // distinct banks (SQ_LDS_BANK_CONFLICT = 0).  The DMA writes LDS lane-linear, so the swap is applied to each lane's SOURCE
@@ -36,17 +40,17 @@
 
 namespace rife {
 
-constexpr int T64_TH = 16;                                               // tile rows = waves per workgroup
-constexpr int T64_IH = T64_TH + 2, T64_IW = 34, T64_NPX = T64_IH * T64_IW;      // halo tile of a 16 x 32 output tile: 612 pixels
-constexpr int T64_PLANE = T64_NPX * 32;                                  // 19,584 B: hi (or lo) halves of one 16-channel chunk
-constexpr int T64_INB = 2 * T64_PLANE;                                   // 39,168 B per halo chunk buffer = 38.25 DMA pieces
+constexpr int T64_TH = 8, T64_NTHR = 64 * T64_TH, T64_WG_PER_CU = 2;    // tile rows = waves per workgroup; resident workgroups per CU
+constexpr int T64_IH = T64_TH + 2, T64_IW = 34, T64_NPX = T64_IH * T64_IW;      // halo tile of an 8 x 32 output tile
+constexpr int T64_PLANE = T64_NPX * 32;                                  // 10,880 B: hi (or lo) halves of one 16-channel chunk
+constexpr int T64_INB = 2 * T64_PLANE;                                   // 21,760 B per halo chunk buffer
 constexpr int T64_WCH = 9 * 2048;                                        // 18,432 B: weights of one K chunk [tap][k half][64 rows][8 f16]
 constexpr int T64_WB = 4 * T64_WCH;                                      // 73,728 B
 constexpr int T64_BSB = 2 * 64 * 4;                                      // bias[64], slope[64]
 constexpr int T64_IMG = T64_WB + T64_BSB;                                // 74,240 B: weight image in global memory, built on the host
-constexpr int T64_LDS_IN = 0, T64_LDS_W = 3 * T64_INB, T64_LDS_BS = T64_LDS_W + 2 * T64_WCH;
-constexpr int T64_LDS = T64_LDS_BS + T64_BSB;                            // 154,880 B: one workgroup per CU (limit 163,840)
-static_assert(T64_LDS <= 160 * 1024, "LDS budget");
+constexpr int T64_LDS_IN = 0, T64_LDS_W = 2 * T64_INB, T64_LDS_BS = T64_LDS_W + 2 * T64_WCH;
+constexpr int T64_LDS = T64_LDS_BS + T64_BSB;                            // 80,896 B: two workgroups per CU (limit 163,840)
+static_assert(T64_WG_PER_CU * T64_LDS <= 160 * 1024, "LDS budget");
 
 // row i of a 32-row MFMA block <-> output channel (within the block): a lane's 16 accumulator registers are 16 consecutive channels
 __host__ __device__ constexpr int s16_row_channel(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
@@ -56,13 +60,13 @@ struct T64Args {
     unsigned char* out;          // S16 tensor of the same geometry
     const unsigned char* img;    // T64_IMG bytes
     int H, W;                    // valid pixels
-    int pitch;                   // pixels per plane row (tiles_x * 32 + 2); the planes have ceil(H / 16) * 16 + 2 rows
+    int pitch;                   // pixels per plane row (tiles_x * 32 + 2)
     unsigned plane;              // bytes per plane (rows * pitch * 32)
     int tiles_x, ntiles;
-    long long* stamps = nullptr; // bench builds only (TAG & T64_STAMPS): [workgroup][wave 16][step 32][4] shader-clock stamps
+    long long* stamps = nullptr; // bench builds only (TAG & T64_STAMPS): [workgroup][wave 8][step 32][4] shader-clock stamps
 };
 // bench-only ablation bits of TAG (timing experiments; the results of all but T64_STAMPS are garbage).  The product instantiates TAG = 3.
-enum { T64_NOSTORE = 0x100, T64_NODMA = 0x200, T64_NOMATH = 0x400, T64_NOVMWAIT = 0x800, T64_STAMPS = 0x1000, T64_NOLDSREAD = 0x2000, T64_NOMFMA = 0x4000 };
+enum { T64_NOSTORE = 0x100, T64_NODMA = 0x200, T64_NOMATH = 0x400, T64_NOVMWAIT = 0x800, T64_STAMPS = 0x1000 };
 
 typedef __attribute__((address_space(3))) unsigned char t64_lds_u8;
 typedef __attribute__((address_space(1))) const unsigned char t64_glb_u8;
@@ -72,7 +76,7 @@ __device__ __forceinline__ void t64_glds16(const unsigned char* g, unsigned char
 }
 
 template <int TAG>
-__global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
+__global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_t64_kernel(T64Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* const lds = ldsb;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -80,13 +84,12 @@ __global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
     const int h = lane >> 5, li = lane & 31;
 
     // ---- per-lane constants
-    // halo DMA: piece i = r + 16 j of a chunk buffer covers LDS slots 64 i .. 64 i + 63 (16 bytes each); waves 0..6 move three
-    // pieces per step, the others two (piece 38 is a quarter piece)
+    // halo DMA: piece i = r + 8 j of the chunk buffer covers LDS slots 64 i .. 64 i + 63 (16 bytes each)
     unsigned soff[3];
     bool s2ok;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-        const int s = (r + 16 * j) * 64 + lane;
+        const int s = (r + 8 * j) * 64 + lane;
         const int pl = s >= 2 * T64_NPX ? 1 : 0, s1 = s - pl * 2 * T64_NPX;
         const int P = min(s1 >> 1, T64_NPX - 1), pos = s1 & 1;
         const int kh = pos ^ ((P >> 3) & 1);
@@ -94,18 +97,15 @@ __global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
         soff[j] = (unsigned)pl * a.plane + (unsigned)(py * a.pitch + px) * 32u + (unsigned)(kh * 16);
         if (j == 2) s2ok = s < 4 * T64_NPX;
     }
-    const bool three = r < 7;                                            // this wave's halo pieces per step: 3, else 2
-    // fragment offsets of the nine taps inside a chunk buffer (hi plane; lo = + T64_PLANE), pixel P = (r + dy) * 34 + li + dx
-    unsigned ao[9];
+    // fragment addresses of the nine taps (hi plane; lo = + T64_PLANE), pixel P = (r + dy) * 34 + li + dx
+    const unsigned char* ap[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) {
         const int P = (r + t / 3) * T64_IW + li + t % 3;
-        ao[t] = (unsigned)(P * 32 + ((h ^ ((P >> 3) & 1)) << 4));
+        ap[t] = lds + T64_LDS_IN + P * 32 + ((h ^ ((P >> 3) & 1)) << 4);
     }
     const unsigned char* const wb = lds + T64_LDS_W + h * 1024 + li * 16;
     const float* const bs = reinterpret_cast<const float*>(lds + T64_LDS_BS);
-    // weight pieces (18 per chunk): wave w moves piece 15 - w, waves 15 and 14 also pieces 16 and 17 (the waves with two halo pieces)
-    const int wq0 = 15 - r, wq1 = 31 - r;
     // identity A fragments of the skip connection: K chunk c = 2 n + hc carries input channels 32 n + 16 hc .. + 15, i.e. the rows
     // i of block n with s16_row_channel(i) = 16 hc + k; lane (row li, k half h) holds A[li][8 h .. 8 h + 7]
     f16x8 idf[2];
@@ -123,82 +123,57 @@ __global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
     const int mine = a.ntiles > slot ? (a.ntiles - slot + nwg - 1) / nwg : 0;
     f32x16 acc[2];
     int oy0 = 0, ox0 = 0;
-    unsigned tb = 0;                                                     // byte offset of the tile's halo origin inside a plane
+    unsigned tb = 0;                                                     // byte offset of the tile's halo origin (tensors stay below 4 GB)
     if (mine > 0) { const int ty = slot / a.tiles_x; oy0 = ty * T64_TH; ox0 = (slot - ty * a.tiles_x) * 32; tb = (unsigned)(oy0 * a.pitch + ox0) * 32u; }
+    int poy0 = 0, pox0 = 0;
 
     int stepno = 0;
 #define T64_STAMP(K)                                                                                         \
     if ((TAG & T64_STAMPS) && lane == 0 && stepno < 32)                                                      \
-        a.stamps[(((size_t)blockIdx.x * 16 + r) * 32 + stepno) * 4 + (K)] = (long long)__builtin_readcyclecounter();
-    // halo chunk C of the tile at TB -> ring buffer at byte offset IBO; weight chunk C -> w[PAR]
-#define T64_DMA_PIECE(TB, C, IBO, J)                                                                         \
+        a.stamps[(((size_t)blockIdx.x * 8 + r) * 32 + stepno) * 4 + (K)] = (long long)__builtin_readcyclecounter();
+    // halo chunk C of the tile at TB -> in[PAR]; weight chunk C -> w[PAR]
+#define T64_DMA_IN(TB, C, PAR)                                                                               \
     if (!(TAG & T64_NODMA)) {                                                                                \
         const unsigned char* src_ = a.in + ((TB) + (unsigned)(2 * (C)) * a.plane);       /* wave-uniform base + 32-bit lane offset */ \
-        unsigned char* dst_ = lds + T64_LDS_IN + (IBO) + r * 1024;                                           \
-        if ((J) == 0) t64_glds16(src_ + soff[0], dst_);                                                      \
-        if ((J) == 1) t64_glds16(src_ + soff[1], dst_ + 16 * 1024);                                          \
-        if ((J) == 2) { if (three) { if (s2ok) t64_glds16(src_ + soff[2], dst_ + 32 * 1024); } }             \
+        unsigned char* dst_ = lds + T64_LDS_IN + (PAR) * T64_INB + r * 1024;                                 \
+        t64_glds16(src_ + soff[0], dst_);                                                                    \
+        t64_glds16(src_ + soff[1], dst_ + 8 * 1024);                                                         \
+        if (r < 6 && s2ok) t64_glds16(src_ + soff[2], dst_ + 16 * 1024);                                     \
     }
-#define T64_DMA_IN(TB, C, IBO) { T64_DMA_PIECE(TB, C, IBO, 0) T64_DMA_PIECE(TB, C, IBO, 1) T64_DMA_PIECE(TB, C, IBO, 2) }
 #define T64_DMA_W(C, PAR)                                                                                    \
     if (!(TAG & T64_NODMA)) {                                                                                \
-        const unsigned char* src_ = a.img + (C) * T64_WCH + lane * 16;                                       \
-        unsigned char* dst_ = lds + T64_LDS_W + (PAR) * T64_WCH;                                             \
-        t64_glds16(src_ + wq0 * 1024, dst_ + wq0 * 1024);                                                    \
-        if (r >= 14) t64_glds16(src_ + wq1 * 1024, dst_ + wq1 * 1024);                                       \
+        const unsigned char* src_ = a.img + (C) * T64_WCH + r * 1024 + lane * 16;                            \
+        unsigned char* dst_ = lds + T64_LDS_W + (PAR) * T64_WCH + r * 1024;                                  \
+        t64_glds16(src_, dst_);                                                                              \
+        t64_glds16(src_ + 8 * 1024, dst_ + 8 * 1024);                                                        \
+        if (r < 2) t64_glds16(src_ + 16 * 1024, dst_ + 16 * 1024);                                           \
     }
 #define T64_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
-    // the step's matrix work; the halo pieces of the step after next (DO: there is one; tile at TBN, chunk CN, ring slot IBN) are sent
-    // one at a time between the taps instead of in a burst at the start of the step: a VMEM instruction blocks its wave while the
-    // memory queue is full, and a burst of 57 pieces per step kept the last waves from their matrix work for thousands of cycles
-#define T64_TAPS(C, IBO, DO, TBN, CN, IBN)                                                                   \
+#define T64_TAPS(C, PAR)                                                                                     \
     T64_STAMP(3)                                                                                             \
-    if (TAG & T64_NOMATH) { if (DO) T64_DMA_IN(TBN, CN, IBN) }                                               \
     if (!(TAG & T64_NOMATH)) {                                                                               \
-        const unsigned char* const ib_ = lds + T64_LDS_IN + (IBO);                                           \
         _Pragma("unroll") for (int t = 0; t < 9; t++) {                                                      \
-            if (t == 2 && (DO)) T64_DMA_PIECE(TBN, CN, IBN, 0)                                               \
-            if (t == 4 && (DO)) T64_DMA_PIECE(TBN, CN, IBN, 1)                                               \
-            if (t == 6 && (DO)) T64_DMA_PIECE(TBN, CN, IBN, 2)                                               \
-            if (TAG & T64_NOLDSREAD) {      /* ablation: matrix work on registers only */                    \
-                acc[0] = T64_MFMA(idf[0], idf[1], acc[0]); acc[1] = T64_MFMA(idf[1], idf[0], acc[1]);        \
-                acc[0] = T64_MFMA(idf[1], idf[1], acc[0]); acc[1] = T64_MFMA(idf[0], idf[0], acc[1]);        \
-                continue;                                                                                    \
-            }                                                                                                \
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(ib_ + ao[t]);                                   \
-            const f16x8 al = *reinterpret_cast<const f16x8*>(ib_ + ao[t] + T64_PLANE);                       \
-            const f16x8 b0 = *reinterpret_cast<const f16x8*>(wb + ((C) & 1) * T64_WCH + t * 2048);           \
-            const f16x8 b1 = *reinterpret_cast<const f16x8*>(wb + ((C) & 1) * T64_WCH + t * 2048 + 512);     \
-            if (TAG & T64_NOMFMA) {         /* ablation: fragment reads only (kept alive through the accumulators) */ \
-                _Pragma("unroll") for (int e = 0; e < 8; e++) { acc[0][e] += (float)(ah[e] + b0[e]); acc[1][e] += (float)(al[e] + b1[e]); } \
-                continue;                                                                                    \
-            }                                                                                                \
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(ap[t] + (PAR) * T64_INB);                       \
+            const f16x8 al = *reinterpret_cast<const f16x8*>(ap[t] + (PAR) * T64_INB + T64_PLANE);           \
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(wb + (PAR) * T64_WCH + t * 2048);               \
+            const f16x8 b1 = *reinterpret_cast<const f16x8*>(wb + (PAR) * T64_WCH + t * 2048 + 512);         \
             acc[0] = T64_MFMA(b0, ah, acc[0]);                                                               \
             acc[1] = T64_MFMA(b1, ah, acc[1]);                                                               \
             acc[0] = T64_MFMA(b0, al, acc[0]);                                                               \
             acc[1] = T64_MFMA(b1, al, acc[1]);                                                               \
         }                                                                                                    \
         {   /* skip connection: identity on the centre pixel; chunk C only feeds output block C >> 1 */      \
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(ib_ + ao[4]);                                   \
-            const f16x8 al = *reinterpret_cast<const f16x8*>(ib_ + ao[4] + T64_PLANE);                       \
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(ap[4] + (PAR) * T64_INB);                       \
+            const f16x8 al = *reinterpret_cast<const f16x8*>(ap[4] + (PAR) * T64_INB + T64_PLANE);           \
             acc[(C) >> 1] = T64_MFMA(idf[(C) & 1], ah, acc[(C) >> 1]);                                       \
             acc[(C) >> 1] = T64_MFMA(idf[(C) & 1], al, acc[(C) >> 1]);                                       \
         }                                                                                                    \
     }
-    // end of a step: everything this wave issued BEFORE this step's halo pieces (the halo chunk of the next step, the weight chunk
-    // of the next step, the stores of the last epilogue) must be complete; the halo pieces of this step (INFLIGHT: were any issued)
-    // stay in flight across the barrier.  vmcnt counts in issue order on gfx9, and every wave knows how many pieces it issued.
-    // ST: the 8 stores of this wave's epilogue were issued after the halo pieces and may stay in flight too (only when the whole row
-    // of the tile lies inside the tensor: then every store instruction is known to have been issued)
-#define T64_SYNC(INFLIGHT, ST)                                                                               \
+    // end of a step: this wave's LDS-DMA pieces have landed (a raw s_barrier: __syncthreads() would add nothing but its own vmcnt(0))
+#define T64_SYNC()                                                                                           \
     {                                                                                                        \
         T64_STAMP(0)                                                                                         \
-        if (!(TAG & T64_NOVMWAIT)) {                                                                         \
-            if (!(INFLIGHT) || (TAG & (T64_NODMA | T64_NOMATH | T64_NOSTORE))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-            else if (ST) { if (three) asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); } \
-            else if (three) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                 \
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                            \
-        }                                                                                                    \
+        if (!(TAG & T64_NOVMWAIT)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
         T64_STAMP(1)                                                                                         \
         __builtin_amdgcn_s_barrier();                                                                        \
         T64_STAMP(2)                                                                                         \
@@ -224,53 +199,50 @@ __global__ __launch_bounds__(1024) void conv_t64_kernel(T64Args a) {
         }                                                                                                    \
     }
 
-    // ---- prologue: bias / slopes, weight chunk 0, halo chunks 0 and 1 of the first tile
-    if (r == 8 && lane < 32 && !(TAG & T64_NODMA)) t64_glds16(a.img + T64_WB + lane * 16, lds + T64_LDS_BS);
-    if (TAG & T64_NODMA) { for (int i = tid; i < T64_LDS / 16; i += 1024) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // ---- prologue: bias / slopes, weight chunk 0, halo chunk 0 of the first tile
+    if (r == 7 && lane < 32 && !(TAG & T64_NODMA)) t64_glds16(a.img + T64_WB + lane * 16, lds + T64_LDS_BS);
+    if (TAG & T64_NODMA) { for (int i = tid; i < T64_LDS / 16; i += T64_NTHR) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     T64_DMA_W(0, 0)
-    if (mine > 0) { T64_DMA_IN(tb, 0, 0) T64_DMA_IN(tb, 1, T64_INB) }
-    T64_SYNC(false, false)
+    if (mine > 0) T64_DMA_IN(tb, 0, 0)
+    T64_SYNC()
 
-    unsigned ib = 0;                                                     // ring offset of the current step's halo chunk (0, INB, 2 INB)
-#define T64_NEXT(X) ((X) >= 2 * T64_INB ? (X) - 2 * T64_INB : (X) + T64_INB)
     for (int k = 0; k < mine; k++) {
         const int Tn = slot + (k + 1) * nwg;
         const bool more = k + 1 < mine;
         int oy0n = 0, ox0n = 0;
         unsigned tbn = 0;
         if (more) { const int ty = Tn / a.tiles_x; oy0n = ty * T64_TH; ox0n = (Tn - ty * a.tiles_x) * 32; tbn = (unsigned)(oy0n * a.pitch + ox0n) * 32u; }
-        const unsigned ib1 = T64_NEXT(ib), ib2 = T64_NEXT(ib1);         // ring slots of chunks 1 / 2 of this tile; chunk 3 -> ib, next tile's chunk 0 -> ib1 ...
 
-        // chunk 0 (ring ib): sends chunk 2 -> ib2, weights 1
+        T64_DMA_IN(tb, 1, 1)
         T64_DMA_W(1, 1)
+        if (k > 0) T64_EPILOGUE(poy0, pox0)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[n][q] = 0.f;
-        T64_TAPS(0, ib, true, tb, 2, ib2)
-        T64_SYNC(true, false)
-        // chunk 1 (ring ib1): sends chunk 3 -> ib, weights 2
-        T64_DMA_W(2, 0)
-        T64_TAPS(1, ib1, true, tb, 3, ib)
-        T64_SYNC(true, false)
-        // chunk 2 (ring ib2): sends the next tile's chunk 0 -> ib1, weights 3
-        T64_DMA_W(3, 1)
-        T64_TAPS(2, ib2, more, tbn, 0, ib1)
-        T64_SYNC(more, false)
-        // chunk 3 (ring ib): sends the next tile's chunk 1 -> ib2, weights 0; then this wave's epilogue straight after its own last
-        // MFMA - the waves finish their matrix work at different times, so most epilogues run under other waves' matrix work
-        if (more) T64_DMA_W(0, 0)
-        T64_TAPS(3, ib, more, tbn, 1, ib2)
-        T64_EPILOGUE(oy0, ox0)
-        T64_SYNC(more, oy0 + r < a.H && ox0 + 32 <= a.W)
+        T64_TAPS(0, 0)
+        T64_SYNC()
 
+        T64_DMA_IN(tb, 2, 0)
+        T64_DMA_W(2, 0)
+        T64_TAPS(1, 1)
+        T64_SYNC()
+
+        T64_DMA_IN(tb, 3, 1)
+        T64_DMA_W(3, 1)
+        T64_TAPS(2, 0)
+        T64_SYNC()
+
+        if (more) { T64_DMA_IN(tbn, 0, 0) T64_DMA_W(0, 0) }
+        T64_TAPS(3, 1)
+        T64_SYNC()
+
+        poy0 = oy0; pox0 = ox0;
         oy0 = oy0n; ox0 = ox0n; tb = tbn;
-        ib = ib1;                                                        // the next tile's chunk 0 went to ib1
     }
-#undef T64_NEXT
+    if (mine > 0) T64_EPILOGUE(poy0, pox0)
 #undef T64_STAMP
 #undef T64_DMA_IN
-#undef T64_DMA_PIECE
 #undef T64_DMA_W
 #undef T64_MFMA
 #undef T64_TAPS

@@ -612,7 +612,7 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
     return 0;
 }
 
-// S16 tensor geometry for an H x W pixel grid (conv_t64.h): 16 x 32 tiles, one pixel of zero border on every side of every plane
+// S16 tensor geometry for an H x W pixel grid (conv_t64.h): T64_TH x 32 tiles, one pixel of zero border on every side of every plane
 struct S16Geom {
     int tiles_x, tiles_y, pitch, rows;
     S16Geom(int H, int W) : tiles_x((W + 31) / 32), tiles_y((H + T64_TH - 1) / T64_TH), pitch(tiles_x * 32 + 2), rows(tiles_y * T64_TH + 2) {}
@@ -620,7 +620,7 @@ struct S16Geom {
     size_t bytes(int C) const { return (size_t)plane() * (C / 8); }
 };
 
-// one 64 -> 64 residual trunk convolution, S16 in / S16 out, persistent workgroups (one per CU)
+// one 64 -> 64 residual trunk convolution, S16 in / S16 out, persistent workgroups (T64_WG_PER_CU per CU)
 static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st) {
     if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_t64 image");
     int dev = 0; (void)hipGetDevice(&dev);
@@ -640,8 +640,8 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
     const S16Geom G(H, W);
     T64Args a;
     a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y;
-    const int nwg = std::min(cus, (a.ntiles + 7) / 8 * 8);                // one resident workgroup per CU (LDS: 151 KB)
-    hipLaunchKernelGGL(conv_t64_kernel<3>, dim3(nwg), dim3(1024), T64_LDS, st, a);
+    const int nwg = std::min(T64_WG_PER_CU * cus, (a.ntiles + 7) / 8 * 8);      // all workgroups resident at once
+    hipLaunchKernelGGL(conv_t64_kernel<3>, dim3(nwg), dim3(T64_NTHR), T64_LDS, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_t64 launch: ") + hipGetErrorString(e));
     return 0;

@@ -13,9 +13,7 @@ h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (544, 960)
 NOSTORE, NODMA, NOMATH, NOVMWAIT, STAMPS = 0x100, 0x200, 0x400, 0x800, 0x1000
 for rep in range(2):
     for name, v in (("full", 0), ("no stores (loads + math)", NOSTORE), ("no DMA (math + stores)", NODMA), ("no DMA, no stores (math only)", NODMA | NOSTORE), ("no math", NOMATH),
-                    ("no math, no stores (loads only)", NOMATH | NOSTORE), ("no math, no DMA (stores only)", NOMATH | NODMA), ("no vmcnt wait", NOVMWAIT),
-                    ("loads + MFMAs on registers (no LDS reads)", 0x2000 | NOSTORE), ("MFMAs on registers only", 0x2000 | NOSTORE | NODMA),
-                    ("loads + LDS fragment reads (no MFMA)", 0x4000 | NOSTORE), ("LDS fragment reads only", 0x4000 | NOSTORE | NODMA)):
+                    ("no math, no stores (loads only)", NOMATH | NOSTORE), ("no math, no DMA (stores only)", NOMATH | NODMA), ("no vmcnt wait", NOVMWAIT)):
         ms = ctypes.c_float()
         rc = L.rife_hip_bench_t64(0, h, w, v, 20, ctypes.byref(ms))
         print("%dx%d %-44s rc=%d %.1f us" % (h, w, name, rc, ms.value * 1e3), flush=True)
@@ -26,24 +24,25 @@ print("stamped launch rc=%d %.1f us" % (rc, ms.value * 1e3))
 raw = open("gpurun_out/t64_stamps.bin", "rb").read()
 n = len(raw) // 8
 st = struct.unpack("<%dq" % n, raw)
-nwg = n // (16 * 32 * 4)
-def S(b, wv, s, k): return st[((b * 16 + wv) * 32 + s) * 4 + k]
+NW = 8
+nwg = n // (NW * 32 * 4)
+def S(b, wv, s, k): return st[((b * NW + wv) * 32 + s) * 4 + k]
 print("per step, median over %d workgroups [cycles since the workgroup's previous barrier release (= max over waves of stamp 2)]" % nwg)
 print("columns per wave class: start of MFMAs, end of MFMAs, DMA landed, barrier passed")
 for s in range(1, 20):
     rows = {}
     for b in range(nwg):
-        prev = [S(b, wv, s - 1, 2) for wv in range(16)]
+        prev = [S(b, wv, s - 1, 2) for wv in range(NW)]
         if not all(prev) or not S(b, 0, s, 2):
             continue
         t0 = max(prev)
-        for wv in range(16):
+        for wv in range(NW):
             if S(b, wv, s, 0):
                 rows.setdefault(wv, []).append([S(b, wv, s, k) - t0 for k in (3, 0, 1, 2)])
     if not rows:
         continue
     line = "step %2d " % s
-    for wv in (0, 4, 8, 12, 15):
+    for wv in (0, 2, 4, 6, 7):
         if wv in rows:
             med = [int(statistics.median(x[k] for x in rows[wv])) for k in range(4)]
             line += "| w%-2d %5d %5d %5d %5d " % (wv, med[0], med[1], med[2], med[3])
