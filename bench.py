@@ -2,7 +2,10 @@
 """Throughput of the RIFE hot path (`RIFE::process`, rife-v4.6) on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p] [--streams S]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: either launched as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+    (RANK / LOCAL_RANK / WORLD_SIZE come from the launcher) or plainly as `python bench.py --gpus N`, which re-executes
+    itself under that launcher on 127.0.0.1.  The communicator size must equal --gpus (checked; printed as `rccl_ranks`).
+    --dry-run: launcher / sharding / barrier / JSON plumbing on CPU (gloo), no HIP work: what the CPU tests exercise.
 
 One "step" = one frame pair (two resident u8 RGB frames -> one interpolated frame) through
 `rife_hip_process_device`, per rank.  Frame pairs shard embarrassingly (the reference runs one RIFE replica
@@ -33,36 +36,58 @@ WORKLOADS = {
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense v_mfma_f32_32x32x2_f32 peak
 F16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 HBM_PEAK_TBPS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak
-# dominant kernel per family: (profile class, kernel symbol, channels C of the C->C 3x3 trunk conv, MFMA work factor of the
-# split-f16 scheme = 2 MFMAs per product (+ the identity tap of the folded skip connection for v4: 10/9))
-DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_h2b_kernel<2,10,3,8> (IFNet block-3 trunk: 3x3 conv 64->64 + skip + LeakyReLU, split-f16)", 64, 2.0 * 10 / 9),
+# dominant kernel per family: (profile class, kernel symbol, channels C of the C->C 3x3 trunk conv, MFMA instructions issued per
+# algorithmic product: 2 for the split-f16 scheme (hi and lo) x the identity tap of the folded skip connection)
+DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_t64_kernel<3> (IFNet block-3 trunk: 3x3 conv 64->64 + skip + LeakyReLU; split-f16 MFMA, S16 {hi, lo} tensors)", 64, 2.0 * 38 / 36),
             "rife-v2.3": ("v2_flow_trunk_b3", "conv_h2_kernel<3,9,0> (IFNet block-3 trunk: 3x3 conv 96->96 + PReLU, split-f16)", 96, 2.0)}
 
 
 def roofline_of(dom, family, w, h, f32_mode):
     """Roofline object for the dominant kernel from the live HIP-event timing of its launches.
-    Algorithmic bytes per launch: fp32 NHWC input + output of the C->C trunk conv at 1/4 of the padded
-    resolution + weights; algorithmic flops = 2*C*C*9 per output pixel."""
+
+    Two byte models per launch, both reported:
+      * `bytes_per_launch` = ALGORITHMIC bytes on SURVEY.md 8(d) / App. E-2's basis: fp16 input + fp16 output of the C->C trunk conv
+        at 1/4 of the padded resolution + fp16 weights (4K block 3: 133.8 MB).  `achieved` and `frac` use these.
+      * `bytes_per_launch_stored` = what the kernel really moves: activations are stored as {hi, lo} f16 pairs (4 B per element, the
+        fp32-equivalent precision the <= 1 LSB bar needs) -> twice the bytes; `frac_stored_bytes` uses these.
+    Algorithmic flops = 2*C*C*9 per output pixel (38.50 GFLOP at 4K); the split scheme issues 2 x 38/36 as many MFMA flops."""
     cls, name, C, mfma_factor = DOMINANT[family]
     if not dom["launches"]:
         return None
     wp, hp = (w + 31) // 32 * 32, (h + 31) // 32 * 32
     pix = (hp // 4) * (wp // 4)
-    bytes_launch = 2.0 * pix * C * 4 + C * C * 9 * 2
+    bytes_alg = 2.0 * pix * C * 2 + C * C * 9 * 2
+    bytes_stored = 2.0 * pix * C * 4 + C * C * 9 * 2
     flops_launch = dom["flops"] / dom["launches"]
     avg_ms = dom["ms"] / dom["launches"]
     tflops = flops_launch / (avg_ms * 1e-3) / 1e12
-    tbps = bytes_launch / (avg_ms * 1e-3) / 1e12
+    tbps = bytes_alg / (avg_ms * 1e-3) / 1e12
+    tbps_stored = bytes_stored / (avg_ms * 1e-3) / 1e12
     if f32_mode:
         return {"bound": "mfma", "kernel": name.replace("split-f16", "fp32 MFMA"), "achieved": round(tflops, 2), "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(tflops / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                "launches": dom["launches"], "flops_per_launch": flops_launch, "bytes_per_launch": bytes_launch}
-    # split-f16: arithmetic intensity 144-216 flop/B puts the HBM roof (8 TB/s) and the effective matrix roof
-    # (2.5 PF / mfma_factor) within a few % of each other; report against HBM (the SURVEY's fused-minimum roofline is HBM)
+                "launches": dom["launches"], "flops_per_launch": flops_launch, "bytes_per_launch": bytes_alg}
     return {"bound": "hbm", "kernel": name, "achieved": round(tbps * 1e3, 1), "peak": HBM_PEAK_TBPS * 1e3, "unit": "GB/s",
-            "frac": round(tbps / HBM_PEAK_TBPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
-            "flops_per_launch": flops_launch, "bytes_per_launch": bytes_launch,
-            "algorithmic_tflops": round(tflops, 1), "mfma_frac_of_f16_peak": round(tflops * mfma_factor / F16_MFMA_PEAK_TFLOPS, 4)}
+            "frac": round(tbps / HBM_PEAK_TBPS, 4), "frac_survey_basis": round(tbps / HBM_PEAK_TBPS, 4), "traffic": None,
+            "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
+            "flops_per_launch": flops_launch, "bytes_per_launch": bytes_alg, "bytes_basis": "algorithmic: fp16 in + fp16 out + fp16 weights (SURVEY 8(d), App. E-2)",
+            "bytes_per_launch_stored": bytes_stored, "achieved_stored_GBps": round(tbps_stored * 1e3, 1), "frac_stored_bytes": round(tbps_stored / HBM_PEAK_TBPS, 4),
+            "algorithmic_tflops": round(tflops, 1), "mfma_frac_survey_basis": round(tflops / F16_MFMA_PEAK_TFLOPS, 4),
+            "mfma_frac_issued": round(tflops * mfma_factor / F16_MFMA_PEAK_TFLOPS, 4)}
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def percentiles(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    pick = lambda q: xs[min(n - 1, max(0, int(round(q * (n - 1)))))]
+    return {"n": n, "median": round(pick(0.5), 3), "p10": round(pick(0.1), 3), "p90": round(pick(0.9), 3), "min": round(xs[0], 3), "max": round(xs[-1], 3)}
 
 
 def main():
@@ -74,20 +99,39 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="frame pairs in flight per GPU in the timed region (the reference's default: 2 proc threads per GPU, -j 1:2:2)")
     ap.add_argument("--no-extra", action="store_true", help="skip the second region (1 pair in flight, clean per-launch kernel timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive legs (rife_hip_process from pageable host buffers)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU plumbing check (gloo): launcher, sharding, barrier, MAX over ranks, JSON; no HIP work")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s); the two must agree (n_gpus is the communicator size)" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d device(s) visible)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dist = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        rccl_ranks = dist.get_world_size()
 
     amd = importlib.import_module("rife-ncnn-vulkan_amd")
     from tools import gen_frames, gen_models
@@ -145,6 +189,45 @@ def main():
     # 4K and 20 % at 1080p, so they are kept out of it) ...
     elapsed = sh.timed_steps(lambda i: run_steps(i, args.steps), 1, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
                              make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+    # the same K-step region repeated (>= 50 pairs, median / p10 / p90): `value` stays the FIRST region, exactly K steps
+    reps = max(3, -(-150 // max(1, args.steps)))
+    region_fps = [world * args.steps / elapsed]
+    for _ in range(reps - 1):
+        el = sh.timed_steps(lambda i: run_steps(i, args.steps), 1, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
+                            make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+        region_fps.append(world * args.steps / el)
+    # PCIe-inclusive legs: the boundary call the reference CLI makes (RIFE::process on host frames: H2D x2 + pass + D2H inside the
+    # call, src/rife.cpp:2522-2530, 3176-3186) from pageable host memory, 1 and 2 caller threads (the reference's default -j 1:2:2)
+    host = None
+    if not args.no_host_path and not tta:
+        host = {}
+        hframes = [f.cpu().numpy() for f in frames]
+        houts = [np.empty((h, w, 3), np.uint8) for _ in range(2)]
+
+        def host_step(i, slot):
+            eng.process(hframes[i % nfr], hframes[(i + 1) % nfr], timesteps[i % len(timesteps)], outimage=houts[slot])
+
+        def host_run(nthreads):
+            def region(_):
+                if nthreads == 1:
+                    for i in range(args.steps):
+                        host_step(i, 0)
+                    return
+
+                def worker(s):
+                    torch.cuda.set_device(local)
+                    for i in range(args.steps):
+                        if i % nthreads == s:
+                            host_step(i, s)
+                th = [threading.Thread(target=worker, args=(s,)) for s in range(nthreads)]
+                [t.start() for t in th]
+                [t.join() for t in th]
+            for i in range(3):
+                host_step(i, 0)
+            return sh.timed_steps(region, 1, dist=dist, device_sync=torch.cuda.synchronize,
+                                  make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+        for nt in (1, 2):
+            host["caller_threads_%d" % nt] = round(world * args.steps / host_run(nt), 3)
     # ... and the same K steps again with HIP events around every launch on its stream (`roofline_in_timed_region`)
     sh.barrier(dist, torch.cuda.synchronize)
     eng.profile_enable(True)
@@ -181,7 +264,7 @@ def main():
             roof = roofline_of(prof1.get(DOMINANT[family][0], dict(ms=0.0, launches=0, flops=0.0)), family, w, h, f32_mode)
             if roof is not None:
                 roof["measured_in"] = "HIP events on the launch stream over a region of the same %d steps with 1 pair in flight (non-overlapping launches); roofline_in_timed_region = the timed region repeated with the events on" % args.steps
-        traffic_file = os.path.join(ROOT, "profiles", "r1", "pmc_%s.json" % args.workload)
+        traffic_file = os.path.join(ROOT, "profiles", "r2", "pmc_%s.json" % args.workload)
         if roof is not None and os.path.exists(traffic_file):
             tf = json.load(open(traffic_file))                   # from the committed rocprofv3 --pmc passes (not live)
             roof["traffic"] = tf["hbm_bytes_per_launch"]
@@ -192,15 +275,18 @@ def main():
         fps = world * args.steps / elapsed
         line = {
             "metric": "interpolated frames/sec (%s, %dx%d%s)" % (family, w, h, " -x -z" if tta else ""), "value": round(fps, 3), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if f32_mode else "f16x2-split MFMA + f32 accumulate (fp32-equivalent; activations stored f32)", "data": "synthetic",
+            "dtype": "f32" if f32_mode else "f16x2-split MFMA + f32 accumulate (fp32-equivalent; activations stored f32 or as {hi, lo} f16 pairs)", "data": "synthetic",
             "config": {"workload": "%s %dx%d%s frame pairs resident in HBM, timestep sweep %s, synthetic seeded weights" % (family, w, h, " -x -z (TTA)" if tta else "", timesteps),
                        "pairs_in_flight_per_gpu": nstreams, "parallelism": "frame pairs sharded over ranks, no data-path collective"},
             "roofline": roof,
             "roofline_in_timed_region": roof_timed if prof1 is not None else None,
             "cpu_baseline": cpu,
-            "extra": {"frames_per_s_same_region_with_per_launch_events": round(world * args.steps / elapsed_instr, 3),
+            "extra": {"frames_per_s_repeated_regions": dict(percentiles(region_fps), pairs_measured=reps * args.steps * world,
+                                                            note="the K-step timed region repeated %d times back to back; `value` is the first" % reps),
+                      "frames_per_s_host_buffers": None if host is None else dict(host, note="rife_hip_process from pageable host memory: 2 x H2D + pass + D2H inside the call (PCIe-inclusive; never `value`)"),
+                      "frames_per_s_same_region_with_per_launch_events": round(world * args.steps / elapsed_instr, 3),
                       "frames_per_s_with_1_pair_in_flight": None if fps1 is None else round(fps1, 3), "kernel_ms_per_pair": round(all_ms / args.steps, 4), "conv_ms_per_pair": round(conv_ms / args.steps, 4),
                       "conv_tflops_overall": round(gflop_pair / max(conv_ms / args.steps, 1e-9), 2),
                       "frac_of_fused_hbm_roofline_e2e": None if roofline_ms is None else round(roofline_ms / (elapsed / args.steps * 1e3), 5),
@@ -210,6 +296,32 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dry_run(args, rank, world):
+    """Everything of the N-rank bench but the GPU: rendezvous (gloo), pair -> rank sharding, barrier + MAX timing, one JSON line."""
+    import importlib as il
+    import torch
+    sh = il.import_module("rife-ncnn-vulkan_amd.sharding")
+    dist = None
+    ranks = 1
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ranks = dist.get_world_size()
+    mine = sh.shard_pairs(args.steps * world, rank, world)            # weak scaling: K pairs per rank
+    assert len(mine) == args.steps
+    elapsed = sh.timed_steps(lambda i: time.sleep(0.001), args.steps, first_index=args.warmup, dist=dist)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run: launcher / sharding / barrier plumbing (no GPU work)", "value": round(world * args.steps / elapsed, 3), "unit": "steps/s",
+                          "n_gpus": world, "rccl_ranks": ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run",
+                          "config": {"workload": "dry run on CPU (gloo)", "parallelism": "frame pairs sharded over ranks, no data-path collective"}}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def cpu_baseline(modeldir, family, pixels, passes, size=None):

@@ -95,6 +95,10 @@ int rife_hip_v4_flow_dims(const rife_hip_t* r, int w, int h, int fi, int* channe
  * kernel, RIFE_HIP_EMODEL with the offending layer in rife_hip_last_error() otherwise.  The v1 family (models/rife, rife-HD,
  * rife-UHD, rife-anime) is executed from its .param layer by layer, like ncnn::Net does for every model (src/rife.cpp:112-121). */
 int rife_hip_graph_check(const char* param_path_without_extension);
+/* Structural hash of the sub-graph that produces blob `blob` of an ncnn .param file (layer types, parameters, topology; no names,
+ * no weights) - what rife_hip_load() compares with the compiled-in constants of csrc/model_hashes.h to prove that a model directory
+ * holds the graph a fused schedule was written for (the reference's models/rife-v4.6/flownet.param etc.).  CPU only. */
+int rife_hip_param_hash(const char* param_path, const char* blob, uint64_t* hash_out);
 
 /* ---- single-kernel entry points for per-kernel parity tests (host arrays, planar CHW fp32 like ncnn::Mat) --- */
 /* 3x3 conv, pad 1, stride 1|2, + bias, optional residual add (same shape as output), per-channel negative slope

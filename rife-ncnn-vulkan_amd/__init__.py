@@ -24,7 +24,7 @@ C_ABI_SYMBOLS = [
     "rife_hip_device_count", "rife_hip_create", "rife_hip_destroy", "rife_hip_load", "rife_hip_process",
     "rife_hip_process_device", "rife_hip_process_batch", "rife_hip_frame_upload", "rife_hip_process_frames", "rife_hip_frame_release",
     "rife_hip_last_error", "rife_hip_profile_enable", "rife_hip_profile_read",
-    "rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_graph_check", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
+    "rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_graph_check", "rife_hip_param_hash", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
 ]
 
 
@@ -143,6 +143,8 @@ class RIFE:
             raise ValueError("frames must be (h, w, 3) uint8 arrays of equal size")
         h, w, _ = a.shape
         out = outimage if outimage is not None else np.empty_like(a)
+        if not isinstance(out, np.ndarray) or out.shape != a.shape or out.dtype != np.uint8 or not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError("outimage must be a writable contiguous (h, w, 3) uint8 array of the frames' size")
         _check(lib().rife_hip_process(self._h, _p(a), _p(b), w, h, float(timestep), _p(out)), "process")
         return out
 

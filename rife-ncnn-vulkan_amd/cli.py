@@ -254,10 +254,13 @@ def main(argv=None):
             if item is END:
                 return
             t, a, b = item
-            if t[2] == 0.0 or t[2] == 1.0:                      # rife.cpp:2470-2480: an input frame, unchanged
-                tosave.put((t, a.px if t[2] == 0.0 else b.px))
-            else:
-                tosave.put((t, r.process_frames(a.on(r), b.on(r), t[2])))
+            try:
+                if t[2] == 0.0 or t[2] == 1.0:                  # rife.cpp:2470-2480: an input frame, unchanged
+                    tosave.put((t, a.px if t[2] == 0.0 else b.px))
+                else:
+                    tosave.put((t, r.process_frames(a.on(r), b.on(r), t[2])))
+            except Exception as e:                              # log and go on like csrc/main.cpp: a dead proc thread would stall the loaders on the bounded queue
+                sys.stderr.write("process %s failed: %s\n" % (t[3], e))
 
     def save():
         while True:

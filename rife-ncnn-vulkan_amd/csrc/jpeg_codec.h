@@ -351,6 +351,9 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
                 i += 17 + total;
             }
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+            // one frame header per image: a second SOF after the geometry / coefficient store have been set up would re-size w, h, ncomp and
+            // the sampling factors under them (heap overflow in finish(): ADVICE r1)
+            if (have_sof) return fail("duplicate SOF");
             progressive = m == 0xC2;
             if (n < 6 || s[0] != 8) return fail("only 8-bit samples are supported");
             h = (s[1] << 8) | s[2]; w = (s[3] << 8) | s[4]; ncomp = s[5];
@@ -362,6 +365,8 @@ inline bool decode(const std::vector<unsigned char>& d, int& w, int& h, std::vec
                 if (comp[c].hs < 1 || comp[c].hs > 2 || comp[c].vs < 1 || comp[c].vs > 2 || comp[c].tq > 3) return fail("unsupported sampling factors");
                 hmax = std::max(hmax, comp[c].hs); vmax = std::max(vmax, comp[c].vs);
             }
+            // a single-component scan is never interleaved: its MCU is one block whatever the header's sampling factors say (like libjpeg / stb_image)
+            if (ncomp == 1) { comp[0].hs = comp[0].vs = 1; hmax = vmax = 1; }
             have_sof = true;
         } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             return fail("lossless / hierarchical / arithmetic-coded JPEG is not supported");

@@ -76,7 +76,10 @@ static bool decode_png(const std::vector<unsigned char>& d, int& w, int& h, std:
         const unsigned char* typ = &d[pos + 4];
         if (pos + 12 + (size_t)len > d.size()) return false;
         const unsigned char* body = &d[pos + 8];
-        if (!memcmp(typ, "IHDR", 4)) { w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        if (!memcmp(typ, "IHDR", 4)) {
+            if (len != 13 || pos != 8) return false;          // IHDR is 13 bytes and the first chunk (a short one would be read past its end)
+            w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+        }
         else if (!memcmp(typ, "PLTE", 4)) pal.assign(body, body + len);
         else if (!memcmp(typ, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
         else if (!memcmp(typ, "IEND", 4)) break;

@@ -318,3 +318,73 @@ def test_cpp_cli_decoders_survive_corrupt_files(tmp_path):
             (tmp_path / "t.bin").write_bytes(c)
             p = subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "t.bin"), str(tmp_path / "o.ppm")], capture_output=True, text=True, timeout=30)
             assert p.returncode in (0, 1), (name, k, p.returncode, p.stderr[-200:])
+
+
+def _jpeg_segments(data):
+    """[(marker, start, end)] of the header segments of a JPEG up to and including the first SOS header (start = the 0xFF byte)."""
+    out, i = [], 2
+    while i + 4 <= len(data) and data[i] == 0xFF:
+        m = data[i + 1]
+        n = (data[i + 2] << 8) | data[i + 3]
+        out.append((m, i, i + 2 + n))
+        if m == 0xDA:
+            break
+        i += 2 + n
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(RIFE_HIP), reason="rife-hip is not built")
+def test_cpp_cli_decoders_refuse_crafted_headers(tmp_path):
+    """(1) a second SOF after the first scan of a multi-scan JPEG re-sized w / h / sampling factors under the coefficient
+    store (ASan: heap overflow in finish()): now "duplicate SOF"; (2) an IHDR chunk shorter than 13 bytes was read past its end;
+    (3) a grey JPEG whose header carries 2x2 sampling factors is a non-interleaved scan and must decode like libjpeg decodes it."""
+    import struct
+    import subprocess
+    from PIL import Image
+    from tools import gen_frames
+    a = gen_frames.smooth_pair(96, 64, 5)[0]
+
+    def run(data):
+        (tmp_path / "t.bin").write_bytes(data)
+        return subprocess.run([RIFE_HIP, "--transcode", str(tmp_path / "t.bin"), str(tmp_path / "o.ppm")], capture_output=True, text=True, timeout=30)
+
+    Image.fromarray(a).save(tmp_path / "p.jpg", quality=90, progressive=True)
+    data = (tmp_path / "p.jpg").read_bytes()
+    segs = _jpeg_segments(data)
+    sof = next(s for s in segs if s[0] == 0xC2)
+    sos = next(s for s in segs if s[0] == 0xDA)
+    # entropy-coded data of the first scan ends at the next marker that is not a stuffed 0xFF00 / RSTn
+    j = sos[2]
+    while not (data[j] == 0xFF and data[j + 1] != 0 and not 0xD0 <= data[j + 1] <= 0xD7):
+        j += 1
+    big = bytearray(data[sof[1]:sof[2]])
+    big[5:9] = struct.pack(">HH", 512, 512)                   # enlarge h, w
+    swapped = bytearray(data[sof[1]:sof[2]])
+    swapped[11], swapped[14] = swapped[14], swapped[11]       # swap the sampling factors of components 0 and 1
+    for dup in (bytes(big), bytes(swapped), data[sof[1]:sof[2]]):
+        p = run(data[:j] + dup + data[j:])
+        assert p.returncode == 1 and "duplicate SOF" in (p.stderr + p.stdout), (p.returncode, p.stderr[-200:])
+    assert run(data).returncode == 0                          # the unmodified file still decodes
+
+    Image.fromarray(a).save(tmp_path / "a.png")
+    png = (tmp_path / "a.png").read_bytes()
+    short = png[:8] + struct.pack(">I", 5) + b"IHDR" + png[16:21] + b"\0\0\0\0"      # a 5-byte IHDR right before the end of the file
+    assert run(short).returncode == 1
+    late = png[:8] + png[33:45] + png[8:33] + png[45:]       # IHDR not the first chunk
+    assert run(late).returncode in (0, 1)
+
+    g = np.asarray(Image.fromarray(a).convert("L"))
+    Image.fromarray(g).save(tmp_path / "g.jpg", quality=95)
+    gd = bytearray((tmp_path / "g.jpg").read_bytes())
+    gs = next(s for s in _jpeg_segments(bytes(gd)) if s[0] == 0xC0)
+    assert gd[gs[1] + 9] == 1                                  # one component
+    gd[gs[1] + 11] = 0x22                                      # ... now with 2x2 sampling factors in the header
+    p = run(bytes(gd))
+    assert p.returncode == 0, p.stderr[-200:]
+    with open(tmp_path / "o.ppm", "rb") as f:
+        assert f.readline() == b"P6\n"
+        wh = f.readline().split()
+        f.readline()
+        got = np.frombuffer(f.read(), np.uint8).reshape(int(wh[1]), int(wh[0]), 3)
+    want = np.asarray(Image.open(tmp_path / "g.jpg").convert("RGB")).astype(int)
+    assert np.abs(got.astype(int) - want).max() <= 3          # same tolerance as the other JPEG-vs-libjpeg checks

@@ -109,7 +109,8 @@ def test_conv3x3_split_f16_trunk_path_matches_oracle(c, h, w):
 def test_f16_mfma_keeps_subnormals():
     """conv_h2*_kernel relies on the matrix pipe preserving f16 subnormal inputs (lo = f16(a - hi) is often subnormal)."""
     import ctypes
-    L = amd.lib()
+    from tools import benchlib                  # hardware probes live in the bench build, not in the product library
+    L = benchlib.lib()
     out = ctypes.c_float()
     assert L.rife_hip_probe_f16_denorm(0, ctypes.byref(out)) == 0
     assert out.value == 16 * 2.0 ** -20

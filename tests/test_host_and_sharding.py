@@ -4,6 +4,7 @@ import ctypes
 import importlib
 import os
 import re
+import subprocess
 import sys
 
 import numpy as np
@@ -21,6 +22,11 @@ def test_c_abi_exports_every_declared_symbol():
     L = ctypes.CDLL(amd.LIB_PATH)
     for s in declared:
         assert hasattr(L, s), s
+    # ... and nothing else: no bench / probe / ablation entry point may ride in the product library
+    nm = subprocess.run(["nm", "-D", "--defined-only", amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\b(rife_hip_[A-Za-z0-9_]+)$", nm, flags=re.M)))
+    assert exported == declared, sorted(set(exported) ^ set(declared))
+    assert "bench" not in " ".join(exported) and "probe" not in " ".join(exported)
 
 
 def test_no_cpu_fallback_without_a_device():
@@ -99,6 +105,32 @@ def build_shim_demo(outdir):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(pkg, "csrc"), os.path.join(ROOT, "tests", "cpp", "shim_demo.cpp"),
                            "-o", exe, "-L" + pkg, "-lrife", "-lrife_hip", "-Wl,-rpath," + pkg])
     return exe
+
+
+def _bench(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, timeout=240, env=e)
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher around it) must run 2 ranks and say so: n_gpus = rccl_ranks = 2 (the flag was dead)."""
+    import json
+    r = _bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 4 and d["scaling"] == "weak"
+    r1 = _bench("--steps", "3", "--warmup", "0", "--dry-run")
+    assert r1.returncode == 0 and json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_bench_refuses_a_launcher_world_that_differs_from_gpus():
+    r = _bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
 
 
 def test_cpp_class_shim_compiles_and_fails_cleanly_without_gpu(tmp_path):

@@ -2,7 +2,8 @@
 import ctypes, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
-L = amd.lib()
+from tools import benchlib
+L = benchlib.lib()
 L.rife_hip_bench_conv8.argtypes = [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_float)]
 h, w, c = 544, 960, 64
 gf = 2.0 * c * c * 9 * h * w / 1e9

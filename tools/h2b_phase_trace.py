@@ -10,7 +10,8 @@ if len(sys.argv) > 1:                       # offline: python tools/h2b_phase_tr
     kernel_us = float(sys.argv[2])
 else:
     amd = importlib.import_module("rife-ncnn-vulkan_amd")
-    L = amd.lib()
+    from tools import benchlib
+    L = benchlib.lib()
     L.rife_hip_bench_h2b.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float)]
     ms = ctypes.c_float()
     assert L.rife_hip_bench_h2b(0, 544, 960, 0, 20, ctypes.byref(ms)) == 0

@@ -3,7 +3,8 @@ hi + lo as f16 (today) vs hi as f16 + lo as scaled fp8 vs hi alone.  512 workgro
 import ctypes, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
-L = amd.lib()
+from tools import benchlib
+L = benchlib.lib()
 L.rife_hip_bench_mfma_mix.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p]
 tiles = 16
 out = (ctypes.c_float * 6)()

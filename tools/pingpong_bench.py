@@ -1,7 +1,8 @@
 import ctypes, importlib, os, sys
 sys.path.insert(0, os.getcwd())
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
-L = amd.lib()
+from tools import benchlib
+L = benchlib.lib()
 L.rife_hip_bench_h2b.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float)]
 for rep in range(2):
   for h in (544, 272):

@@ -2,7 +2,8 @@
 import ctypes, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
-L = amd.lib()
+from tools import benchlib
+L = benchlib.lib()
 L.rife_hip_bench_stemf.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float)]
 for name, v in [("full", 0), ("second halo pixel in a second round", 2), ("full", 0), ("second halo pixel in a second round", 2), ("no mfma/epilogue", 1), ("no mfma/epilogue, second round", 3),
                 ("no stores", 16), ("no MFMAs (LDS reads kept)", 32), ("direct-store epilogue", 64), ("64-byte LDS records", 128)]:

@@ -7,7 +7,8 @@ no matrix work / no vmcnt wait, and combinations.  Then one stamped launch: per 
 import ctypes, importlib, os, struct, sys, statistics
 sys.path.insert(0, os.getcwd())
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
-L = amd.lib()
+from tools import benchlib
+L = benchlib.lib()
 L.rife_hip_bench_t64.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float)]
 h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (544, 960)
 NOSTORE, NODMA, NOMATH, NOVMWAIT, STAMPS = 0x100, 0x200, 0x400, 0x800, 0x1000
