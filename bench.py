@@ -182,6 +182,10 @@ def main():
         [t.join() for t in th]
 
     sh = importlib.import_module("rife-ncnn-vulkan_amd.sharding")
+    # untimed: workspace allocation, kernel attributes and clock ramp (the first timed region after only W = 5 warm-up pairs ran 4 % below
+    # the following ones), then the W warm-up steps the contract asks for
+    PREWARM = 12
+    run_steps(0, PREWARM)
     for i in range(args.warmup):
         step(i)
     sh.barrier(dist, torch.cuda.synchronize)
@@ -201,13 +205,17 @@ def main():
     host = None
     if not args.no_host_path and not tta:
         host = {}
-        hframes = [f.cpu().numpy() for f in frames]
-        houts = [np.empty((h, w, 3), np.uint8) for _ in range(2)]
+        pageable = ([f.cpu().numpy() for f in frames], [np.empty((h, w, 3), np.uint8) for _ in range(2)])
+        pinned = ([amd.pinned_empty((h, w, 3)) for _ in frames], [amd.pinned_empty((h, w, 3)) for _ in range(2)])     # rife_hip_host_alloc
+        for dst, src in zip(pinned[0], pageable[0]):
+            dst[...] = src
 
-        def host_step(i, slot):
-            eng.process(hframes[i % nfr], hframes[(i + 1) % nfr], timesteps[i % len(timesteps)], outimage=houts[slot])
+        def host_run(bufs, nthreads):
+            hin, hout = bufs
 
-        def host_run(nthreads):
+            def host_step(i, slot):
+                eng.process(hin[i % nfr], hin[(i + 1) % nfr], timesteps[i % len(timesteps)], outimage=hout[slot])
+
             def region(_):
                 if nthreads == 1:
                     for i in range(args.steps):
@@ -226,8 +234,9 @@ def main():
                 host_step(i, 0)
             return sh.timed_steps(region, 1, dist=dist, device_sync=torch.cuda.synchronize,
                                   make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
-        for nt in (1, 2):
-            host["caller_threads_%d" % nt] = round(world * args.steps / host_run(nt), 3)
+        for kind, bufs in (("pageable", pageable), ("page_locked", pinned)):
+            for nt in (1, 2, 3):
+                host["%s_caller_threads_%d" % (kind, nt)] = round(world * args.steps / host_run(bufs, nt), 3)
     # ... and the same K steps again with HIP events around every launch on its stream (`roofline_in_timed_region`)
     sh.barrier(dist, torch.cuda.synchronize)
     eng.profile_enable(True)
@@ -279,13 +288,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if f32_mode else "f16x2-split MFMA + f32 accumulate (fp32-equivalent; activations stored f32 or as {hi, lo} f16 pairs)", "data": "synthetic",
             "config": {"workload": "%s %dx%d%s frame pairs resident in HBM, timestep sweep %s, synthetic seeded weights" % (family, w, h, " -x -z (TTA)" if tta else "", timesteps),
-                       "pairs_in_flight_per_gpu": nstreams, "parallelism": "frame pairs sharded over ranks, no data-path collective"},
+                       "pairs_in_flight_per_gpu": nstreams, "untimed_prewarm_pairs": PREWARM, "parallelism": "frame pairs sharded over ranks, no data-path collective"},
             "roofline": roof,
             "roofline_in_timed_region": roof_timed if prof1 is not None else None,
             "cpu_baseline": cpu,
             "extra": {"frames_per_s_repeated_regions": dict(percentiles(region_fps), pairs_measured=reps * args.steps * world,
                                                             note="the K-step timed region repeated %d times back to back; `value` is the first" % reps),
-                      "frames_per_s_host_buffers": None if host is None else dict(host, note="rife_hip_process from pageable host memory: 2 x H2D + pass + D2H inside the call (PCIe-inclusive; never `value`)"),
+                      "frames_per_s_host_buffers": None if host is None else dict(host, note="rife_hip_process on host frames: 2 x H2D + pass + D2H inside the call (PCIe-inclusive; never `value`); page_locked = frames from rife_hip_host_alloc"),
                       "frames_per_s_same_region_with_per_launch_events": round(world * args.steps / elapsed_instr, 3),
                       "frames_per_s_with_1_pair_in_flight": None if fps1 is None else round(fps1, 3), "kernel_ms_per_pair": round(all_ms / args.steps, 4), "conv_ms_per_pair": round(conv_ms / args.steps, 4),
                       "conv_tflops_overall": round(gflop_pair / max(conv_ms / args.steps, 1e-9), 2),

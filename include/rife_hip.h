@@ -100,6 +100,18 @@ int rife_hip_graph_check(const char* param_path_without_extension);
  * holds the graph a fused schedule was written for (the reference's models/rife-v4.6/flownet.param etc.).  CPU only. */
 int rife_hip_param_hash(const char* param_path, const char* blob, uint64_t* hash_out);
 
+/* ---- page-locked host frames (optional) -------------------------------------------------------------------------------
+ * rife_hip_process() takes any host pointer, like RIFE::process() takes any ncnn::Mat (src/main.cpp:187, 332).  Copies from / to
+ * pageable memory are staged by the HIP runtime and hold the calling thread for their whole duration; from page-locked memory they
+ * are asynchronous DMA at PCIe rate, so that with two caller threads (the reference's default -j 1:2:2) one pair's copies run
+ * under the other pair's kernels.  A caller without HIP headers can get such memory here: allocate frames with
+ * rife_hip_host_alloc() (returns NULL on failure), or page-lock buffers it already owns for as long as it keeps them
+ * (rife_hip_host_register / rife_hip_host_unregister; the range must stay mapped in between).  Pixels are identical either way. */
+void* rife_hip_host_alloc(size_t bytes);
+void rife_hip_host_free(void* p);
+int rife_hip_host_register(void* p, size_t bytes);
+int rife_hip_host_unregister(void* p);
+
 /* ---- single-kernel entry points for per-kernel parity tests (host arrays, planar CHW fp32 like ncnn::Mat) --- */
 /* 3x3 conv, pad 1, stride 1|2, + bias, optional residual add (same shape as output), per-channel negative slope
  * (1.0 = none, 0.2 = LeakyReLU(0.2), PReLU slopes otherwise): ncnn Convolution (+BinaryOp add +ReLU/PReLU). */

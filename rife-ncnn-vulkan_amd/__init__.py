@@ -24,6 +24,7 @@ C_ABI_SYMBOLS = [
     "rife_hip_device_count", "rife_hip_create", "rife_hip_destroy", "rife_hip_load", "rife_hip_process",
     "rife_hip_process_device", "rife_hip_process_batch", "rife_hip_frame_upload", "rife_hip_process_frames", "rife_hip_frame_release",
     "rife_hip_last_error", "rife_hip_profile_enable", "rife_hip_profile_read",
+    "rife_hip_host_alloc", "rife_hip_host_free", "rife_hip_host_register", "rife_hip_host_unregister",
     "rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_graph_check", "rife_hip_param_hash", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
 ]
 
@@ -74,6 +75,12 @@ def lib():
     L.rife_hip_op_conv3x3.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, ci, vp, vp, vp]
     L.rife_hip_op_deconv4x4.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, vp, vp]
     L.rife_hip_op_warp.argtypes = [ci, vp, vp, ci, ci, ci, vp]
+    L.rife_hip_param_hash.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
+    L.rife_hip_host_alloc.restype = vp
+    L.rife_hip_host_alloc.argtypes = [ctypes.c_size_t]
+    L.rife_hip_host_free.argtypes = [vp]
+    L.rife_hip_host_register.argtypes = [vp, ctypes.c_size_t]
+    L.rife_hip_host_unregister.argtypes = [vp]
     _lib = L
     return L
 
@@ -98,6 +105,29 @@ def graph_check(param_base):
 
 def device_count():
     return lib().rife_hip_device_count()
+
+
+class _PinnedOwner:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        if self.ptr and _lib is not None:
+            _lib.rife_hip_host_free(self.ptr)
+        self.ptr = None
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """A numpy array in page-locked host memory (rife_hip_host_alloc): copies to / from it are asynchronous DMA at PCIe rate.
+    The memory is released when the last array that views it is collected."""
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = lib().rife_hip_host_alloc(max(1, nbytes))
+    if not ptr:
+        raise RifeError("rife_hip_host_alloc(%d) failed: %s" % (nbytes, lib().rife_hip_last_error().decode()))
+    buf = (ctypes.c_uint8 * max(1, nbytes)).from_address(ptr)
+    buf._owner = _PinnedOwner(ptr)        # arr.base -> buf -> owner: freed when the last view is collected
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 class Frame:

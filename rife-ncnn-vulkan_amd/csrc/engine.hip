@@ -1999,7 +1999,9 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     for (int i = 0; i < n; i++) if (!in0[i] || !in1[i] || !out[i]) return fail(RIFE_HIP_EINVAL, "null frame pointer");
     if (n == 0) return 0;
     if ((rc = check_device(E->gpuid))) return rc;
-    const int K = std::min(n, 2);                          // measured on MI355X + EPYC 9575F: 2 workers beat 1 and 3 (pageable copies contend)
+    // three workers = three pairs in flight: tools/host_path_bench2.py, 4K, 48 pairs: process() from 1 / 2 / 3 / 4 caller threads
+    // 192 / 341 / 389 / 365 frames/s from pageable frames (resident frames: 395), 244 / 307 / 349 / 344 from page-locked ones
+    const int K = std::min(n, 3);
     // A host frame that serves several pairs of the batch (consecutive pairs of a sequence share one) crosses PCIe once: it becomes a
     // resident frame on first use and is released after its last (stream mode, below).  Batches without shared frames run as before.
     struct Shared { std::mutex mu; rife_hip_frame_t* f = nullptr; int left = 0; };
@@ -2190,6 +2192,24 @@ int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* 
     try { return rife_hip_process_device_impl(E, d_in0, d_in1, w, h, timestep, d_out, hip_stream); }
     catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_process_device: ") + e.what()); }
     catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_process_device: unknown exception"); }
+}
+
+// ---- page-locked host frames (include/rife_hip.h) ----
+void* rife_hip_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { g_err = "hipHostMalloc failed"; return nullptr; }
+    return p;
+}
+void rife_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
+int rife_hip_host_register(void* p, size_t bytes) {
+    if (!p || bytes == 0) return fail(RIFE_HIP_EINVAL, "null range");
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return 0;
+}
+int rife_hip_host_unregister(void* p) {
+    if (!p) return fail(RIFE_HIP_EINVAL, "null pointer");
+    HIPCHK(hipHostUnregister(p));
+    return 0;
 }
 
 int rife_hip_profile_enable(rife_hip_t* E, int on) {

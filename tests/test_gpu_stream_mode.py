@@ -74,3 +74,26 @@ def test_frame_errors_and_lifetime(modeldirs):
     assert np.array_equal(g.process_frames(a, c, 0.5), ref)
     del g
     a.release(); c.release()
+
+
+def test_page_locked_frames_give_the_same_pixels(modeldirs):
+    """rife_hip_host_alloc / rife_hip_host_register: page-locked host frames (asynchronous DMA) in, page-locked frame out."""
+    import ctypes
+    g = amd.RIFE(0, rife_v4=True)
+    g.load(modeldirs["rife-v4.6"])
+    a, b = gen_frames.smooth_pair(320, 200, 31)
+    want = g.process(a, b, 0.5)
+    pa, pb, po = amd.pinned_empty(a.shape), amd.pinned_empty(a.shape), amd.pinned_empty(a.shape)
+    pa[...] = a; pb[...] = b
+    assert np.array_equal(g.process(pa, pb, 0.5, outimage=po), want)
+    # a buffer the caller owns, page-locked in place for as long as it is used
+    ra, ro = a.copy(), np.empty_like(a)
+    L = amd.lib()
+    assert L.rife_hip_host_register(ra.ctypes.data_as(ctypes.c_void_p), ra.nbytes) == 0
+    assert L.rife_hip_host_register(ro.ctypes.data_as(ctypes.c_void_p), ro.nbytes) == 0
+    try:
+        assert np.array_equal(g.process(ra, pb, 0.5, outimage=ro), want)
+    finally:
+        assert L.rife_hip_host_unregister(ra.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert L.rife_hip_host_unregister(ro.ctypes.data_as(ctypes.c_void_p)) == 0
+    del pa, pb, po                                      # the last view gone: rife_hip_host_free
