@@ -306,7 +306,8 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
     int cus = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpuid));
     T64Args a;
-    a.in = x; a.out = y; a.img = dimg; a.H = h; a.W = w; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y;
+    a.in = x; a.out = y; a.img = dimg; a.H = h; a.W = w; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y; a.reverse = 0;
+    const bool alternate = (variant & 0x10000) != 0; variant &= ~0x10000;
     const int nwg = std::min(T64_WG_PER_CU * (cus / 8 * 8), (a.ntiles + 7) / 8 * 8);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     auto run = [&](auto kfn) -> int {
@@ -315,6 +316,7 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
         HIPCHK(hipEventRecord(e0, 0));
         for (int i = 0; i < iters; i++) {
             a.in = (i & 1) ? y : x; a.out = (i & 1) ? x : y;
+            a.reverse = alternate ? (i & 1) : 0;
             hipLaunchKernelGGL(kfn, dim3(nwg), dim3(T64_NTHR), T64_LDS, 0, a);
         }
         HIPCHK(hipEventRecord(e1, 0));

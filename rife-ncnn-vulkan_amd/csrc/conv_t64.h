@@ -63,6 +63,7 @@ struct T64Args {
     int pitch;                   // pixels per plane row (tiles_x * 32 + 2)
     unsigned plane;              // bytes per plane (rows * pitch * 32)
     int tiles_x, ntiles;
+    int reverse;                 // 1: walk the tiles from the last to the first (see launch_t64: consecutive layers alternate)
     long long* stamps = nullptr; // bench builds only (TAG & T64_STAMPS): [workgroup][wave 8][step 32][4] shader-clock stamps
 };
 // bench-only ablation bits of TAG (timing experiments; the results of all but T64_STAMPS are garbage).  The product instantiates TAG = 3.
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
     f32x16 acc[2];
     int oy0 = 0, ox0 = 0;
     unsigned tb = 0;                                                     // byte offset of the tile's halo origin (tensors stay below 4 GB)
-    if (mine > 0) { const int ty = slot / a.tiles_x; oy0 = ty * T64_TH; ox0 = (slot - ty * a.tiles_x) * 32; tb = (unsigned)(oy0 * a.pitch + ox0) * 32u; }
+    if (mine > 0) { const int T0 = a.reverse ? a.ntiles - 1 - slot : slot; const int ty = T0 / a.tiles_x; oy0 = ty * T64_TH; ox0 = (T0 - ty * a.tiles_x) * 32; tb = (unsigned)(oy0 * a.pitch + ox0) * 32u; }
     int poy0 = 0, pox0 = 0;
 
     int stepno = 0;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
     T64_SYNC()
 
     for (int k = 0; k < mine; k++) {
-        const int Tn = slot + (k + 1) * nwg;
+        const int Tn = a.reverse ? a.ntiles - 1 - (slot + (k + 1) * nwg) : slot + (k + 1) * nwg;
         const bool more = k + 1 < mine;
         int oy0n = 0, ox0n = 0;
         unsigned tbn = 0;

@@ -616,7 +616,10 @@ struct S16Geom {
 };
 
 // one 64 -> 64 residual trunk convolution, S16 in / S16 out, persistent workgroups (T64_WG_PER_CU per CU)
-static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st) {
+// reverse: walk the tiles last to first.  Consecutive trunk layers alternate, so that a layer starts on what its predecessor wrote
+// last - still in the L2 / Infinity Cache (134 MB in + 134 MB out per 4K layer against 256 MB of cache: in one direction only the
+// first rows of a layer's input were written more than a cache-full of traffic ago by the time they are read).
+static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool reverse = false) {
     if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_t64 image");
     int dev = 0; (void)hipGetDevice(&dev);
     static std::mutex mu; static std::map<int, int> ncu;
@@ -634,7 +637,7 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
     }
     const S16Geom G(H, W);
     T64Args a;
-    a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y;
+    a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y; a.reverse = reverse ? 1 : 0;
     const int nwg = std::min(T64_WG_PER_CU * cus, (a.ntiles + 7) / 8 * 8);      // all workgroups resident at once
     hipLaunchKernelGGL(conv_t64_kernel<3>, dim3(nwg), dim3(T64_NTHR), T64_LDS, st, a);
     hipError_t e = hipGetLastError();
@@ -794,6 +797,7 @@ struct rife_hip {
     // finest-block trunk on S16 tensors + the persistent conv_t64 kernel (RIFE_HIP_T64=0 at create time keeps conv_h2b: A/B and
     // the bit-equality test of the two trunk implementations)
     bool t64 = true;
+    bool t64_alternate = true;               // RIFE_HIP_T64_ALT=0 at create time: every trunk layer walks its tiles first to last (A/B)
     int flow_div(int b) const { return v40 ? 2 * blk[b].scale : blk[b].scale; }
     // rife-v2.x schedule (IFNet + ContextNet + FusionNet)
     struct V2Block { ConvLayer stem0, stem1, conv[6], head; int c = 0, scale = 1; } fblk[4];
@@ -983,7 +987,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         unsigned char *pc = c.P0, *pn = c.P1;
         for (int i = 0; i < 8; i++) {
             Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
-            if ((rc = launch_t64(B.res[i], pc, pn, Ht, Wt, st))) return rc;
+            if ((rc = launch_t64(B.res[i], pc, pn, Ht, Wt, st, E.t64_alternate && (i & 1) == 0))) return rc;
             std::swap(pc, pn);
         }
         Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);
@@ -1805,6 +1809,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     E->frame_pool = std::make_shared<FramePool>();
     E->frame_pool->gpuid = gpuid;
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
+    { const char* e = getenv("RIFE_HIP_T64_ALT"); E->t64_alternate = !(e && e[0] == '0'); }
     return E;
 }
 

@@ -13,7 +13,7 @@ L.rife_hip_bench_t64.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_fl
 h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (544, 960)
 NOSTORE, NODMA, NOMATH, NOVMWAIT, STAMPS = 0x100, 0x200, 0x400, 0x800, 0x1000
 for rep in range(2):
-    for name, v in (("full", 0), ("no stores (loads + math)", NOSTORE), ("no DMA (math + stores)", NODMA), ("no DMA, no stores (math only)", NODMA | NOSTORE), ("no math", NOMATH),
+    for name, v in (("full", 0), ("full, layers alternate direction", 0x10000), ("no stores (loads + math)", NOSTORE), ("no DMA (math + stores)", NODMA), ("no DMA, no stores (math only)", NODMA | NOSTORE), ("no math", NOMATH),
                     ("no math, no stores (loads only)", NOMATH | NOSTORE), ("no math, no DMA (stores only)", NOMATH | NODMA), ("no vmcnt wait", NOVMWAIT)):
         ms = ctypes.c_float()
         rc = L.rife_hip_bench_t64(0, h, w, v, 20, ctypes.byref(ms))
