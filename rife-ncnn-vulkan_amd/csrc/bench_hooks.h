@@ -308,7 +308,7 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
     T64Args a;
     a.in = x; a.out = y; a.img = dimg; a.H = h; a.W = w; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y; a.reverse = 0;
     const bool alternate = (variant & 0x10000) != 0; variant &= ~0x10000;
-    const int nwg = std::min(T64_WG_PER_CU * (cus / 8 * 8), (a.ntiles + 7) / 8 * 8);
+    const int nwg = std::min(t64_wg_per_cu(2) * (cus / 8 * 8), (a.ntiles + 7) / 8 * 8);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     auto run = [&](auto kfn) -> int {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, T64_LDS));

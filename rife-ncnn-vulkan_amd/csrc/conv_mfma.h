@@ -945,7 +945,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int oy = oy0 + wv, ox = ox0 + li;
     const bool pok = oy < a.Ho && ox < a.Wo;
     if (S16OUT) {
-        static_assert(!S16OUT || NS == 2, "S16 tensors of this path have 64 channels");
         unsigned char* const o = reinterpret_cast<unsigned char*>(a.out) + ((size_t)(2 * half) * a.s16_plane + ((size_t)(oy + 1) * a.s16_pitch + ox + 1) * 32);
 #pragma unroll
         for (int n = 0; n < NS; n++) {

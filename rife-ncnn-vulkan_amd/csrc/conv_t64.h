@@ -40,17 +40,21 @@
 
 namespace rife {
 
-constexpr int T64_TH = 8, T64_NTHR = 64 * T64_TH, T64_WG_PER_CU = 2;    // tile rows = waves per workgroup; resident workgroups per CU
+constexpr int T64_TH = 8, T64_NTHR = 64 * T64_TH;                        // tile rows = waves per workgroup
 constexpr int T64_IH = T64_TH + 2, T64_IW = 34, T64_NPX = T64_IH * T64_IW;      // halo tile of an 8 x 32 output tile
 constexpr int T64_PLANE = T64_NPX * 32;                                  // 10,880 B: hi (or lo) halves of one 16-channel chunk
 constexpr int T64_INB = 2 * T64_PLANE;                                   // 21,760 B per halo chunk buffer
-constexpr int T64_WCH = 9 * 2048;                                        // 18,432 B: weights of one K chunk [tap][k half][64 rows][8 f16]
-constexpr int T64_WB = 4 * T64_WCH;                                      // 73,728 B
-constexpr int T64_BSB = 2 * 64 * 4;                                      // bias[64], slope[64]
-constexpr int T64_IMG = T64_WB + T64_BSB;                                // 74,240 B: weight image in global memory, built on the host
-constexpr int T64_LDS_IN = 0, T64_LDS_W = 2 * T64_INB, T64_LDS_BS = T64_LDS_W + 2 * T64_WCH;
-constexpr int T64_LDS = T64_LDS_BS + T64_BSB;                            // 80,896 B: two workgroups per CU (limit 163,840)
-static_assert(T64_WG_PER_CU * T64_LDS <= 160 * 1024, "LDS budget");
+// C = 32 NS channels (NS = 2: the 64-channel trunk of the finest block, NS = 3: the 96-channel trunk of block 2)
+constexpr int t64_wch(int NS) { return 9 * 2 * 32 * NS * 16; }          // weights of one K chunk [tap][k half][C rows][8 f16]: 18,432 / 27,648 B
+constexpr int t64_wb(int NS) { return 2 * NS * t64_wch(NS); }           // C / 16 chunks
+constexpr int t64_bsb(int NS) { return 2 * 32 * NS * 4; }               // bias[C], slope[C]
+constexpr int t64_img(int NS) { return t64_wb(NS) + t64_bsb(NS); }      // weight image in global memory, built on the host
+constexpr int T64_LDS_IN = 0, T64_LDS_W = 2 * T64_INB;
+constexpr int t64_lds_bs(int NS) { return T64_LDS_W + 2 * t64_wch(NS); }
+constexpr int t64_lds(int NS) { return t64_lds_bs(NS) + t64_bsb(NS); }  // 80,896 B (two workgroups per CU) / 99,584 B (one)
+constexpr int t64_wg_per_cu(int NS) { return 160 * 1024 / t64_lds(NS); }
+static_assert(t64_wg_per_cu(2) == 2 && t64_wg_per_cu(3) == 1, "LDS budget");
+constexpr int T64_IMG = t64_img(2), T64_WB = t64_wb(2), T64_LDS = t64_lds(2);
 
 // row i of a 32-row MFMA block <-> output channel (within the block): a lane's 16 accumulator registers are 16 consecutive channels
 __host__ __device__ constexpr int s16_row_channel(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
@@ -76,8 +80,9 @@ __device__ __forceinline__ void t64_glds16(const unsigned char* g, unsigned char
     __builtin_amdgcn_global_load_lds((t64_glb_u8*)g, (t64_lds_u8*)l, 16, 0, 0);
 }
 
-template <int TAG>
-__global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_t64_kernel(T64Args a) {
+template <int TAG, int NS = 2>
+__global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t64_wg_per_cu(NS), 2 * t64_wg_per_cu(NS)))) void conv_t64_kernel(T64Args a) {
+    constexpr int T64_WCH = t64_wch(NS), T64_WB = t64_wb(NS), T64_BSB = t64_bsb(NS), T64_LDS_BS = t64_lds_bs(NS), T64_LDS = t64_lds(NS), CH = 32 * NS;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* const lds = ldsb;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int P = (r + t / 3) * T64_IW + li + t % 3;
         ap[t] = lds + T64_LDS_IN + P * 32 + ((h ^ ((P >> 3) & 1)) << 4);
     }
-    const unsigned char* const wb = lds + T64_LDS_W + h * 1024 + li * 16;
+    const unsigned char* const wb = lds + T64_LDS_W + h * (CH * 16) + li * 16;
     const float* const bs = reinterpret_cast<const float*>(lds + T64_LDS_BS);
     // identity A fragments of the skip connection: K chunk c = 2 n + hc carries input channels 32 n + 16 hc .. + 15, i.e. the rows
     // i of block n with s16_row_channel(i) = 16 hc + k; lane (row li, k half h) holds A[li][8 h .. 8 h + 7]
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int nwg = gridDim.x, b = blockIdx.x;
     const int slot = (b & 7) * (nwg >> 3) + (b >> 3);
     const int mine = a.ntiles > slot ? (a.ntiles - slot + nwg - 1) / nwg : 0;
-    f32x16 acc[2];
+    f32x16 acc[NS];
     int oy0 = 0, ox0 = 0;
     unsigned tb = 0;                                                     // byte offset of the tile's halo origin (tensors stay below 4 GB)
     if (mine > 0) { const int T0 = a.reverse ? a.ntiles - 1 - slot : slot; const int ty = T0 / a.tiles_x; oy0 = ty * T64_TH; ox0 = (T0 - ty * a.tiles_x) * 32; tb = (unsigned)(oy0 * a.pitch + ox0) * 32u; }
@@ -147,7 +152,8 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
         unsigned char* dst_ = lds + T64_LDS_W + (PAR) * T64_WCH + r * 1024;                                  \
         t64_glds16(src_, dst_);                                                                              \
         t64_glds16(src_ + 8 * 1024, dst_ + 8 * 1024);                                                        \
-        if (r < 2) t64_glds16(src_ + 16 * 1024, dst_ + 16 * 1024);                                           \
+        if (r + 16 < T64_WCH / 1024) t64_glds16(src_ + 16 * 1024, dst_ + 16 * 1024);                         \
+        if (r + 24 < T64_WCH / 1024) t64_glds16(src_ + 24 * 1024, dst_ + 24 * 1024);                         \
     }
 #define T64_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
 #define T64_TAPS(C, PAR)                                                                                     \
@@ -156,12 +162,10 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
         _Pragma("unroll") for (int t = 0; t < 9; t++) {                                                      \
             const f16x8 ah = *reinterpret_cast<const f16x8*>(ap[t] + (PAR) * T64_INB);                       \
             const f16x8 al = *reinterpret_cast<const f16x8*>(ap[t] + (PAR) * T64_INB + T64_PLANE);           \
-            const f16x8 b0 = *reinterpret_cast<const f16x8*>(wb + (PAR) * T64_WCH + t * 2048);               \
-            const f16x8 b1 = *reinterpret_cast<const f16x8*>(wb + (PAR) * T64_WCH + t * 2048 + 512);         \
-            acc[0] = T64_MFMA(b0, ah, acc[0]);                                                               \
-            acc[1] = T64_MFMA(b1, ah, acc[1]);                                                               \
-            acc[0] = T64_MFMA(b0, al, acc[0]);                                                               \
-            acc[1] = T64_MFMA(b1, al, acc[1]);                                                               \
+            f16x8 bw_[NS];                                                                                   \
+            _Pragma("unroll") for (int n = 0; n < NS; n++) bw_[n] = *reinterpret_cast<const f16x8*>(wb + (PAR) * T64_WCH + t * (2 * CH * 16) + n * 512); \
+            _Pragma("unroll") for (int n = 0; n < NS; n++) acc[n] = T64_MFMA(bw_[n], ah, acc[n]);            \
+            _Pragma("unroll") for (int n = 0; n < NS; n++) acc[n] = T64_MFMA(bw_[n], al, acc[n]);            \
         }                                                                                                    \
         {   /* skip connection: identity on the centre pixel; chunk C only feeds output block C >> 1 */      \
             const f16x8 ah = *reinterpret_cast<const f16x8*>(ap[4] + (PAR) * T64_INB);                       \
@@ -186,11 +190,11 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int oy_ = (OY0) + r, ox_ = (OX0) + li;                                                         \
         const bool ok_ = oy_ < a.H && ox_ < a.W && (!(TAG & T64_NOSTORE) || acc[0][0] == 123.456f);          /* ablation: (almost) never true, keeps the matrix work alive */ \
         unsigned char* const o_ = a.out + ((unsigned)(2 * h) * a.plane + (unsigned)((oy_ + 1) * a.pitch + ox_ + 1) * 32u); \
-        _Pragma("unroll") for (int n = 0; n < 2; n++) {                                                      \
+        _Pragma("unroll") for (int n = 0; n < NS; n++) {                                                     \
             float v_[16];                                                                                    \
             _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                  \
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(bs + n * 32 + 16 * h + 4 * q);              \
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(bs + 64 + n * 32 + 16 * h + 4 * q);         \
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(bs + CH + n * 32 + 16 * h + 4 * q);         \
                 _Pragma("unroll") for (int k = 0; k < 4; k++) {                                              \
                     const float y = acc[n][4 * q + k] + b4[k];                                               \
                     v_[4 * q + k] = y < 0.f ? y * s4[k] : y;                                                 \
@@ -201,43 +205,34 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
 
     // ---- prologue: bias / slopes, weight chunk 0, halo chunk 0 of the first tile
-    if (r == 7 && lane < 32 && !(TAG & T64_NODMA)) t64_glds16(a.img + T64_WB + lane * 16, lds + T64_LDS_BS);
+    if (r == 7 && lane < T64_BSB / 16 && !(TAG & T64_NODMA)) t64_glds16(a.img + T64_WB + lane * 16, lds + T64_LDS_BS);
     if (TAG & T64_NODMA) { for (int i = tid; i < T64_LDS / 16; i += T64_NTHR) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     T64_DMA_W(0, 0)
     if (mine > 0) T64_DMA_IN(tb, 0, 0)
     T64_SYNC()
 
+    constexpr int NCH = 2 * NS;                                          // K chunks per tile (even: chunk c always sits in buffer c & 1)
     for (int k = 0; k < mine; k++) {
         const int Tn = a.reverse ? a.ntiles - 1 - (slot + (k + 1) * nwg) : slot + (k + 1) * nwg;
         const bool more = k + 1 < mine;
         int oy0n = 0, ox0n = 0;
         unsigned tbn = 0;
         if (more) { const int ty = Tn / a.tiles_x; oy0n = ty * T64_TH; ox0n = (Tn - ty * a.tiles_x) * 32; tbn = (unsigned)(oy0n * a.pitch + ox0n) * 32u; }
-
-        T64_DMA_IN(tb, 1, 1)
-        T64_DMA_W(1, 1)
-        if (k > 0) T64_EPILOGUE(poy0, pox0)
 #pragma unroll
-        for (int n = 0; n < 2; n++)
+        for (int c = 0; c < NCH; c++) {
+            // step c: send chunk c + 1 (or the next tile's chunk 0) and its weights to the other buffers, then the matrix work of chunk c
+            if (c + 1 < NCH) { T64_DMA_IN(tb, c + 1, (c + 1) & 1) T64_DMA_W(c + 1, (c + 1) & 1) }
+            else if (more) { T64_DMA_IN(tbn, 0, 0) T64_DMA_W(0, 0) }
+            if (c == 0) {
+                if (k > 0) T64_EPILOGUE(poy0, pox0)
 #pragma unroll
-            for (int q = 0; q < 16; q++) acc[n][q] = 0.f;
-        T64_TAPS(0, 0)
-        T64_SYNC()
-
-        T64_DMA_IN(tb, 2, 0)
-        T64_DMA_W(2, 0)
-        T64_TAPS(1, 1)
-        T64_SYNC()
-
-        T64_DMA_IN(tb, 3, 1)
-        T64_DMA_W(3, 1)
-        T64_TAPS(2, 0)
-        T64_SYNC()
-
-        if (more) { T64_DMA_IN(tbn, 0, 0) T64_DMA_W(0, 0) }
-        T64_TAPS(3, 1)
-        T64_SYNC()
-
+                for (int n = 0; n < NS; n++)
+#pragma unroll
+                    for (int q = 0; q < 16; q++) acc[n][q] = 0.f;
+            }
+            T64_TAPS(c, c & 1)
+            T64_SYNC()
+        }
         poy0 = oy0; pox0 = ox0;
         oy0 = oy0n; ox0 = ox0n; tb = tbn;
     }

@@ -187,21 +187,22 @@ static std::vector<uint16_t> pack_weights_h2_perm(const ConvLayer& L, const floa
     return out;
 }
 
-// Weight image of conv_t64_kernel (conv_t64.h): fp16 weights [chunk 4][tap 9][k half 2][row 64][8] with the rows of each
-// 32-row block permuted by s16_row_channel() (every chunk is one contiguous LDS-DMA source), then bias[64] and slope[64] as fp32.
-static std::vector<unsigned char> pack_t64_image(const float* w, const float* bias, float slope) {
-    std::vector<unsigned char> img(T64_IMG, 0);
+// Weight image of conv_t64_kernel (conv_t64.h): fp16 weights [chunk C/16][tap 9][k half 2][row C][8] with the rows of each
+// 32-row block permuted by s16_row_channel() (every chunk is one contiguous LDS-DMA source), then bias[C] and slope[C] as fp32.
+static std::vector<unsigned char> pack_t64_image(const float* w, const float* bias, float slope, int C = 64) {
+    const int NS = C / 32;
+    std::vector<unsigned char> img(t64_img(NS), 0);
     uint16_t* wh = reinterpret_cast<uint16_t*>(img.data());
-    for (int c = 0; c < 4; c++)
+    for (int c = 0; c < C / 16; c++)
         for (int t = 0; t < 9; t++)
             for (int kh = 0; kh < 2; kh++)
-                for (int row = 0; row < 64; row++)
+                for (int row = 0; row < C; row++)
                     for (int e = 0; e < 8; e++) {
                         const int oc = (row & ~31) + s16_row_channel(row & 31), ic = 16 * c + 8 * kh + e;
-                        wh[((((size_t)c * 9 + t) * 2 + kh) * 64 + row) * 8 + e] = f2h(w[((size_t)oc * 64 + ic) * 9 + t]);
+                        wh[((((size_t)c * 9 + t) * 2 + kh) * C + row) * 8 + e] = f2h(w[((size_t)oc * C + ic) * 9 + t]);
                     }
-    float* bs = reinterpret_cast<float*>(img.data() + T64_WB);
-    for (int i = 0; i < 64; i++) { bs[i] = bias ? bias[i] : 0.f; bs[64 + i] = slope; }
+    float* bs = reinterpret_cast<float*>(img.data() + t64_wb(NS));
+    for (int i = 0; i < C; i++) { bs[i] = bias ? bias[i] : 0.f; bs[C + i] = slope; }
     return img;
 }
 
@@ -319,8 +320,8 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
             HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
             L.nchunksh = L.cin / 16;
-            if (L.want_t64 && L.skip && L.cin == 64 && L.cout == 64 && !slope) {
-                std::vector<unsigned char> img = pack_t64_image(w_orig, bias, uniform_slope);
+            if (L.want_t64 && L.skip && L.cin == L.cout && (L.cout == 64 || L.cout == 96) && !slope) {
+                std::vector<unsigned char> img = pack_t64_image(w_orig, bias, uniform_slope, L.cout);
                 HIPCHK(hipMalloc(&L.d_t64, img.size()));
                 HIPCHK(hipMemcpy(L.d_t64, img.data(), img.size(), hipMemcpyHostToDevice));
             }
@@ -401,14 +402,16 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
             if (!sdone[dev]) {
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2s2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, ls2));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2s2_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ls2));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2s2_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ls3));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2s2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, ls3));
                 sdone[dev] = true;
             }
         }
         if (s16_pitch > 0) {
-            if (L.NS != 2 || !L.d_whp) return fail(RIFE_HIP_EINVAL, "no S16 variant of this stride-2 layer");
+            if ((L.NS != 2 && L.NS != 3) || !L.d_whp) return fail(RIFE_HIP_EINVAL, "no S16 variant of this stride-2 layer");
             a.wpk = reinterpret_cast<const float*>(L.d_whp);
-            hipLaunchKernelGGL((conv_h2s2_kernel<2, true>), dim3(nb), dim3(256), ls2, st, a);
+            if (L.NS == 2) hipLaunchKernelGGL((conv_h2s2_kernel<2, true>), dim3(nb), dim3(256), ls2, st, a);
+            else hipLaunchKernelGGL((conv_h2s2_kernel<3, true>), dim3(nb), dim3(256), ls3, st, a);
         }
         else if (L.NS == 1) hipLaunchKernelGGL(conv_h2s2_kernel<1>, dim3(nb), dim3(256), ls1, st, a);
         else if (L.NS == 2) hipLaunchKernelGGL(conv_h2s2_kernel<2>, dim3(nb), dim3(256), ls2, st, a);
@@ -615,12 +618,13 @@ struct S16Geom {
     size_t bytes(int C) const { return (size_t)plane() * (C / 8); }
 };
 
-// one 64 -> 64 residual trunk convolution, S16 in / S16 out, persistent workgroups (T64_WG_PER_CU per CU)
+// one C -> C (C = 64, 96) residual trunk convolution, S16 in / S16 out, persistent workgroups (two / one per CU)
 // reverse: walk the tiles last to first.  Consecutive trunk layers alternate, so that a layer starts on what its predecessor wrote
 // last - still in the L2 / Infinity Cache (134 MB in + 134 MB out per 4K layer against 256 MB of cache: in one direction only the
 // first rows of a layer's input were written more than a cache-full of traffic ago by the time they are read).
 static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool reverse = false) {
     if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_t64 image");
+    const int NS = L.cout / 32;
     int dev = 0; (void)hipGetDevice(&dev);
     static std::mutex mu; static std::map<int, int> ncu;
     int cus;
@@ -628,7 +632,8 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
         std::lock_guard<std::mutex> g(mu);
         auto it = ncu.find(dev);
         if (it == ncu.end()) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_t64_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, T64_LDS));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_t64_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, t64_lds(2)));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_t64_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, t64_lds(3)));
             int n = 0;
             HIPCHK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
             it = ncu.emplace(dev, std::max(8, n / 8 * 8)).first;
@@ -638,8 +643,10 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
     const S16Geom G(H, W);
     T64Args a;
     a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y; a.reverse = reverse ? 1 : 0;
-    const int nwg = std::min(T64_WG_PER_CU * cus, (a.ntiles + 7) / 8 * 8);      // all workgroups resident at once
-    hipLaunchKernelGGL(conv_t64_kernel<3>, dim3(nwg), dim3(T64_NTHR), T64_LDS, st, a);
+    const int nwg = std::min(t64_wg_per_cu(NS) * cus, (a.ntiles + 7) / 8 * 8);      // all workgroups resident at once
+    if (NS == 2) hipLaunchKernelGGL((conv_t64_kernel<3, 2>), dim3(nwg), dim3(T64_NTHR), t64_lds(2), st, a);       // TAG: the profile class (trunk_b3 / trunk_b2)
+    else if (NS == 3) hipLaunchKernelGGL((conv_t64_kernel<2, 3>), dim3(nwg), dim3(T64_NTHR), t64_lds(3), st, a);
+    else return fail(RIFE_HIP_EINVAL, "conv_t64 serves 64 and 96 channels");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_t64 launch: ") + hipGetErrorString(e));
     return 0;
@@ -709,6 +716,7 @@ struct Ctx {
     float *X = nullptr, *S1 = nullptr, *T0 = nullptr, *T1 = nullptr; // block input, stem-1 output, trunk ping/pong
     float *T2 = nullptr;                                             // rife-v4 (4.0): stem-1 output kept for the block's residual add
     unsigned char *P0 = nullptr, *P1 = nullptr;                      // block 3 trunk ping / pong as S16 tensors (conv_t64.h), zero borders
+    unsigned char *Q0 = nullptr, *Q1 = nullptr;                      // block 2 trunk (96 channels at 1/8 resolution), likewise
     float* flow[4] = {nullptr, nullptr, nullptr, nullptr};           // [hp/s][wp/s][8]
     float4* F = nullptr; float* M = nullptr;                         // full-resolution flow (4ch) and mask logit
     float4* outf = nullptr;                                          // TTA only: out0 as float, padded
@@ -797,6 +805,7 @@ struct rife_hip {
     // finest-block trunk on S16 tensors + the persistent conv_t64 kernel (RIFE_HIP_T64=0 at create time keeps conv_h2b: A/B and
     // the bit-equality test of the two trunk implementations)
     bool t64 = true;
+    bool t64_b2 = true;                      // RIFE_HIP_T64_B2=0 at create time: block 2 (96 channels) stays on the per-tile trunk kernel (A/B)
     bool t64_alternate = true;               // RIFE_HIP_T64_ALT=0 at create time: every trunk layer walks its tiles first to last (A/B)
     int flow_div(int b) const { return v40 ? 2 * blk[b].scale : blk[b].scale; }
     // rife-v2.x schedule (IFNet + ContextNet + FusionNet)
@@ -878,6 +887,12 @@ static int ensure_ctx_dims_impl(Ctx& c, int w, int h, int wp, int hp, const Ctx*
         if ((rc = dalloc(c, c.P1, nb))) return rc;
         if (c.stream) { HIPCHK(hipMemsetAsync(c.P0, 0, nb, c.stream)); HIPCHK(hipMemsetAsync(c.P1, 0, nb, c.stream)); }
         else { HIPCHK(hipMemset(c.P0, 0, nb)); HIPCHK(hipMemset(c.P1, 0, nb)); }
+        const S16Geom G2(hp / 8, wp / 8);
+        const size_t nb2 = G2.bytes(96);
+        if ((rc = dalloc(c, c.Q0, nb2))) return rc;
+        if ((rc = dalloc(c, c.Q1, nb2))) return rc;
+        if (c.stream) { HIPCHK(hipMemsetAsync(c.Q0, 0, nb2, c.stream)); HIPCHK(hipMemsetAsync(c.Q1, 0, nb2, c.stream)); }
+        else { HIPCHK(hipMemset(c.Q0, 0, nb2)); HIPCHK(hipMemset(c.Q1, 0, nb2)); }
     }
     static const int sc[4] = {8, 4, 2, 1};
     for (int b = 0; b < 4; b++) {
@@ -902,7 +917,7 @@ static void reset_ctx(Ctx& c) {
     if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
     for (void* p : c.allocs) (void)hipFree(p);
     c.allocs.clear();
-    c.w = c.h = c.wp = c.hp = 0; c.v2 = false; c.outf = nullptr; c.d_ts = nullptr; c.g_warm = false; c.P0 = c.P1 = nullptr;
+    c.w = c.h = c.wp = c.hp = 0; c.v2 = false; c.outf = nullptr; c.d_ts = nullptr; c.g_warm = false; c.P0 = c.P1 = c.Q0 = c.Q1 = nullptr;
 }
 static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scratch = nullptr, bool own_images = true, bool want_outf = false) {
     const int rc = ensure_ctx_dims_impl(c, w, h, wp, hp, scratch, own_images, want_outf);
@@ -975,16 +990,21 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         if ((rc = launch_conv(B.stem0, {c.X, xin_ld, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, nullptr, st))) return rc;
     }
     const int Ht = Hb / 4, Wt = Wb / 4;
-    bool s16 = E.t64 && !E.v40 && b == 3 && B.c == 64 && g_trunk_h2 && g_head_h2 && g_s2_h2 && c.P0 && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS;
+    // blocks 3 (64 ch) and 2 (96 ch): S16 tensors + the persistent trunk kernel; block 2 only when its grid fills a good part of the chip
+    // (16 launches of a few workgroups each are served better by the per-tile kernels with their 4-row / split-K variants)
+    unsigned char* const PA = b == 3 ? c.P0 : c.Q0;
+    unsigned char* const PB = b == 3 ? c.P1 : c.Q1;
+    bool s16 = E.t64 && !E.v40 && ((b == 3 && B.c == 64) || (b == 2 && B.c == 96 && E.t64_b2 && ((Ht + 7) / 8) * ((Wt + 31) / 32) >= 96)) && g_trunk_h2 && PA &&
+               B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS;
     for (int i = 0; i < 8 && s16; i++) s16 = B.res[i].d_t64 != nullptr;
     if (s16) {
         // stem-1 writes the first S16 tensor, eight persistent trunk launches ping-pong between the two, the head reads the last one
         const S16Geom G(Ht, Wt);
         {
             Timed t(E.prof, B.stem1.cls, B.stem1.flops_per_pixel * Ht * Wt, st);
-            if ((rc = launch_conv(B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {reinterpret_cast<float*>(c.P0), B.c, 0}, nullptr, st, nullptr, G.pitch, G.plane()))) return rc;
+            if ((rc = launch_conv(B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {reinterpret_cast<float*>(PA), B.c, 0}, nullptr, st, nullptr, G.pitch, G.plane()))) return rc;
         }
-        unsigned char *pc = c.P0, *pn = c.P1;
+        unsigned char *pc = PA, *pn = PB;
         for (int i = 0; i < 8; i++) {
             Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
             if ((rc = launch_t64(B.res[i], pc, pn, Ht, Wt, st, E.t64_alternate && (i & 1) == 0))) return rc;
@@ -1810,6 +1830,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     E->frame_pool->gpuid = gpuid;
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_T64_ALT"); E->t64_alternate = !(e && e[0] == '0'); }
+    { const char* e = getenv("RIFE_HIP_T64_B2"); E->t64_b2 = !(e && e[0] == '0'); }
     return E;
 }
 
@@ -1896,8 +1917,8 @@ static int rife_hip_load_impl(rife_hip_t* E, const char* modeldir) {
             L.cin = cin; L.cout = cout; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi; L.cls = cls;
             L.tag = std::strcmp(cls, "trunk_b3") == 0 ? 3 : 0;
             L.skip = fold_skip;
-            L.want_t64 = fold_skip && cin == 64 && cout == 64;
-            L.want_s16out = !deconv && stride == 2 && cout == 64 && b == 3;
+            L.want_t64 = fold_skip && cin == cout && (cout == 64 || cout == 96);
+            L.want_s16out = !deconv && stride == 2 && ((cout == 64 && b == 3) || (cout == 96 && b == 2));
             return upload_layer(L, nl->weight.data(), nl->bias.data(), nullptr, slope);
         };
         std::snprintf(name, sizeof name, "stem0_b%d", b);

@@ -1,28 +1,35 @@
 #!/bin/bash
 # One-shot profile refresh on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_round.sh <round-tag>      -> gpurun_out/profile_<tag>/...
+#   bash tools/profile_round.sh <round-tag>      -> gpurun_out/profile_<tag>/...   (copy what is to be judged into profiles/<tag>/)
 # 1) rocprofv3 --kernel-trace --stats of the bench workload (4K, rife-v4.6, one pair in flight)
-# 2) three separate PMC passes (matrix pipe / LDS, FETCH_SIZE, WRITE_SIZE) of the same workload
-# 3) bench.py JSON lines for every workload
+# 2) separate PMC passes of the same workload: matrix pipe / LDS / wave states, FETCH_SIZE, WRITE_SIZE (never combined with other traces)
+# 3) the dominant kernel's ablation timings and per-step clock stamps (tools/t64_bench.py)
+# 4) bench.py JSON lines for every workload, the host-path sweep
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profile_$TAG
+DOM=${DOM:-conv_t64_kernel}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $ROOT/tools/prof_run.py --workload 4k --pairs 8 > $OUT/kt.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $ROOT/tools/prof_run.py --workload 4k --pairs 8 > $OUT/kt.log 2>&1
 cp $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_4k.csv 2>/dev/null
-for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt1080 -- python $ROOT/tools/prof_run.py --workload 1080p --pairs 8 > $OUT/kt1080.log 2>&1
+cp $(find $OUT/kt1080 -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_1080p.csv 2>/dev/null
+for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
     name=$(echo $pass | cut -d' ' -f1)
-    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$name -- python $ROOT/tools/prof_run.py --workload 4k --pairs 3 > $OUT/pmc_$name.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$name -- python $ROOT/tools/prof_run.py --workload 4k --pairs 3 > $OUT/pmc_$name.log 2>&1
     f=$(find $OUT/pmc_$name -name '*counter_collection.csv' | head -1)
-    python $ROOT/tools/pmc_summary.py $f "conv_h2b_kernel<2, 10, 3, 8>" > $OUT/pmc_${name}_trunk_b3.txt 2>&1
+    python $ROOT/tools/pmc_summary.py $f "$DOM" > $OUT/pmc_${name}_trunk_b3.txt 2>&1
     python $ROOT/tools/pmc_summary.py $f > $OUT/pmc_${name}_all.txt 2>&1
 done
 # keep only the small summaries (gpurun_out is capped at 64 MiB)
-rm -rf $OUT/kt $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+rm -rf $OUT/kt $OUT/kt1080 $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES $OUT/pmc_SQ_WAIT_ANY $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 cd $ROOT
+timeout 300 python tools/t64_bench.py > $OUT/t64_bench.txt 2>&1
+rm -f gpurun_out/t64_stamps.bin
 for wl in 4k 1080p v23-1080p 4k-tta; do
-    python bench.py --workload $wl > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
+    timeout 600 python bench.py --workload $wl --steps 50 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
 done
+timeout 300 python tools/host_path_bench2.py > $OUT/host_path.txt 2>&1
 ls -la $OUT
