@@ -306,7 +306,7 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
     int cus = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpuid));
     T64Args a;
-    a.in = x; a.out = y; a.img = dimg; a.H = h; a.W = w; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y; a.reverse = 0;
+    a.in = x; a.out = y; a.img = dimg; a.H = h; a.W = w; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y; a.reverse = 0; a.nchunks = 4; a.nnt = 1;
     const bool alternate = (variant & 0x10000) != 0; variant &= ~0x10000;
     const int nwg = std::min(t64_wg_per_cu(2) * (cus / 8 * 8), (a.ntiles + 7) / 8 * 8);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));

@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int oy = oy0 + wv, ox = ox0 + li;
     const bool pok = oy < a.Ho && ox < a.Wo;
     if (S16OUT) {
-        unsigned char* const o = reinterpret_cast<unsigned char*>(a.out) + ((size_t)(2 * half) * a.s16_plane + ((size_t)(oy + 1) * a.s16_pitch + ox + 1) * 32);
+        unsigned char* const o = reinterpret_cast<unsigned char*>(a.out) + ((size_t)(2 * half + 4 * NS * ntile) * a.s16_plane + ((size_t)(oy + 1) * a.s16_pitch + ox + 1) * 32);
 #pragma unroll
         for (int n = 0; n < NS; n++) {
             float v[16];

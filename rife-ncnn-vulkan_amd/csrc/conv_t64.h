@@ -48,10 +48,13 @@ constexpr int T64_INB = 2 * T64_PLANE;                                   // 21,7
 constexpr int t64_wch(int NS) { return 9 * 2 * 32 * NS * 16; }          // weights of one K chunk [tap][k half][C rows][8 f16]: 18,432 / 27,648 B
 constexpr int t64_wb(int NS) { return 2 * NS * t64_wch(NS); }           // C / 16 chunks
 constexpr int t64_bsb(int NS) { return 2 * 32 * NS * 4; }               // bias[C], slope[C]
-constexpr int t64_img(int NS) { return t64_wb(NS) + t64_bsb(NS); }      // weight image in global memory, built on the host
+constexpr int t64_img(int NS) { return t64_wb(NS) + t64_bsb(NS); }      // weight image of a C = 32 NS layer in global memory, built on the host
+// C = 128 / 192 (blocks 1 / 0): NS = 2 with C / 64 N-tiles of 64 output channels; a work item = (pixel tile, N-tile), K = C / 16 chunks;
+// the image holds per N-tile: nchunks x t64_wch(2) of weights, then that N-tile's bias and slopes
+constexpr int t64_img_nt(int NS, int nchunks) { return nchunks * t64_wch(NS) + t64_bsb(NS); }
 constexpr int T64_LDS_IN = 0, T64_LDS_W = 2 * T64_INB;
 constexpr int t64_lds_bs(int NS) { return T64_LDS_W + 2 * t64_wch(NS); }
-constexpr int t64_lds(int NS) { return t64_lds_bs(NS) + t64_bsb(NS); }  // 80,896 B (two workgroups per CU) / 99,584 B (one)
+constexpr int t64_lds(int NS) { return t64_lds_bs(NS) + 2 * t64_bsb(NS); }  // two bias / slope buffers; 81,408 B (two workgroups per CU) / 100,352 B (one)
 constexpr int t64_wg_per_cu(int NS) { return 160 * 1024 / t64_lds(NS); }
 static_assert(t64_wg_per_cu(2) == 2 && t64_wg_per_cu(3) == 1, "LDS budget");
 constexpr int T64_IMG = t64_img(2), T64_WB = t64_wb(2), T64_LDS = t64_lds(2);
@@ -66,7 +69,8 @@ struct T64Args {
     int H, W;                    // valid pixels
     int pitch;                   // pixels per plane row (tiles_x * 32 + 2)
     unsigned plane;              // bytes per plane (rows * pitch * 32)
-    int tiles_x, ntiles;
+    int tiles_x, ntiles;         // pixel tiles
+    int nchunks, nnt;            // K chunks (input channels / 16, even), N-tiles of 32 NS output channels; work items = ntiles * nnt
     int reverse;                 // 1: walk the tiles from the last to the first (see launch_t64: consecutive layers alternate)
     long long* stamps = nullptr; // bench builds only (TAG & T64_STAMPS): [workgroup][wave 8][step 32][4] shader-clock stamps
 };
@@ -82,7 +86,7 @@ __device__ __forceinline__ void t64_glds16(const unsigned char* g, unsigned char
 
 template <int TAG, int NS = 2>
 __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t64_wg_per_cu(NS), 2 * t64_wg_per_cu(NS)))) void conv_t64_kernel(T64Args a) {
-    constexpr int T64_WCH = t64_wch(NS), T64_WB = t64_wb(NS), T64_BSB = t64_bsb(NS), T64_LDS_BS = t64_lds_bs(NS), T64_LDS = t64_lds(NS), CH = 32 * NS;
+    constexpr int T64_WCH = t64_wch(NS), T64_BSB = t64_bsb(NS), T64_LDS_BS = t64_lds_bs(NS), T64_LDS = t64_lds(NS), CH = 32 * NS;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* const lds = ldsb;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
         ap[t] = lds + T64_LDS_IN + P * 32 + ((h ^ ((P >> 3) & 1)) << 4);
     }
     const unsigned char* const wb = lds + T64_LDS_W + h * (CH * 16) + li * 16;
-    const float* const bs = reinterpret_cast<const float*>(lds + T64_LDS_BS);
+    const float* const bs0 = reinterpret_cast<const float*>(lds + T64_LDS_BS);      // bias | slopes of the work item, two buffers (item parity)
     // identity A fragments of the skip connection: K chunk c = 2 n + hc carries input channels 32 n + 16 hc .. + 15, i.e. the rows
     // i of block n with s16_row_channel(i) = 16 hc + k; lane (row li, k half h) holds A[li][8 h .. 8 h + 7]
     f16x8 idf[2];
@@ -123,15 +127,24 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
             for (int e = 0; e < 8; e++) idf[hc][e] = ch == 16 * hc + 8 * h + e ? (_Float16)1.f : (_Float16)0.f;
     }
 
-    // ---- tile stream: workgroup b runs on XCD b % 8; per round every XCD walks a contiguous band of tiles
+    // ---- work-item stream: workgroup b runs on XCD b % 8; per round every XCD walks a contiguous band of (pixel tile, N-tile) items
     const int nwg = gridDim.x, b = blockIdx.x;
     const int slot = (b & 7) * (nwg >> 3) + (b >> 3);
-    const int mine = a.ntiles > slot ? (a.ntiles - slot + nwg - 1) / nwg : 0;
+    const int nitems = a.ntiles * a.nnt;
+    const int mine = nitems > slot ? (nitems - slot + nwg - 1) / nwg : 0;
+    const int imgstride = a.nchunks * T64_WCH + T64_BSB;                 // bytes per N-tile of the weight image
     f32x16 acc[NS];
-    int oy0 = 0, ox0 = 0;
+    int oy0 = 0, ox0 = 0, nt = 0;
     unsigned tb = 0;                                                     // byte offset of the tile's halo origin (tensors stay below 4 GB)
-    if (mine > 0) { const int T0 = a.reverse ? a.ntiles - 1 - slot : slot; const int ty = T0 / a.tiles_x; oy0 = ty * T64_TH; ox0 = (T0 - ty * a.tiles_x) * 32; tb = (unsigned)(oy0 * a.pitch + ox0) * 32u; }
-    int poy0 = 0, pox0 = 0;
+#define T64_ITEM(W, OY, OX, TB, NT)                                                                          \
+    {                                                                                                        \
+        const int w_ = a.reverse ? nitems - 1 - (W) : (W);                                                   \
+        const int t_ = w_ / a.nnt; NT = w_ - t_ * a.nnt;                                                     \
+        const int ty_ = t_ / a.tiles_x; OY = ty_ * T64_TH; OX = (t_ - ty_ * a.tiles_x) * 32;                 \
+        TB = (unsigned)(OY * a.pitch + OX) * 32u;                                                            \
+    }
+    if (mine > 0) T64_ITEM(slot, oy0, ox0, tb, nt)
+    int poy0 = 0, pox0 = 0, pnt = 0;
 
     int stepno = 0;
 #define T64_STAMP(K)                                                                                         \
@@ -146,9 +159,9 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
         t64_glds16(src_ + soff[1], dst_ + 8 * 1024);                                                         \
         if (r < 6 && s2ok) t64_glds16(src_ + soff[2], dst_ + 16 * 1024);                                     \
     }
-#define T64_DMA_W(C, PAR)                                                                                    \
+#define T64_DMA_W(NT, C, PAR)                                                                                \
     if (!(TAG & T64_NODMA)) {                                                                                \
-        const unsigned char* src_ = a.img + (C) * T64_WCH + r * 1024 + lane * 16;                            \
+        const unsigned char* src_ = a.img + ((NT) * imgstride + (C) * T64_WCH + r * 1024) + lane * 16;       \
         unsigned char* dst_ = lds + T64_LDS_W + (PAR) * T64_WCH + r * 1024;                                  \
         t64_glds16(src_, dst_);                                                                              \
         t64_glds16(src_ + 8 * 1024, dst_ + 8 * 1024);                                                        \
@@ -156,7 +169,8 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
         if (r + 24 < T64_WCH / 1024) t64_glds16(src_ + 24 * 1024, dst_ + 24 * 1024);                         \
     }
 #define T64_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
-#define T64_TAPS(C, PAR)                                                                                     \
+    // IDN: the 32-channel output block (of this work item) that K chunk C is the skip connection of, or -1
+#define T64_TAPS(C, PAR, IDN)                                                                                \
     T64_STAMP(3)                                                                                             \
     if (!(TAG & T64_NOMATH)) {                                                                               \
         _Pragma("unroll") for (int t = 0; t < 9; t++) {                                                      \
@@ -167,14 +181,13 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
             _Pragma("unroll") for (int n = 0; n < NS; n++) acc[n] = T64_MFMA(bw_[n], ah, acc[n]);            \
             _Pragma("unroll") for (int n = 0; n < NS; n++) acc[n] = T64_MFMA(bw_[n], al, acc[n]);            \
         }                                                                                                    \
-        {   /* skip connection: identity on the centre pixel; chunk C only feeds output block C >> 1 */      \
+        if ((IDN) >= 0) {   /* skip connection: identity on the centre pixel; K chunk C only feeds output block C >> 1 */ \
             const f16x8 ah = *reinterpret_cast<const f16x8*>(ap[4] + (PAR) * T64_INB);                       \
             const f16x8 al = *reinterpret_cast<const f16x8*>(ap[4] + (PAR) * T64_INB + T64_PLANE);           \
-            acc[(C) >> 1] = T64_MFMA(idf[(C) & 1], ah, acc[(C) >> 1]);                                       \
-            acc[(C) >> 1] = T64_MFMA(idf[(C) & 1], al, acc[(C) >> 1]);                                       \
+            _Pragma("unroll") for (int n = 0; n < NS; n++)                                                   \
+                if ((IDN) == n) { acc[n] = T64_MFMA(idf[(PAR)], ah, acc[n]); acc[n] = T64_MFMA(idf[(PAR)], al, acc[n]); } \
         }                                                                                                    \
     }
-    // end of a step: this wave's LDS-DMA pieces have landed (a raw s_barrier: __syncthreads() would add nothing but its own vmcnt(0))
 #define T64_SYNC()                                                                                           \
     {                                                                                                        \
         T64_STAMP(0)                                                                                         \
@@ -185,11 +198,12 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
         stepno++;                                                                                            \
     }
     // y = slope(acc + bias) -> hi / lo entries of chunk 2 n + h, 32 bytes per pixel and plane
-#define T64_EPILOGUE(OY0, OX0)                                                                               \
+#define T64_EPILOGUE(OY0, OX0, NT, BUF)                                                                      \
     {                                                                                                        \
+        const float* const bs = bs0 + (BUF) * (T64_BSB / 4);                                                 \
         const int oy_ = (OY0) + r, ox_ = (OX0) + li;                                                         \
         const bool ok_ = oy_ < a.H && ox_ < a.W && (!(TAG & T64_NOSTORE) || acc[0][0] == 123.456f);          /* ablation: (almost) never true, keeps the matrix work alive */ \
-        unsigned char* const o_ = a.out + ((unsigned)(2 * h) * a.plane + (unsigned)((oy_ + 1) * a.pitch + ox_ + 1) * 32u); \
+        unsigned char* const o_ = a.out + ((unsigned)(2 * h + 4 * NS * (NT)) * a.plane + (unsigned)((oy_ + 1) * a.pitch + ox_ + 1) * 32u); \
         _Pragma("unroll") for (int n = 0; n < NS; n++) {                                                     \
             float v_[16];                                                                                    \
             _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                  \
@@ -204,39 +218,46 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
         }                                                                                                    \
     }
 
-    // ---- prologue: bias / slopes, weight chunk 0, halo chunk 0 of the first tile
-    if (r == 7 && lane < T64_BSB / 16 && !(TAG & T64_NODMA)) t64_glds16(a.img + T64_WB + lane * 16, lds + T64_LDS_BS);
+    // ---- prologue: bias / slopes, weight chunk 0, halo chunk 0 of the first work item
+#define T64_DMA_BS(NT, BUF)                                                                                  \
+    if (r == 7 && lane < T64_BSB / 16 && !(TAG & T64_NODMA))                                                 \
+        t64_glds16(a.img + ((NT) * imgstride + a.nchunks * T64_WCH) + lane * 16, lds + T64_LDS_BS + (BUF) * T64_BSB);
     if (TAG & T64_NODMA) { for (int i = tid; i < T64_LDS / 16; i += T64_NTHR) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    T64_DMA_W(0, 0)
-    if (mine > 0) T64_DMA_IN(tb, 0, 0)
+    if (mine > 0) { T64_DMA_BS(nt, 0) T64_DMA_W(nt, 0, 0) T64_DMA_IN(tb, 0, 0) }
     T64_SYNC()
 
-    constexpr int NCH = 2 * NS;                                          // K chunks per tile (even: chunk c always sits in buffer c & 1)
-    for (int k = 0; k < mine; k++) {
-        const int Tn = a.reverse ? a.ntiles - 1 - (slot + (k + 1) * nwg) : slot + (k + 1) * nwg;
-        const bool more = k + 1 < mine;
-        int oy0n = 0, ox0n = 0;
-        unsigned tbn = 0;
-        if (more) { const int ty = Tn / a.tiles_x; oy0n = ty * T64_TH; ox0n = (Tn - ty * a.tiles_x) * 32; tbn = (unsigned)(oy0n * a.pitch + ox0n) * 32u; }
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            // step c: send chunk c + 1 (or the next tile's chunk 0) and its weights to the other buffers, then the matrix work of chunk c
-            if (c + 1 < NCH) { T64_DMA_IN(tb, c + 1, (c + 1) & 1) T64_DMA_W(c + 1, (c + 1) & 1) }
-            else if (more) { T64_DMA_IN(tbn, 0, 0) T64_DMA_W(0, 0) }
-            if (c == 0) {
-                if (k > 0) T64_EPILOGUE(poy0, pox0)
-#pragma unroll
-                for (int n = 0; n < NS; n++)
-#pragma unroll
-                    for (int q = 0; q < 16; q++) acc[n][q] = 0.f;
-            }
-            T64_TAPS(c, c & 1)
-            T64_SYNC()
-        }
-        poy0 = oy0; pox0 = ox0;
-        oy0 = oy0n; ox0 = ox0n; tb = tbn;
+    // one step = one K chunk of one work item: send chunk c + 1 (or the next item's chunk 0) and its weights to the other buffers, then
+    // the matrix work of chunk c.  The chunk count is even, so chunk c always sits in buffer c & 1.
+#define T64_STEP(C, PAR, LAST)                                                                               \
+    {                                                                                                        \
+        if (!(LAST)) { T64_DMA_IN(tb, (C) + 1, (PAR) ^ 1) T64_DMA_W(nt, (C) + 1, (PAR) ^ 1) }                \
+        else if (more) { T64_DMA_IN(tbn, 0, 0) T64_DMA_W(ntn, 0, 0) }                                        \
+        if ((C) == 1 && more) T64_DMA_BS(ntn, (k + 1) & 1)      /* that buffer served the epilogue of item k - 1 during step 0 */ \
+        if ((C) == 0) {                                                                                      \
+            if (k > 0) T64_EPILOGUE(poy0, pox0, pnt, (k - 1) & 1)                                            \
+            _Pragma("unroll") for (int n = 0; n < NS; n++)                                                   \
+                _Pragma("unroll") for (int q = 0; q < 16; q++) acc[n][q] = 0.f;                              \
+        }                                                                                                    \
+        const int idn_ = ((C) >> 1) - nt * NS;                                                               \
+        T64_TAPS(C, PAR, (idn_ >= 0 && idn_ < NS) ? idn_ : -1)                                               \
+        T64_SYNC()                                                                                           \
     }
-    if (mine > 0) T64_EPILOGUE(poy0, pox0)
+    for (int k = 0; k < mine; k++) {
+        const bool more = k + 1 < mine;
+        int oy0n = 0, ox0n = 0, ntn = 0;
+        unsigned tbn = 0;
+        if (more) T64_ITEM(slot + (k + 1) * nwg, oy0n, ox0n, tbn, ntn)
+        for (int c = 0; c < a.nchunks; c += 2) {
+            T64_STEP(c, 0, false)
+            T64_STEP(c + 1, 1, c + 2 >= a.nchunks)
+        }
+        poy0 = oy0; pox0 = ox0; pnt = nt;
+        oy0 = oy0n; ox0 = ox0n; tb = tbn; nt = ntn;
+    }
+    if (mine > 0) T64_EPILOGUE(poy0, pox0, pnt, (mine - 1) & 1)
+#undef T64_ITEM
+#undef T64_DMA_BS
+#undef T64_STEP
 #undef T64_STAMP
 #undef T64_DMA_IN
 #undef T64_DMA_W

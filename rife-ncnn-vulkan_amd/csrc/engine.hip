@@ -174,35 +174,41 @@ static std::vector<uint16_t> pack_weights_h2(const ConvLayer& L, const float* w,
 // pack_weights_h2 with the output rows of every 32-row MFMA block permuted by s16_row_channel(): conv_h2s2_kernel<NS, true>
 static std::vector<uint16_t> pack_weights_h2_perm(const ConvLayer& L, const float* w) {
     const int NT = L.NS * 32, nch = (L.cin + 15) / 16;
-    std::vector<uint16_t> out((size_t)nch * 9 * 2 * NT * 8, 0);
+    std::vector<uint16_t> out((size_t)L.ntiles * nch * 9 * 2 * NT * 8, 0);
     size_t o = 0;
-    for (int ch = 0; ch < nch; ch++)
-        for (int t = 0; t < 9; t++)
-            for (int half = 0; half < 2; half++)
-                for (int n = 0; n < NT; n++)
-                    for (int e = 0; e < 8; e++, o++) {
-                        const int c = ch * 16 + half * 8 + e, oc = (n & ~31) + s16_row_channel(n & 31);
-                        if (oc < L.cout && c < L.cin) out[o] = f2h(w[((size_t)oc * L.cin + c) * 9 + t]);
-                    }
+    for (int nt = 0; nt < L.ntiles; nt++)
+        for (int ch = 0; ch < nch; ch++)
+            for (int t = 0; t < 9; t++)
+                for (int half = 0; half < 2; half++)
+                    for (int n = 0; n < NT; n++)
+                        for (int e = 0; e < 8; e++, o++) {
+                            const int c = ch * 16 + half * 8 + e, oc = nt * NT + (n & ~31) + s16_row_channel(n & 31);
+                            if (oc < L.cout && c < L.cin) out[o] = f2h(w[((size_t)oc * L.cin + c) * 9 + t]);
+                        }
     return out;
 }
 
-// Weight image of conv_t64_kernel (conv_t64.h): fp16 weights [chunk C/16][tap 9][k half 2][row C][8] with the rows of each
-// 32-row block permuted by s16_row_channel() (every chunk is one contiguous LDS-DMA source), then bias[C] and slope[C] as fp32.
+// Weight image of conv_t64_kernel (conv_t64.h) for a C -> C layer: N-tiles of NT = 32 NS output channels (C = 64, 96: one N-tile of C;
+// C = 128, 192: N-tiles of 64); per N-tile fp16 weights [chunk C/16][tap 9][k half 2][row NT][8] with the rows of each 32-row block
+// permuted by s16_row_channel() (every chunk is one contiguous LDS-DMA source), then that N-tile's bias[NT] and slope[NT] as fp32.
+static int t64_ns(int C) { return C == 96 ? 3 : 2; }
 static std::vector<unsigned char> pack_t64_image(const float* w, const float* bias, float slope, int C = 64) {
-    const int NS = C / 32;
-    std::vector<unsigned char> img(t64_img(NS), 0);
-    uint16_t* wh = reinterpret_cast<uint16_t*>(img.data());
-    for (int c = 0; c < C / 16; c++)
-        for (int t = 0; t < 9; t++)
-            for (int kh = 0; kh < 2; kh++)
-                for (int row = 0; row < C; row++)
-                    for (int e = 0; e < 8; e++) {
-                        const int oc = (row & ~31) + s16_row_channel(row & 31), ic = 16 * c + 8 * kh + e;
-                        wh[((((size_t)c * 9 + t) * 2 + kh) * C + row) * 8 + e] = f2h(w[((size_t)oc * C + ic) * 9 + t]);
-                    }
-    float* bs = reinterpret_cast<float*>(img.data() + t64_wb(NS));
-    for (int i = 0; i < C; i++) { bs[i] = bias ? bias[i] : 0.f; bs[C + i] = slope; }
+    const int NS = t64_ns(C), NT = 32 * NS, nnt = C / NT, nch = C / 16;
+    const size_t stride = t64_img_nt(NS, nch);
+    std::vector<unsigned char> img(stride * nnt, 0);
+    for (int nt = 0; nt < nnt; nt++) {
+        uint16_t* wh = reinterpret_cast<uint16_t*>(img.data() + nt * stride);
+        for (int c = 0; c < nch; c++)
+            for (int t = 0; t < 9; t++)
+                for (int kh = 0; kh < 2; kh++)
+                    for (int row = 0; row < NT; row++)
+                        for (int e = 0; e < 8; e++) {
+                            const int oc = nt * NT + (row & ~31) + s16_row_channel(row & 31), ic = 16 * c + 8 * kh + e;
+                            wh[((((size_t)c * 9 + t) * 2 + kh) * NT + row) * 8 + e] = f2h(w[((size_t)oc * C + ic) * 9 + t]);
+                        }
+        float* bs = reinterpret_cast<float*>(img.data() + nt * stride + (size_t)nch * t64_wch(NS));
+        for (int i = 0; i < NT; i++) { bs[i] = bias ? bias[nt * NT + i] : 0.f; bs[NT + i] = slope; }
+    }
     return img;
 }
 
@@ -298,7 +304,7 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
             HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
             L.nchunksh = L.cin / 16;
-            if (L.want_s16out && L.ntiles == 1 && L.cout % 32 == 0) {
+            if (L.want_s16out && L.cout % (L.NS * 32) == 0) {
                 std::vector<uint16_t> pp = pack_weights_h2_perm(L, w_orig);
                 HIPCHK(hipMalloc(&L.d_whp, pp.size() * 2));
                 HIPCHK(hipMemcpy(L.d_whp, pp.data(), pp.size() * 2, hipMemcpyHostToDevice));
@@ -624,7 +630,7 @@ struct S16Geom {
 // first rows of a layer's input were written more than a cache-full of traffic ago by the time they are read).
 static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool reverse = false) {
     if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_t64 image");
-    const int NS = L.cout / 32;
+    const int NS = t64_ns(L.cout);
     int dev = 0; (void)hipGetDevice(&dev);
     static std::mutex mu; static std::map<int, int> ncu;
     int cus;
@@ -643,9 +649,10 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
     const S16Geom G(H, W);
     T64Args a;
     a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y; a.reverse = reverse ? 1 : 0;
-    const int nwg = std::min(t64_wg_per_cu(NS) * cus, (a.ntiles + 7) / 8 * 8);      // all workgroups resident at once
-    if (NS == 2) hipLaunchKernelGGL((conv_t64_kernel<3, 2>), dim3(nwg), dim3(T64_NTHR), t64_lds(2), st, a);       // TAG: the profile class (trunk_b3 / trunk_b2)
-    else if (NS == 3) hipLaunchKernelGGL((conv_t64_kernel<2, 3>), dim3(nwg), dim3(T64_NTHR), t64_lds(3), st, a);
+    a.nchunks = L.cout / 16; a.nnt = L.cout / (32 * NS);
+    const int nwg = std::min(t64_wg_per_cu(NS) * cus, (a.ntiles * a.nnt + 7) / 8 * 8);      // all workgroups resident at once
+    if (L.cout == 64) hipLaunchKernelGGL((conv_t64_kernel<3, 2>), dim3(nwg), dim3(T64_NTHR), t64_lds(2), st, a);       // TAG: the profile class (trunk_b3 .. trunk_b0)
+    else if (L.cout == 96) hipLaunchKernelGGL((conv_t64_kernel<2, 3>), dim3(nwg), dim3(T64_NTHR), t64_lds(3), st, a);
     else return fail(RIFE_HIP_EINVAL, "conv_t64 serves 64 and 96 channels");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_t64 launch: ") + hipGetErrorString(e));
@@ -715,8 +722,7 @@ struct Ctx {
     uint32_t *img0 = nullptr, *img1 = nullptr;                       // padded RGBX u8
     float *X = nullptr, *S1 = nullptr, *T0 = nullptr, *T1 = nullptr; // block input, stem-1 output, trunk ping/pong
     float *T2 = nullptr;                                             // rife-v4 (4.0): stem-1 output kept for the block's residual add
-    unsigned char *P0 = nullptr, *P1 = nullptr;                      // block 3 trunk ping / pong as S16 tensors (conv_t64.h), zero borders
-    unsigned char *Q0 = nullptr, *Q1 = nullptr;                      // block 2 trunk (96 channels at 1/8 resolution), likewise
+    unsigned char* P[4][2] = {};                                     // per block: trunk ping / pong as S16 tensors (conv_t64.h), zero borders
     float* flow[4] = {nullptr, nullptr, nullptr, nullptr};           // [hp/s][wp/s][8]
     float4* F = nullptr; float* M = nullptr;                         // full-resolution flow (4ch) and mask logit
     float4* outf = nullptr;                                          // TTA only: out0 as float, padded
@@ -880,19 +886,17 @@ static int ensure_ctx_dims_impl(Ctx& c, int w, int h, int wp, int hp, const Ctx*
         if ((rc = dalloc(c, c.T1, P / 16 * 64))) return rc;
         if ((rc = dalloc(c, c.T2, P / 16 * 64))) return rc;
     }
-    {   // S16 trunk tensors of the finest block; never borrowed: the zero border belongs to THIS geometry
-        const S16Geom G(hp / 4, wp / 4);
-        const size_t nb = G.bytes(64);
-        if ((rc = dalloc(c, c.P0, nb))) return rc;
-        if ((rc = dalloc(c, c.P1, nb))) return rc;
-        if (c.stream) { HIPCHK(hipMemsetAsync(c.P0, 0, nb, c.stream)); HIPCHK(hipMemsetAsync(c.P1, 0, nb, c.stream)); }
-        else { HIPCHK(hipMemset(c.P0, 0, nb)); HIPCHK(hipMemset(c.P1, 0, nb)); }
-        const S16Geom G2(hp / 8, wp / 8);
-        const size_t nb2 = G2.bytes(96);
-        if ((rc = dalloc(c, c.Q0, nb2))) return rc;
-        if ((rc = dalloc(c, c.Q1, nb2))) return rc;
-        if (c.stream) { HIPCHK(hipMemsetAsync(c.Q0, 0, nb2, c.stream)); HIPCHK(hipMemsetAsync(c.Q1, 0, nb2, c.stream)); }
-        else { HIPCHK(hipMemset(c.Q0, 0, nb2)); HIPCHK(hipMemset(c.Q1, 0, nb2)); }
+    {   // S16 trunk tensors of the four blocks (192 / 128 / 96 / 64 channels at 1/32 .. 1/4 resolution); never borrowed: the zero border belongs to THIS geometry
+        static const int CB[4] = {192, 128, 96, 64}, SB[4] = {32, 16, 8, 4};
+        for (int b = 2; b < 4; b++) {
+            const S16Geom G(hp / SB[b], wp / SB[b]);
+            const size_t nb = G.bytes(CB[b]);
+            for (int k = 0; k < 2; k++) {
+                if ((rc = dalloc(c, c.P[b][k], nb))) return rc;
+                if (c.stream) HIPCHK(hipMemsetAsync(c.P[b][k], 0, nb, c.stream));
+                else HIPCHK(hipMemset(c.P[b][k], 0, nb));
+            }
+        }
     }
     static const int sc[4] = {8, 4, 2, 1};
     for (int b = 0; b < 4; b++) {
@@ -917,7 +921,7 @@ static void reset_ctx(Ctx& c) {
     if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
     for (void* p : c.allocs) (void)hipFree(p);
     c.allocs.clear();
-    c.w = c.h = c.wp = c.hp = 0; c.v2 = false; c.outf = nullptr; c.d_ts = nullptr; c.g_warm = false; c.P0 = c.P1 = c.Q0 = c.Q1 = nullptr;
+    c.w = c.h = c.wp = c.hp = 0; c.v2 = false; c.outf = nullptr; c.d_ts = nullptr; c.g_warm = false; for (auto& pb : c.P) pb[0] = pb[1] = nullptr;
 }
 static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scratch = nullptr, bool own_images = true, bool want_outf = false) {
     const int rc = ensure_ctx_dims_impl(c, w, h, wp, hp, scratch, own_images, want_outf);
@@ -990,12 +994,15 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         if ((rc = launch_conv(B.stem0, {c.X, xin_ld, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, nullptr, st))) return rc;
     }
     const int Ht = Hb / 4, Wt = Wb / 4;
-    // blocks 3 (64 ch) and 2 (96 ch): S16 tensors + the persistent trunk kernel; block 2 only when its grid fills a good part of the chip
-    // (16 launches of a few workgroups each are served better by the per-tile kernels with their 4-row / split-K variants)
-    unsigned char* const PA = b == 3 ? c.P0 : c.Q0;
-    unsigned char* const PB = b == 3 ? c.P1 : c.Q1;
-    bool s16 = E.t64 && !E.v40 && ((b == 3 && B.c == 64) || (b == 2 && B.c == 96 && E.t64_b2 && ((Ht + 7) / 8) * ((Wt + 31) / 32) >= 96)) && g_trunk_h2 && PA &&
-               B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS;
+    // S16 tensors + the persistent trunk kernel (conv_t64.h).  Block 2 (96 channels, one workgroup per CU) only when its grid fills a good
+    // part of the chip.  Blocks 1 / 0 (128 / 192 channels) were measured on the same kernel as N-tiles of 64 output channels ((pixel tile,
+    // N-tile) work items, 8 / 12 K chunks): 4K trunk_b1 0.300 vs 0.285 ms per pair, trunk_b0 0.228 vs 0.206 - a work item is a chain of 8 - 12
+    // dependent steps whose fixed cost (DMA issue + landing + barrier) exceeds its matrix work at these sizes - so they stay on the per-tile kernels
+    unsigned char* const PA = c.P[b][0];
+    unsigned char* const PB = c.P[b][1];
+    const int ptiles = ((Ht + 7) / 8) * ((Wt + 31) / 32);
+    bool s16 = E.t64 && !E.v40 && g_trunk_h2 && PA && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS &&
+               ((b == 3 && B.c == 64) || (b == 2 && B.c == 96 && E.t64_b2 && ptiles >= 96));
     for (int i = 0; i < 8 && s16; i++) s16 = B.res[i].d_t64 != nullptr;
     if (s16) {
         // stem-1 writes the first S16 tensor, eight persistent trunk launches ping-pong between the two, the head reads the last one
@@ -1918,7 +1925,7 @@ static int rife_hip_load_impl(rife_hip_t* E, const char* modeldir) {
             L.tag = std::strcmp(cls, "trunk_b3") == 0 ? 3 : 0;
             L.skip = fold_skip;
             L.want_t64 = fold_skip && cin == cout && (cout == 64 || cout == 96);
-            L.want_s16out = !deconv && stride == 2 && ((cout == 64 && b == 3) || (cout == 96 && b == 2));
+            L.want_s16out = !deconv && stride == 2 && cout == C[b] && b >= 2;
             return upload_layer(L, nl->weight.data(), nl->bias.data(), nullptr, slope);
         };
         std::snprintf(name, sizeof name, "stem0_b%d", b);
