@@ -27,6 +27,7 @@
 #include "stem_fused.h"
 #include "head_h2.h"
 #include "conv_t64.h"
+#include "conv_row.h"
 #include "graph_kernels.h"
 #include "model_hashes.h"
 #include "ncnn_model.h"
@@ -192,8 +193,9 @@ static std::vector<uint16_t> pack_weights_h2_perm(const ConvLayer& L, const floa
 // C = 128, 192: N-tiles of 64); per N-tile fp16 weights [chunk C/16][tap 9][k half 2][row NT][8] with the rows of each 32-row block
 // permuted by s16_row_channel() (every chunk is one contiguous LDS-DMA source), then that N-tile's bias[NT] and slope[NT] as fp32.
 static int t64_ns(int C) { return C == 96 ? 3 : 2; }
-static std::vector<unsigned char> pack_t64_image(const float* w, const float* bias, float slope, int C = 64) {
-    const int NS = t64_ns(C), NT = 32 * NS, nnt = C / NT, nch = C / 16;
+// NSf > 0 forces the N-tile width (conv_row_kernel: NSf = 1, one 32-channel output block per wave)
+static std::vector<unsigned char> pack_t64_image(const float* w, const float* bias, float slope, int C = 64, int NSf = 0) {
+    const int NS = NSf > 0 ? NSf : t64_ns(C), NT = 32 * NS, nnt = C / NT, nch = C / 16;
     const size_t stride = t64_img_nt(NS, nch);
     std::vector<unsigned char> img(stride * nnt, 0);
     for (int nt = 0; nt < nnt; nt++) {
@@ -326,8 +328,8 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
             HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
             L.nchunksh = L.cin / 16;
-            if (L.want_t64 && L.skip && L.cin == L.cout && (L.cout == 64 || L.cout == 96) && !slope) {
-                std::vector<unsigned char> img = pack_t64_image(w_orig, bias, uniform_slope, L.cout);
+            if (L.want_t64 && L.skip && L.cin == L.cout && (L.cout == 64 || L.cout == 96 || L.cout == 128 || L.cout == 192) && !slope) {
+                std::vector<unsigned char> img = pack_t64_image(w_orig, bias, uniform_slope, L.cout, L.cout >= 128 ? 1 : 0);
                 HIPCHK(hipMalloc(&L.d_t64, img.size()));
                 HIPCHK(hipMemcpy(L.d_t64, img.data(), img.size(), hipMemcpyHostToDevice));
             }
@@ -659,6 +661,30 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
     return 0;
 }
 
+// one C -> C (C = 128, 192) residual trunk convolution of a coarse block, S16 in / S16 out: one workgroup per ROWS x 32 pixels (conv_row.h)
+static int launch_row(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st) {
+    if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_row image");
+    {
+        int dev = 0; (void)hipGetDevice(&dev);
+        static std::mutex mu; static std::map<int, bool> done;
+        std::lock_guard<std::mutex> g(mu);
+        if (!done[dev]) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_row_kernel<192, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (convrow_lds_bytes<192, 1>())));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_row_kernel<128, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (convrow_lds_bytes<128, 2>())));
+            done[dev] = true;
+        }
+    }
+    const S16Geom G(H, W);
+    RowArgs a;
+    a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x;
+    if (L.cout == 192) { a.ntiles = a.tiles_x * H; hipLaunchKernelGGL((conv_row_kernel<192, 1, 0>), dim3(a.ntiles), dim3(384), (convrow_lds_bytes<192, 1>()), st, a); }
+    else if (L.cout == 128) { a.ntiles = a.tiles_x * ((H + 1) / 2); hipLaunchKernelGGL((conv_row_kernel<128, 2, 1>), dim3(a.ntiles), dim3(256), (convrow_lds_bytes<128, 2>()), st, a); }
+    else return fail(RIFE_HIP_EINVAL, "conv_row serves 128 and 192 channels");
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_row launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // profiler (rife_hip_profile_*): HIP events on the launch stream around every kernel
 // ------------------------------------------------------------------------------------------------
@@ -811,6 +837,7 @@ struct rife_hip {
     // finest-block trunk on S16 tensors + the persistent conv_t64 kernel (RIFE_HIP_T64=0 at create time keeps conv_h2b: A/B and
     // the bit-equality test of the two trunk implementations)
     bool t64 = true;
+    int rowk = 3;                            // RIFE_HIP_ROWK at create time: bit 0 = block 1, bit 1 = block 0 on conv_row_kernel (A/B)
     bool t64_b2 = true;                      // RIFE_HIP_T64_B2=0 at create time: block 2 (96 channels) stays on the per-tile trunk kernel (A/B)
     bool t64_alternate = true;               // RIFE_HIP_T64_ALT=0 at create time: every trunk layer walks its tiles first to last (A/B)
     int flow_div(int b) const { return v40 ? 2 * blk[b].scale : blk[b].scale; }
@@ -888,7 +915,7 @@ static int ensure_ctx_dims_impl(Ctx& c, int w, int h, int wp, int hp, const Ctx*
     }
     {   // S16 trunk tensors of the four blocks (192 / 128 / 96 / 64 channels at 1/32 .. 1/4 resolution); never borrowed: the zero border belongs to THIS geometry
         static const int CB[4] = {192, 128, 96, 64}, SB[4] = {32, 16, 8, 4};
-        for (int b = 2; b < 4; b++) {
+        for (int b = 0; b < 4; b++) {
             const S16Geom G(hp / SB[b], wp / SB[b]);
             const size_t nb = G.bytes(CB[b]);
             for (int k = 0; k < 2; k++) {
@@ -994,15 +1021,18 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         if ((rc = launch_conv(B.stem0, {c.X, xin_ld, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, nullptr, st))) return rc;
     }
     const int Ht = Hb / 4, Wt = Wb / 4;
-    // S16 tensors + the persistent trunk kernel (conv_t64.h).  Block 2 (96 channels, one workgroup per CU) only when its grid fills a good
-    // part of the chip.  Blocks 1 / 0 (128 / 192 channels) were measured on the same kernel as N-tiles of 64 output channels ((pixel tile,
-    // N-tile) work items, 8 / 12 K chunks): 4K trunk_b1 0.300 vs 0.285 ms per pair, trunk_b0 0.228 vs 0.206 - a work item is a chain of 8 - 12
-    // dependent steps whose fixed cost (DMA issue + landing + barrier) exceeds its matrix work at these sizes - so they stay on the per-tile kernels
+    // S16 trunk tensors: blocks 3 / 2 on the persistent LDS-DMA kernel (conv_t64.h; block 2 only when its grid fills a good part of the
+    // chip), the coarse blocks 1 / 0 on the one-pass row kernel (conv_row.h).  (Blocks 1 / 0 as N-tiles of 64 output channels on the
+    // persistent kernel were measured too: 4K trunk_b1 0.300 vs 0.285 ms per pair, trunk_b0 0.228 vs 0.206 - a chain of 8 - 12 dependent
+    // steps whose fixed cost exceeds a step's matrix work at these sizes.)
     unsigned char* const PA = c.P[b][0];
     unsigned char* const PB = c.P[b][1];
     const int ptiles = ((Ht + 7) / 8) * ((Wt + 31) / 32);
+    // block 0 on the row kernel only while its grid is small: at 4K all 272 workgroups stream the same 663 KB of weights through the L2 at
+    // once (0.239 vs 0.208 ms per pair for the per-tile kernel), at 1080p (68 workgroups) it wins (0.133 vs 0.152); block 1 wins at both
+    const bool rowk = (b == 1 && B.c == 128 && (E.rowk & 1)) || (b == 0 && B.c == 192 && (E.rowk & 2) && ((Wt + 31) / 32) * Ht <= 160);
     bool s16 = E.t64 && !E.v40 && g_trunk_h2 && PA && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS &&
-               ((b == 3 && B.c == 64) || (b == 2 && B.c == 96 && E.t64_b2 && ptiles >= 96));
+               ((b == 3 && B.c == 64) || (b == 2 && B.c == 96 && E.t64_b2 && ptiles >= 96) || rowk);
     for (int i = 0; i < 8 && s16; i++) s16 = B.res[i].d_t64 != nullptr;
     if (s16) {
         // stem-1 writes the first S16 tensor, eight persistent trunk launches ping-pong between the two, the head reads the last one
@@ -1014,7 +1044,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         unsigned char *pc = PA, *pn = PB;
         for (int i = 0; i < 8; i++) {
             Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
-            if ((rc = launch_t64(B.res[i], pc, pn, Ht, Wt, st, E.t64_alternate && (i & 1) == 0))) return rc;
+            if ((rc = rowk ? launch_row(B.res[i], pc, pn, Ht, Wt, st) : launch_t64(B.res[i], pc, pn, Ht, Wt, st, E.t64_alternate && (i & 1) == 0))) return rc;
             std::swap(pc, pn);
         }
         Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);
@@ -1838,6 +1868,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_T64_ALT"); E->t64_alternate = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_T64_B2"); E->t64_b2 = !(e && e[0] == '0'); }
+    { const char* e = getenv("RIFE_HIP_ROWK"); if (e) E->rowk = atoi(e); }
     return E;
 }
 
@@ -1924,8 +1955,8 @@ static int rife_hip_load_impl(rife_hip_t* E, const char* modeldir) {
             L.cin = cin; L.cout = cout; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi; L.cls = cls;
             L.tag = std::strcmp(cls, "trunk_b3") == 0 ? 3 : 0;
             L.skip = fold_skip;
-            L.want_t64 = fold_skip && cin == cout && (cout == 64 || cout == 96);
-            L.want_s16out = !deconv && stride == 2 && cout == C[b] && b >= 2;
+            L.want_t64 = fold_skip && cin == cout;
+            L.want_s16out = !deconv && stride == 2 && cout == C[b];
             return upload_layer(L, nl->weight.data(), nl->bias.data(), nullptr, slope);
         };
         std::snprintf(name, sizeof name, "stem0_b%d", b);
