@@ -837,6 +837,7 @@ struct rife_hip {
     // finest-block trunk on S16 tensors + the persistent conv_t64 kernel (RIFE_HIP_T64=0 at create time keeps conv_h2b: A/B and
     // the bit-equality test of the two trunk implementations)
     bool t64 = true;
+    bool stem_occ = true;                    // RIFE_HIP_STEM_OCC=0 at create time: the fused stem of block 3 with padded 80-byte records, two workgroups per CU (A/B)
     int rowk = 3;                            // RIFE_HIP_ROWK at create time: bit 0 = block 1, bit 1 = block 0 on conv_row_kernel (A/B)
     bool t64_b2 = true;                      // RIFE_HIP_T64_B2=0 at create time: block 2 (96 channels) stays on the per-tile trunk kernel (A/B)
     bool t64_alternate = true;               // RIFE_HIP_T64_ALT=0 at create time: every trunk layer walks its tiles first to last (A/B)
@@ -1013,6 +1014,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         }
         if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
         else if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+        else if (E.stem_occ) hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);
         else hipLaunchKernelGGL((stem0_fused_kernel<1, 1>), dim3(nb), dim3(512), stemf_lds_bytes<1>(), st, fa);
         HIPCHK(hipGetLastError());
     } else {
@@ -1869,6 +1871,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     { const char* e = getenv("RIFE_HIP_T64_ALT"); E->t64_alternate = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_T64_B2"); E->t64_b2 = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_ROWK"); if (e) E->rowk = atoi(e); }
+    { const char* e = getenv("RIFE_HIP_STEM_OCC"); E->stem_occ = !(e && e[0] == '0'); }
     return E;
 }
 

@@ -26,13 +26,15 @@ struct StemFusedArgs {
 
 // LDS pixel record: 32 B hi + 32 B lo (+ 16 B pad: 80-byte records are conflict-free for the 16-byte staging writes and 2-way for
 // the stride-2 operand reads; 64-byte records are 4-way / 8-way).  ABL bit 128 selects the unpadded record for A/B runs.
-template <int ABL> constexpr int stemf_pixb() { return (ABL & 128) ? 64 : 80; }
+template <int ABL> constexpr int stemf_pixb() { return (ABL & (128 | 256)) ? 64 : 80; }
 template <int NS, int ABL = 0>
 constexpr int stemf_lds_bytes() { return 9 * 65 * stemf_pixb<ABL>() + 9 * 2 * NS * 32 * 16; }
 
 // ABL (bench only): 1 = skip MFMA + epilogue, 2 = second halo pixel in a second round, 16 = skip stores, 32 = skip MFMAs, 64 = direct-store epilogue, 128 = 64-byte LDS records
+// ABL 256: 64-byte records with the 16-byte quarters XOR-swizzled by pixel index (quarter q of pixel P at position q ^ ((P >> 2) & 3): 2-way on the
+// stride-2 operand reads like the padded records, conflict-free staging writes) -> 46.6 KB for NS = 1: three workgroups (24 waves) per CU
 template <int S, int NS, int ABL = 0>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem0_fused_kernel(StemFusedArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((ABL & 256) ? 6 : 4, (ABL & 256) ? 6 : 4))) void stem0_fused_kernel(StemFusedArgs a) {
     constexpr int IH = 9, IW = 65, PIXB = stemf_pixb<ABL>(), NT = NS * 32;
     constexpr int NPIX = IH * IW;
     constexpr int W_16 = 9 * 2 * NT;
@@ -81,8 +83,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             h1[c] = hb; l1[c] = (_Float16)(vb - (float)hb);                                                       \
         }                                                                                                         \
         unsigned char* dst = ldsb + (P) * PIXB;                                                                   \
-        *reinterpret_cast<f16x8*>(dst) = h0; *reinterpret_cast<f16x8*>(dst + 16) = h1;                            \
-        *reinterpret_cast<f16x8*>(dst + 32) = l0; *reinterpret_cast<f16x8*>(dst + 48) = l1;                       \
+        const int sw_ = (ABL & 256) ? (((P) >> 2) & 3) : 0;                                                       \
+        *reinterpret_cast<f16x8*>(dst + ((0 ^ sw_) << 4)) = h0; *reinterpret_cast<f16x8*>(dst + ((1 ^ sw_) << 4)) = h1; \
+        *reinterpret_cast<f16x8*>(dst + ((2 ^ sw_) << 4)) = l0; *reinterpret_cast<f16x8*>(dst + ((3 ^ sw_) << 4)) = l1; \
     }
     if (wv8 < 2 && !(ABL & 2)) {
         float o0[12], o1[12];
@@ -113,8 +116,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int t = 0; t < 9; t++) {
         const int dy = t / 3, dx = t % 3;
-        const f16x8 ah = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB);
-        const f16x8 al = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB + 32);
+        f16x8 ah, al;
+        if (ABL & 256) {
+            const int P = (2 * wv + dy) * IW + 2 * li + dx;
+            const int ph = half ^ ((P >> 2) & 3);
+            ah = *reinterpret_cast<const f16x8*>(ldsb + P * 64 + (ph << 4));
+            al = *reinterpret_cast<const f16x8*>(ldsb + P * 64 + ((ph ^ 2) << 4));
+        } else {
+            ah = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB);
+            al = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB + 32);
+        }
         const f16x8 bw = *reinterpret_cast<const f16x8*>(bb + (t * 2 * NT) * 16);
         if (ABL & 32) { acc[0] += (float)ah[0] + (float)al[1] + (float)bw[2]; continue; }     // ablation: LDS reads without the matrix pipe
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, ah, acc, 0, 0, 0);
