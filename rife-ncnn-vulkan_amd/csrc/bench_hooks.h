@@ -310,6 +310,7 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
     const bool alternate = (variant & 0x10000) != 0; variant &= ~0x10000;
     const int nwg = std::min(t64_wg_per_cu(2) * (cus / 8 * 8), (a.ntiles + 7) / 8 * 8);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    long long* clk_base = nullptr;
     auto run = [&](auto kfn) -> int {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, T64_LDS));
         for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(T64_NTHR), T64_LDS, 0, a);
@@ -317,6 +318,7 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
         for (int i = 0; i < iters; i++) {
             a.in = (i & 1) ? y : x; a.out = (i & 1) ? x : y;
             a.reverse = alternate ? (i & 1) : 0;
+            if (clk_base) a.stamps = clk_base + (size_t)std::min(i, 255) * nwg * 4;     // clock probe: launches 0 .. 254 keep their own records
             hipLaunchKernelGGL(kfn, dim3(nwg), dim3(T64_NTHR), T64_LDS, 0, a);
         }
         HIPCHK(hipEventRecord(e1, 0));
@@ -325,7 +327,42 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
         *ms_out = t / iters;
         return 0;
     };
-    if (variant == T64_STAMPS) {
+    if (variant & T64_CLK) {       // shader clock during the launch: per workgroup (cycles, 100 MHz ticks) -> stderr
+        HIPCHK(hipMalloc(&clk_base, (size_t)nwg * 32 * 256));
+        HIPCHK(hipMemset(clk_base, 0, (size_t)nwg * 32 * 256));
+        a.stamps = clk_base;
+        switch (variant & ~T64_CLK) {
+            case 0: rc = run(conv_t64_kernel<T64_CLK>); break;
+            case T64_NOSTORE: rc = run(conv_t64_kernel<T64_CLK | T64_NOSTORE>); break;
+            case T64_NODMA: rc = run(conv_t64_kernel<T64_CLK | T64_NODMA>); break;
+            case T64_NOMATH: rc = run(conv_t64_kernel<T64_CLK | T64_NOMATH>); break;
+            case T64_NODMA | T64_NOSTORE: rc = run(conv_t64_kernel<T64_CLK | T64_NODMA | T64_NOSTORE>); break;
+            case T64_NOMATH | T64_NOSTORE: rc = run(conv_t64_kernel<T64_CLK | T64_NOMATH | T64_NOSTORE>); break;
+            case T64_NOMATH | T64_NODMA: rc = run(conv_t64_kernel<T64_CLK | T64_NOMATH | T64_NODMA>); break;
+            default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+        }
+        const int nl = std::min(iters, 255);
+        std::vector<long long> hs((size_t)nwg * 4 * nl);
+        HIPCHK(hipMemcpy(hs.data(), clk_base, hs.size() * 8, hipMemcpyDeviceToHost));
+        long long prev_end = 0;
+        fprintf(stderr, "t64 clk: variant 0x%x  launch: workgroup life median us | first start -> last end us | gap to the previous launch us | GHz\n", variant & ~T64_CLK);
+        for (int l = 0; l < nl; l++) {
+            const long long* p = hs.data() + (size_t)l * nwg * 4;
+            std::vector<long long> rt;
+            long long s0 = LLONG_MAX, e1 = 0, cyc = 0, tk = 0;
+            for (int i = 0; i < nwg; i++) {
+                rt.push_back(p[4 * i + 2] - p[4 * i + 1]); cyc += p[4 * i]; tk += p[4 * i + 2] - p[4 * i + 1];
+                s0 = std::min(s0, p[4 * i + 1]); e1 = std::max(e1, p[4 * i + 2]);
+            }
+            std::sort(rt.begin(), rt.end());
+            if (l < 4 || l % 20 == 0 || l == nl - 1)
+                fprintf(stderr, "   %3d: %.2f | %.2f | %.2f | %.3f\n", l, rt[nwg / 2] * 0.01, (e1 - s0) * 0.01, l ? (s0 - prev_end) * 0.01 : 0.0, (double)cyc / (double)tk * 0.1);
+            prev_end = e1;
+        }
+        char fn[64]; snprintf(fn, sizeof fn, "gpurun_out/t64_clk_%x.bin", variant & ~T64_CLK);
+        if (FILE* f = fopen(fn, "wb")) { fwrite(hs.data() + (size_t)(nl - 1) * nwg * 4, 8, (size_t)nwg * 4, f); fclose(f); }
+        (void)hipFree(clk_base);
+    } else if (variant == T64_STAMPS) {
         const size_t nst = (size_t)nwg * T64_TH * 32 * 4;
         HIPCHK(hipMalloc(&a.stamps, nst * 8));
         HIPCHK(hipMemset(a.stamps, 0, nst * 8));

@@ -30,6 +30,17 @@
 // group waited at the barrier for the other group's epilogue); one 16-wave workgroup, 16 x 32 tiles, ring of three halo
 // buffers with counted vmcnt waits (loads fully hidden, but all 16 epilogues collide: 86-91 us; best frame rate with two pairs
 // in flight, 409 vs 397 frames/s at 4K); 1-byte LDS-DMA "touches" that pull the chunk after next into the L2 (+5 us).
+// Round-2 probes (tools/t64_bench.py, profiles/r2/t64_bench.txt; T64_CLK records every workgroup's life on the 100 MHz counter and its shader
+// cycles): (1) the chip's clock is not constant under this kernel - a burst of launches starts at 1.77 GHz, sags to 1.2 GHz after ~3 ms (110 us
+// per launch), and settles at 2.0-2.05 GHz after ~12 ms: 68 us first-start-to-last-end + 3 us to the next launch; the same burst of the
+// matrix-only ablation holds 2.1-2.25 GHz, loads + stores only 2.25-2.37 GHz.  (2) Workgroup lives are bimodal: the first-placed workgroup of a
+// CU ends at ~51 us, the second-placed one at ~67 us (the older waves win the issue arbitration) - but that is no imbalance to fix: with the
+// second-placed workgroups at s_setprio 2 on every other tile both end at ~60-64 us and the launch still takes 68 us (the CU's total rate is the
+// limit), and per-XCD atomic tile counters (dynamic schedule; the reset by the last workgroup adds 4 us between launches, 4 tiles per workgroup
+// are too coarse to balance) measured 105 us.  (3) Issuing the DMA pieces one per tap between the MFMAs instead of all at the step start lets
+// the MFMAs start at once but stretches them from ~2,500 to ~4,500 cycles per step: same 84 us; epilogue stores before / after the DMA issue:
+// same.  (4) MFMAs on one fragment set per step (no LDS fragment reads) + loads = 65 us = with the reads (64 us): the LDS is not what keeps
+// loads and matrix work from overlapping.
 // LDS image of a halo chunk: hi plane [340 px][32 B] then lo plane [340 px][32 B]; the two 16-byte halves of a 32-byte entry are
 // swapped when bit 3 of the pixel index is set, which makes the ds_read_b128 fragment reads of 16 consecutive pixels hit 64
 // distinct banks (SQ_LDS_BANK_CONFLICT = 0).  The DMA writes LDS lane-linear, so the swap is applied to each lane's SOURCE
@@ -72,10 +83,11 @@ struct T64Args {
     int tiles_x, ntiles;         // pixel tiles
     int nchunks, nnt;            // K chunks (input channels / 16, even), N-tiles of 32 NS output channels; work items = ntiles * nnt
     int reverse;                 // 1: walk the tiles from the last to the first (see launch_t64: consecutive layers alternate)
-    long long* stamps = nullptr; // bench builds only (TAG & T64_STAMPS): [workgroup][wave 8][step 32][4] shader-clock stamps
+    long long* stamps = nullptr; // bench builds only: TAG & T64_STAMPS: [workgroup][wave 8][step 32][4] shader-clock stamps; TAG & T64_CLK: [workgroup][4] = shader
+                                 // cycles of the workgroup's life, its start and its end on the constant 100 MHz counter (tools/t64_bench.py)
 };
 // bench-only ablation bits of TAG (timing experiments; the results of all but T64_STAMPS are garbage).  The product instantiates TAG = 3.
-enum { T64_NOSTORE = 0x100, T64_NODMA = 0x200, T64_NOMATH = 0x400, T64_NOVMWAIT = 0x800, T64_STAMPS = 0x1000 };
+enum { T64_NOSTORE = 0x100, T64_NODMA = 0x200, T64_NOMATH = 0x400, T64_NOVMWAIT = 0x800, T64_STAMPS = 0x1000, T64_CLK = 0x40000 };
 
 typedef __attribute__((address_space(3))) unsigned char t64_lds_u8;
 typedef __attribute__((address_space(1))) const unsigned char t64_glb_u8;
@@ -92,6 +104,8 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
     const int tid = threadIdx.x, lane = tid & 63;
     const int r = __builtin_amdgcn_readfirstlane(tid >> 6);              // wave = output row of the tile (wave-uniform by construction)
     const int h = lane >> 5, li = lane & 31;
+    long long clk0 = 0, rt0 = 0;
+    if (TAG & T64_CLK) { clk0 = (long long)__builtin_readcyclecounter(); rt0 = (long long)__builtin_amdgcn_s_memrealtime(); }
 
     // ---- per-lane constants
     // halo DMA: piece i = r + 8 j of the chunk buffer covers LDS slots 64 i .. 64 i + 63 (16 bytes each)
@@ -255,6 +269,11 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
         oy0 = oy0n; ox0 = ox0n; tb = tbn; nt = ntn;
     }
     if (mine > 0) T64_EPILOGUE(poy0, pox0, pnt, (mine - 1) & 1)
+    if ((TAG & T64_CLK) && tid == 0) {
+        a.stamps[4 * blockIdx.x] = (long long)__builtin_readcyclecounter() - clk0;
+        a.stamps[4 * blockIdx.x + 1] = rt0;
+        a.stamps[4 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
 #undef T64_ITEM
 #undef T64_DMA_BS
 #undef T64_STEP

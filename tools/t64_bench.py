@@ -2,7 +2,9 @@
 
     python tools/t64_bench.py [h w]        (default 544 960 = the block-3 trunk of a 3840x2160 frame)
 Variants (bench-only template instantiations; all but the first compute garbage): no stores / no LDS-DMA after the prologue /
-no matrix work / no vmcnt wait, and combinations.  Then one stamped launch: per workgroup, wave and step the shader clock at
+no matrix work / no vmcnt wait, and combinations.  Then the clock probe (200 back-to-back launches per variant; the C side prints per launch the
+median workgroup life, first start -> last end, the gap to the previous launch and the shader clock = cycles / 100 MHz ticks, and writes the last
+launch's per-workgroup records to gpurun_out/t64_clk_<variant>.bin).  Then one stamped launch: per workgroup, wave and step the shader clock at
 (3) DMA issued + epilogue done = start of the step's matrix work, (0) end of it, (1) this wave's DMA pieces landed, (2) barrier passed."""
 import ctypes, importlib, os, struct, sys, statistics
 sys.path.insert(0, os.getcwd())
@@ -18,6 +20,11 @@ for rep in range(2):
         ms = ctypes.c_float()
         rc = L.rife_hip_bench_t64(0, h, w, v, 20, ctypes.byref(ms))
         print("%dx%d %-44s rc=%d %.1f us" % (h, w, name, rc, ms.value * 1e3), flush=True)
+CLK = 0x40000
+for name, v in (("full", 0), ("no stores", NOSTORE), ("no DMA", NODMA), ("math only", NODMA | NOSTORE), ("no math", NOMATH), ("loads only", NOMATH | NOSTORE), ("stores only", NOMATH | NODMA)):
+    ms = ctypes.c_float()
+    rc = L.rife_hip_bench_t64(0, h, w, v | CLK, 200, ctypes.byref(ms))
+    print("%dx%d clock probe, %-12s rc=%d %.1f us per launch" % (h, w, name, rc, ms.value * 1e3), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 ms = ctypes.c_float()
 rc = L.rife_hip_bench_t64(0, h, w, STAMPS, 1, ctypes.byref(ms))
