@@ -9,8 +9,9 @@
 // chain instead of shortening its links:
 //   * one workgroup = ROWS x 32 output pixels x ALL C output channels; wave w owns the 32-channel output block w (C / 32 waves), so the
 //     grid is as wide as the layer allows (4K: 255 workgroups for block 0, 510 for block 1) and a workgroup's whole life is one pass over K;
-//   * the S16 halo of the tile ((ROWS + 2) x 34 pixels x C channels: 78 / 70 KB) goes to LDS in a few phases of plain 16-byte copies
-//     (S16 entries need no conversion), one barrier per phase and none inside the K loop;
+//   * the S16 halo of the tile ((ROWS + 2) x 34 pixels x C channels: 78 / 70 KB) goes through LDS in phases of 4 / 2 K chunks of plain 16-byte
+//     copies (S16 entries need no conversion) alternating between two buffers (52 / 35 KB: three workgroups per CU for block 1, so that the
+//     544 workgroups of a 4K layer are resident at once instead of 512 + a second round of 32), one barrier per phase and none inside the K loop;
 //   * every weight fragment is used by exactly one wave (its output block), so the weights never touch LDS: each wave streams its
 //     [chunk][tap][k half][32 rows][8 f16] slice from the L2 straight into MFMA operand registers, through a ring of 18 (chunk, tap) slots
 //     (two K chunks ahead of the matrix pipe).
@@ -42,13 +43,19 @@ __device__ __forceinline__ void for_each_slot(F&& f) {
     if constexpr (B < E) { f(std::integral_constant<int, B>{}); for_each_slot<B + 1, E>(f); }
 }
 
-template <int C, int ROWS> constexpr int convrow_lds_bytes() { return (ROWS + 2) * 34 * 64 * (C / 16); }
+// K chunks per halo load phase; the phases alternate between two LDS buffers (phase p + 1 is written at the end of phase p into the buffer phase
+// p - 1 was read from: every wave has passed the barrier that ended phase p - 1 by then)
+// (TAG bit 16, A/B: block 1 with phases of 4 chunks = 70 KB, two workgroups per CU)
+template <int C, int TAG> constexpr int convrow_ph() { return C == 128 && !(TAG & 16) ? 2 : 4; }
+template <int C, int ROWS, int TAG = 0> constexpr int convrow_lds_bytes() { return 2 * convrow_ph<C, TAG>() * (ROWS + 2) * 34 * 64; }
 
+// waves per SIMD the register budget is set for: block 0 two workgroups x 6 waves, block 1 three workgroups x 4 waves per CU
+template <int C, int TAG> constexpr int convrow_waves_per_simd() { return C == 128 && (TAG & 16) ? 2 : 3; }
 template <int C, int ROWS, int TAG>
-__global__ __launch_bounds__(2 * C) void conv_row_kernel(RowArgs a) {
+__global__ __launch_bounds__(2 * C) __attribute__((amdgpu_waves_per_eu(convrow_waves_per_simd<C, TAG>(), convrow_waves_per_simd<C, TAG>()))) void conv_row_kernel(RowArgs a) {
     constexpr int NW = C / 32, NTHR = 64 * NW, NCH = C / 16, IH = ROWS + 2, IW = 34, NPX = IH * IW;
     constexpr int PLANE = NPX * 32, CHB = 2 * PLANE;                     // bytes per (chunk, hi | lo) plane / per chunk in LDS
-    constexpr int PH = 4, NPH = NCH / PH;                                // K chunks per load phase, phases
+    constexpr int PH = convrow_ph<C, TAG>(), NPH = NCH / PH;            // K chunks per load phase, phases
     constexpr int PSLOTS = PH * 4 * NPX, NLD = (PSLOTS + NTHR - 1) / NTHR;      // 16-byte slots per phase, loads per thread and phase
     constexpr int WSTRIDE = t64_img_nt(1, NCH);                          // bytes per output block of the weight image
     static_assert(NCH % PH == 0, "whole load phases");
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(2 * C) void conv_row_kernel(RowArgs a) {
         stage[k] = *reinterpret_cast<const f32x4*>(a.in + (tb + (unsigned)(2 * PH * (PHASE)) * a.plane + soff[k]));
 #define ROW_STORE(PHASE)                                                                                     \
     _Pragma("unroll") for (int k = 0; k < NLD; k++)                                                          \
-        if (PSLOTS % NTHR == 0 || tid + k * NTHR < PSLOTS) *reinterpret_cast<f32x4*>(lds + (PHASE) * PH * CHB + (tid + k * NTHR) * 16) = stage[k];
+        if (PSLOTS % NTHR == 0 || tid + k * NTHR < PSLOTS) *reinterpret_cast<f32x4*>(lds + ((PHASE) & 1) * PH * CHB + (tid + k * NTHR) * 16) = stage[k];
 
     // ---- operands
     unsigned ao[ROWS][9];                                                // fragment offsets inside a chunk (hi plane; lo = + PLANE)
@@ -114,13 +121,13 @@ __global__ __launch_bounds__(2 * C) void conv_row_kernel(RowArgs a) {
 
     // weight fragments: a ring of RING (chunk, tap) slots, every slot refilled right after its use, i.e. always RING taps (two K chunks)
     // ahead of the matrix pipe: an L2 round trip is longer than the 18 MFMAs of one chunk
-    constexpr int RING = 18, NJ = NCH * 9;
+    constexpr int RING = C == 128 && !(TAG & 16) ? 10 : 18, NJ = NCH * 9;       // block 1: 10 slots keep the kernel inside 168 VGPRs
     f16x8 wr[RING];
 #define ROW_WSLOT(J) wr[(J) % RING] = *reinterpret_cast<const f16x8*>(wsrc + (J) * 1024);
 #define ROW_TAP(J)                                                                                           \
     {                                                                                                        \
         constexpr int c_ = (J) / 9, t_ = (J) % 9;                                                            \
-        const unsigned char* const cb_ = lds + c_ * CHB;                                                     \
+        const unsigned char* const cb_ = lds + (((c_ / PH) & 1) * PH + c_ % PH) * CHB;                       \
         _Pragma("unroll") for (int rr = 0; rr < ROWS; rr++) {                                                \
             const f16x8 ah = *reinterpret_cast<const f16x8*>(cb_ + ao[rr][t_]);                              \
             const f16x8 al = *reinterpret_cast<const f16x8*>(cb_ + ao[rr][t_] + PLANE);                      \
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(2 * C) void conv_row_kernel(RowArgs a) {
         if (p + 1 < NPH) ROW_LOAD(p + 1)                                 // the next phase's halo chunks travel under this phase's matrix work
         for_each_slot<p * PH * 9, (p + 1) * PH * 9>([&](auto j) { ROW_TAP(decltype(j)::value) });
         if (p + 1 < NPH) {
-            ROW_STORE(p + 1)                                             // its own LDS region: nobody reads it yet
+            ROW_STORE(p + 1)                                             // the other buffer: last read in phase p - 1
             __syncthreads();
         }
     });

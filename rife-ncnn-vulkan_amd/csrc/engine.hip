@@ -679,7 +679,10 @@ static int launch_row(const ConvLayer& L, const unsigned char* in, unsigned char
     RowArgs a;
     a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x;
     if (L.cout == 192) { a.ntiles = a.tiles_x * H; hipLaunchKernelGGL((conv_row_kernel<192, 1, 0>), dim3(a.ntiles), dim3(384), (convrow_lds_bytes<192, 1>()), st, a); }
-    else if (L.cout == 128) { a.ntiles = a.tiles_x * ((H + 1) / 2); hipLaunchKernelGGL((conv_row_kernel<128, 2, 1>), dim3(a.ntiles), dim3(256), (convrow_lds_bytes<128, 2>()), st, a); }
+    else if (L.cout == 128) {
+        a.ntiles = a.tiles_x * ((H + 1) / 2);
+        hipLaunchKernelGGL((conv_row_kernel<128, 2, 1>), dim3(a.ntiles), dim3(256), (convrow_lds_bytes<128, 2>()), st, a);
+    }
     else return fail(RIFE_HIP_EINVAL, "conv_row serves 128 and 192 channels");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_row launch: ") + hipGetErrorString(e));
@@ -838,10 +841,6 @@ struct rife_hip {
     // finest-block trunk on S16 tensors + the persistent conv_t64 kernel (RIFE_HIP_T64=0 at create time keeps conv_h2b: A/B and
     // the bit-equality test of the two trunk implementations)
     bool t64 = true;
-    bool stem_occ = true;                    // RIFE_HIP_STEM_OCC=0 at create time: the fused stem of block 3 with padded 80-byte records, two workgroups per CU (A/B)
-    int rowk = 3;                            // RIFE_HIP_ROWK at create time: bit 0 = block 1, bit 1 = block 0 on conv_row_kernel (A/B)
-    bool t64_b2 = true;                      // RIFE_HIP_T64_B2=0 at create time: block 2 (96 channels) stays on the per-tile trunk kernel (A/B)
-    bool t64_alternate = true;               // RIFE_HIP_T64_ALT=0 at create time: every trunk layer walks its tiles first to last (A/B)
     int flow_div(int b) const { return v40 ? 2 * blk[b].scale : blk[b].scale; }
     // rife-v2.x schedule (IFNet + ContextNet + FusionNet)
     struct V2Block { ConvLayer stem0, stem1, conv[6], head; int c = 0, scale = 1; } fblk[4];
@@ -1015,8 +1014,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         }
         if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
         else if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
-        else if (E.stem_occ) hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);
-        else hipLaunchKernelGGL((stem0_fused_kernel<1, 1>), dim3(nb), dim3(512), stemf_lds_bytes<1>(), st, fa);
+        else hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);      // 64-byte swizzled records, three workgroups per CU
         HIPCHK(hipGetLastError());
     } else {
         if (b > 0 && (rc = run_assemble(E, c, b, timestep, tsp))) return rc;
@@ -1033,9 +1031,9 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
     const int ptiles = ((Ht + 7) / 8) * ((Wt + 31) / 32);
     // block 0 on the row kernel only while its grid is small: at 4K all 272 workgroups stream the same 663 KB of weights through the L2 at
     // once (0.239 vs 0.208 ms per pair for the per-tile kernel), at 1080p (68 workgroups) it wins (0.133 vs 0.152); block 1 wins at both
-    const bool rowk = (b == 1 && B.c == 128 && (E.rowk & 1)) || (b == 0 && B.c == 192 && (E.rowk & 2) && ((Wt + 31) / 32) * Ht <= 160);
+    const bool rowk = (b == 1 && B.c == 128) || (b == 0 && B.c == 192 && ((Wt + 31) / 32) * Ht <= 160);
     bool s16 = E.t64 && !E.v40 && g_trunk_h2 && PA && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS &&
-               ((b == 3 && B.c == 64) || (b == 2 && B.c == 96 && E.t64_b2 && ptiles >= 96) || rowk);
+               ((b == 3 && B.c == 64) || (b == 2 && B.c == 96 && ptiles >= 96) || rowk);
     for (int i = 0; i < 8 && s16; i++) s16 = B.res[i].d_t64 != nullptr;
     if (s16) {
         // stem-1 writes the first S16 tensor, eight persistent trunk launches ping-pong between the two, the head reads the last one
@@ -1047,7 +1045,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         unsigned char *pc = PA, *pn = PB;
         for (int i = 0; i < 8; i++) {
             Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
-            if ((rc = rowk ? launch_row(B.res[i], pc, pn, Ht, Wt, st) : launch_t64(B.res[i], pc, pn, Ht, Wt, st, E.t64_alternate && (i & 1) == 0))) return rc;
+            if ((rc = rowk ? launch_row(B.res[i], pc, pn, Ht, Wt, st) : launch_t64(B.res[i], pc, pn, Ht, Wt, st, (i & 1) == 0))) return rc;
             std::swap(pc, pn);
         }
         Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);
@@ -1869,10 +1867,6 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     E->frame_pool = std::make_shared<FramePool>();
     E->frame_pool->gpuid = gpuid;
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
-    { const char* e = getenv("RIFE_HIP_T64_ALT"); E->t64_alternate = !(e && e[0] == '0'); }
-    { const char* e = getenv("RIFE_HIP_T64_B2"); E->t64_b2 = !(e && e[0] == '0'); }
-    { const char* e = getenv("RIFE_HIP_ROWK"); if (e) E->rowk = atoi(e); }
-    { const char* e = getenv("RIFE_HIP_STEM_OCC"); E->stem_occ = !(e && e[0] == '0'); }
     return E;
 }
 

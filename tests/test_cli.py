@@ -132,6 +132,35 @@ def test_cpp_cli_directory_and_file_modes(modeldirs, tmp_path):
     assert np.array_equal(np.asarray(Image.open(tmp_path / "o.ppm").convert("RGB")), g.process(frames[0], frames[1], 0.25))
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(RIFE_HIP), reason="rife-hip is not built")
+def test_cpp_cli_two_replicas_on_one_device_equal_one(modeldirs, tmp_path):
+    """The per-device replica path (csrc/main.cpp: one RIFE object and its own proc threads per -g entry, one shared task queue;
+    reference src/main.cpp:766-781, 849-866): `-g 0,0 -j 1:2,2:2` = two engines on device 0 fed from the same queue must write
+    exactly the files `-g 0` writes.  Same for the Python CLI."""
+    from PIL import Image
+    from tools import gen_frames
+    ind = tmp_path / "in"; ind.mkdir()
+    for i in range(5):
+        Image.fromarray(gen_frames.smooth_pair(160, 96, 20 + i)[0]).save(ind / ("%03d.png" % i))
+    model = modeldirs["rife-v4.6"]
+    outs = {}
+    for name, extra in (("one", ["-g", "0", "-j", "1:2:2"]), ("two", ["-g", "0,0", "-j", "1:2,2:2"])):
+        outd = tmp_path / name; outd.mkdir()
+        rc, err = run_cpp(["-i", str(ind), "-o", str(outd), "-m", model, "-n", "13"] + extra)
+        assert rc == 0, err
+        outs[name] = outd
+    names = sorted(os.listdir(outs["one"]))
+    assert names == ["%08d.png" % i for i in range(1, 14)] and sorted(os.listdir(outs["two"])) == names
+    for n in names:
+        a = np.asarray(Image.open(outs["one"] / n).convert("RGB")); b = np.asarray(Image.open(outs["two"] / n).convert("RGB"))
+        assert np.array_equal(a, b), n
+    outp = tmp_path / "py"; outp.mkdir()
+    assert cli.main(["-i", str(ind), "-o", str(outp), "-m", model, "-n", "13", "-g", "0,0", "-j", "1:2,2:2"]) == 0
+    for n in names:
+        assert np.array_equal(np.asarray(Image.open(outp / n).convert("RGB")), np.asarray(Image.open(outs["one"] / n).convert("RGB"))), n
+
+
 @pytest.mark.skipif(not os.path.exists(RIFE_HIP), reason="rife-hip is not built")
 def test_cpp_cli_png_and_ppm_codecs_round_trip(tmp_path):
     """rife-hip's own PNG reader (all five filter types, RGB / RGBA / gray / palette) and writer against PIL, no GPU involved."""

@@ -32,4 +32,5 @@ for wl in 4k 1080p v23-1080p 4k-tta; do
     timeout 600 python bench.py --workload $wl --steps 50 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
 done
 timeout 300 python tools/host_path_bench2.py > $OUT/host_path.txt 2>&1
+python tools/pmc_tables.py $OUT $OUT/tables > $OUT/tables.log 2>&1
 ls -la $OUT
