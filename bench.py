@@ -205,8 +205,8 @@ def main():
     host = None
     if not args.no_host_path and not tta:
         host = {}
-        pageable = ([f.cpu().numpy() for f in frames], [np.empty((h, w, 3), np.uint8) for _ in range(2)])
-        pinned = ([amd.pinned_empty((h, w, 3)) for _ in frames], [amd.pinned_empty((h, w, 3)) for _ in range(2)])     # rife_hip_host_alloc
+        pageable = ([f.cpu().numpy() for f in frames], [np.empty((h, w, 3), np.uint8) for _ in range(3)])       # one output per caller thread
+        pinned = ([amd.pinned_empty((h, w, 3)) for _ in frames], [amd.pinned_empty((h, w, 3)) for _ in range(3)])     # rife_hip_host_alloc
         for dst, src in zip(pinned[0], pageable[0]):
             dst[...] = src
 
@@ -222,14 +222,21 @@ def main():
                         host_step(i, 0)
                     return
 
+                errs = []
+
                 def worker(s):
-                    torch.cuda.set_device(local)
-                    for i in range(args.steps):
-                        if i % nthreads == s:
-                            host_step(i, s)
+                    try:
+                        torch.cuda.set_device(local)
+                        for i in range(args.steps):
+                            if i % nthreads == s:
+                                host_step(i, s)
+                    except Exception as e:       # a dead caller thread would inflate the rate: fail the leg instead
+                        errs.append(e)
                 th = [threading.Thread(target=worker, args=(s,)) for s in range(nthreads)]
                 [t.start() for t in th]
                 [t.join() for t in th]
+                if errs:
+                    raise errs[0]
             for i in range(3):
                 host_step(i, 0)
             return sh.timed_steps(region, 1, dist=dist, device_sync=torch.cuda.synchronize,
