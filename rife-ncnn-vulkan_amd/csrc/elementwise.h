@@ -28,6 +28,20 @@ __global__ void k_preproc(const uint8_t* __restrict__ rgb, int w, int h, uint32_
     out[(size_t)y * wp + x] = v;
 }
 
+// the same for four pixels per lane (w % 4 == 0, 4-byte aligned frame): 12 contiguous bytes in, one 16-byte store out
+__global__ void k_preproc4(const uint8_t* __restrict__ rgb, int w, int h, uint32_t* __restrict__ out, int wp, int hp) {
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    if (x4 >= wp) return;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (x4 < w && y < h) {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        u32x3 q;
+        __builtin_memcpy(&q, __builtin_assume_aligned(rgb + ((size_t)y * w + x4) * 3, 4), 12);
+        v.x = q.x & 0xffffffu; v.y = (q.x >> 24) | ((q.y & 0xffffu) << 8); v.z = (q.y >> 16) | ((q.z & 0xffu) << 16); v.w = q.z >> 8;
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)y * wp + x4) = v;
+}
+
 __device__ __forceinline__ float3 unpack_rgb(uint32_t v) {
     const float k = 1 / 255.f;
     return make_float3((float)(v & 0xff) * k, (float)((v >> 8) & 0xff) * k, (float)((v >> 16) & 0xff) * k);

@@ -968,6 +968,11 @@ struct Timed {
 };
 
 static inline dim3 grid2d(int w, int h) { return dim3((w + 255) / 256, h); }
+// rife_preproc.comp: u8 HWC RGB -> zero-padded RGBX; four pixels per lane when the frame allows 4-byte loads
+static inline void launch_preproc(hipStream_t st, const uint8_t* rgb, int w, int h, uint32_t* out, int wp, int hp) {
+    if ((w & 3) == 0 && (reinterpret_cast<uintptr_t>(rgb) & 3) == 0) hipLaunchKernelGGL(k_preproc4, dim3((wp / 4 + 255) / 256, hp), dim3(256), 0, st, rgb, w, h, out, wp, hp);
+    else hipLaunchKernelGGL(k_preproc, grid2d(wp, hp), dim3(256), 0, st, rgb, w, h, out, wp, hp);
+}
 
 }  // namespace rife
 #include "graph_run.h"
@@ -1101,9 +1106,8 @@ static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     int rc;
     {
         Timed t(E.prof, "preproc", 0, st);
-        dim3 g = grid2d(c.wp, c.hp);
-        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.img0, c.wp, c.hp);
-        hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.img1, c.wp, c.hp);
+        launch_preproc(st, d_in0, c.w, c.h, c.img0, c.wp, c.hp);
+        launch_preproc(st, d_in1, c.w, c.h, c.img1, c.wp, c.hp);
         HIPCHK(hipGetLastError());
     }
     const bool fuse_tail = !E.v40 && g_trunk_h2 && g_head_h2 && g_fuse_tail && E.blk[3].head.d_wh != nullptr;
@@ -1216,8 +1220,8 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
             hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in0, w, h, a, wp, hp);
             hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in1, w, h, b, wp, hp);
         } else {
-            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, w, h, E.tta_ctx[0][0]->img0, wp, hp);
-            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, w, h, E.tta_ctx[0][0]->img1, wp, hp);
+            launch_preproc(st, d_in0, w, h, E.tta_ctx[0][0]->img0, wp, hp);
+            launch_preproc(st, d_in1, w, h, E.tta_ctx[0][0]->img1, wp, hp);
         }
         HIPCHK(hipGetLastError());
     }
@@ -1501,9 +1505,8 @@ static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     if (nori * ntemp == 1) {
         {
             Timed t(E.prof, "preproc", 0, st);
-            dim3 g = grid2d(wp, hp);
-            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.img0, wp, hp);
-            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.img1, wp, hp);
+            launch_preproc(st, d_in0, c.w, c.h, c.img0, wp, hp);
+            launch_preproc(st, d_in1, c.w, c.h, c.img1, wp, hp);
             HIPCHK(hipGetLastError());
         }
         if ((rc = run_v2_flow(E, c, c.img0, c.img1, wp, hp, c.acc))) return rc;
@@ -1518,8 +1521,8 @@ static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
             hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in0, c.w, c.h, a, wp, hp);
             hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in1, c.w, c.h, b, wp, hp);
         } else {
-            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.timg0[0], wp, hp);
-            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.timg1[0], wp, hp);
+            launch_preproc(st, d_in0, c.w, c.h, c.timg0[0], wp, hp);
+            launch_preproc(st, d_in1, c.w, c.h, c.timg1[0], wp, hp);
         }
         HIPCHK(hipGetLastError());
     }
@@ -1605,8 +1608,8 @@ static int run_v1(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
             hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in0, c.w, c.h, a, wp, hp);
             hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in1, c.w, c.h, b, wp, hp);
         } else {
-            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in0, c.w, c.h, c.timg0[0], wp, hp);
-            hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, st, d_in1, c.w, c.h, c.timg1[0], wp, hp);
+            launch_preproc(st, d_in0, c.w, c.h, c.timg0[0], wp, hp);
+            launch_preproc(st, d_in1, c.w, c.h, c.timg1[0], wp, hp);
         }
         HIPCHK(hipGetLastError());
     }
@@ -2316,9 +2319,8 @@ int rife_hip_v4_extract_flow(const rife_hip_t* E, const uint8_t* in0, const uint
     const size_t nbytes = (size_t)w * h * 3;
     HIPCHK(hipMemcpyAsync(c.d_in0, in0, nbytes, hipMemcpyHostToDevice, c.stream));
     HIPCHK(hipMemcpyAsync(c.d_in1, in1, nbytes, hipMemcpyHostToDevice, c.stream));
-    dim3 g = grid2d(c.wp, c.hp);
-    hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, c.stream, c.d_in0, c.w, c.h, c.img0, c.wp, c.hp);
-    hipLaunchKernelGGL(k_preproc, g, dim3(256), 0, c.stream, c.d_in1, c.w, c.h, c.img1, c.wp, c.hp);
+    launch_preproc(c.stream, c.d_in0, c.w, c.h, c.img0, c.wp, c.hp);
+    launch_preproc(c.stream, c.d_in1, c.w, c.h, c.img1, c.wp, c.hp);
     float* tmp = nullptr;
     if ((rc = dalloc(c, tmp, (size_t)c.wp * c.hp * 6))) return rc;
     const int nc = E->v40 ? 5 : 6;      // channels of blob flow{b}: rife-v4.6 PixelShuffle output 6, rife-v4 deconv output 5
