@@ -185,3 +185,25 @@ def test_8k_within_1_lsb(engines):
     a, b = [np.ascontiguousarray(np.kron(x, np.ones((4, 4, 1), np.uint8))) for x in base]
     mx, f0, f1, psnr = lsb_report(g.process(a, b, 0.5), o.process(a, b, 0.5))
     assert mx <= 1, (mx, f0, f1, psnr)
+
+
+def test_device_frames_at_odd_addresses_equal_aligned_ones(engines):
+    """rife_hip_process_device on frames whose device address is not 4-byte aligned (k_preproc, one pixel per lane) equals the same
+    frames at aligned addresses (k_preproc4, four pixels per lane: the width is a multiple of 4) and the host-buffer call."""
+    import torch
+    g, _ = engines
+    w, h = 128, 72
+    f0, f1 = gen_frames.smooth_pair(w, h, 4242)
+    want = g.process(f0, f1, 0.5)
+    n = w * h * 3
+    outs = []
+    for off in (0, 1, 3):
+        b0 = torch.zeros(n + 8, dtype=torch.uint8, device="cuda"); b1 = torch.zeros(n + 8, dtype=torch.uint8, device="cuda")
+        b0[off:off + n] = torch.from_numpy(f0.reshape(-1)).cuda(); b1[off:off + n] = torch.from_numpy(f1.reshape(-1)).cuda()
+        out = torch.zeros(n + 8, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()      # the engine enqueues on its own stream
+        g.process_device(b0.data_ptr() + off, b1.data_ptr() + off, w, h, 0.5, out.data_ptr() + off, None)
+        torch.cuda.synchronize()
+        outs.append(out[off:off + n].cpu().numpy().reshape(h, w, 3))
+    for o in outs:
+        assert np.array_equal(o, want)
