@@ -386,6 +386,97 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
     return rc;
 }
 
+// probe: is the fused stem kernel deterministic in isolation?  Random frames, flows (some leaving the frame), mask and weights; `reps` launches
+// into separate outputs, compared on the host: mismatch[r] = floats of launch r that differ from launch 0.  variant = S + 16 x ABL.
+int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, long long* mismatch) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    const int S = variant & 15, ABL = variant >> 4;
+    const size_t P = (size_t)wp * hp;
+    const int Hb = hp / S, Wb = wp / S, Ho = Hb / 2, Wo = Wb / 2;
+    const int cout = S == 1 ? 32 : (S == 2 ? 48 : 64), NSv = S == 1 ? 1 : 2;
+    std::vector<uint32_t> hi0(P), hi1(P);
+    std::vector<float> hF(P * 4), hM(P), hb(64), hs(64);
+    std::vector<_Float16> hw((size_t)9 * 2 * NSv * 32 * 8);
+    uint32_t lcg = 777u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((int)(lcg >> 9) - (1 << 22)) / (float)(1 << 22); };
+    for (size_t i = 0; i < P; i++) { lcg = lcg * 1664525u + 1013904223u; hi0[i] = lcg & 0xffffffu; lcg = lcg * 1664525u + 1013904223u; hi1[i] = lcg & 0xffffffu; }
+    for (auto& v : hF) v = rnd() * 9.f;
+    for (auto& v : hM) v = rnd();
+    for (auto& v : hb) v = rnd() * 0.1f;
+    for (auto& v : hs) v = 0.2f;
+    for (auto& v : hw) v = (_Float16)(rnd() * 0.2f);
+    uint32_t *i0 = nullptr, *i1 = nullptr; float4* F = nullptr; float *M = nullptr, *bias = nullptr, *slope = nullptr; void* wh = nullptr;
+    HIPCHK(hipMalloc(&i0, P * 4)); HIPCHK(hipMalloc(&i1, P * 4)); HIPCHK(hipMalloc(&F, P * 16)); HIPCHK(hipMalloc(&M, P * 4));
+    HIPCHK(hipMalloc(&bias, 256)); HIPCHK(hipMalloc(&slope, 256)); HIPCHK(hipMalloc(&wh, hw.size() * 2));
+    HIPCHK(hipMemcpy(i0, hi0.data(), P * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(i1, hi1.data(), P * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(F, hF.data(), P * 16, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(M, hM.data(), P * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(bias, hb.data(), 256, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(slope, hs.data(), 256, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(wh, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    const size_t nout = (size_t)Ho * Wo * cout;
+    std::vector<float*> outs(reps, nullptr);
+    for (int r = 0; r < reps; r++) { HIPCHK(hipMalloc(&outs[r], nout * 4)); HIPCHK(hipMemset(outs[r], 0, nout * 4)); }
+    const int nb_dbg = ((Wo + 31) / 32) * ((Ho + 3) / 4);
+    const size_t ndbg = (size_t)nb_dbg * 512 * 12;
+    std::vector<float*> dbgs(reps, nullptr);
+    if (ABL & 1024) for (int r = 0; r < reps; r++) { HIPCHK(hipMalloc(&dbgs[r], ndbg * 4)); HIPCHK(hipMemset(dbgs[r], 0, ndbg * 4)); }
+    StemFusedArgs fa;
+    fa.img0 = i0; fa.img1 = i1; fa.F = F; fa.M = M; fa.wpk = wh; fa.bias = bias; fa.slope = slope; fa.timestep = 0.5f; fa.tsp = nullptr;
+    fa.wp = wp; fa.hp = hp; fa.Ho = Ho; fa.Wo = Wo; fa.out_ld = cout; fa.Cout = cout; fa.tiles_x = (Wo + 31) / 32;
+    const int nb = fa.tiles_x * ((Ho + 3) / 4);
+    auto run = [&](auto kfn, int lds) -> int {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        for (int r = 0; r < reps; r++) { fa.out = outs[r]; fa.dbg = dbgs[r]; hipLaunchKernelGGL(kfn, dim3(nb), dim3(512), lds, 0, fa); }
+        HIPCHK(hipDeviceSynchronize());
+        return 0;
+    };
+    switch (variant) {
+        case 4: rc = run(stem0_fused_kernel<4, 2, 0>, stemf_lds_bytes<2>()); break;
+        case 2: rc = run(stem0_fused_kernel<2, 2, 0>, stemf_lds_bytes<2>()); break;
+        case 1 + 16 * 256: rc = run(stem0_fused_kernel<1, 1, 256>, (stemf_lds_bytes<1, 256>())); break;
+        case 1: rc = run(stem0_fused_kernel<1, 1, 0>, stemf_lds_bytes<1>()); break;
+        case 4 + 16 * 2: rc = run(stem0_fused_kernel<4, 2, 2>, stemf_lds_bytes<2>()); break;
+        case 4 + 16 * 64: rc = run(stem0_fused_kernel<4, 2, 64>, stemf_lds_bytes<2>()); break;
+        case 4 + 16 * 66: rc = run(stem0_fused_kernel<4, 2, 66>, stemf_lds_bytes<2>()); break;
+        case 4 + 16 * 1024: rc = run(stem0_fused_kernel<4, 2, 1024>, stemf_lds_bytes<2>()); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    if (!rc) {
+        std::vector<float> h0(nout), hr(nout);
+        HIPCHK(hipMemcpy(h0.data(), outs[0], nout * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < reps; r++) {
+            HIPCHK(hipMemcpy(hr.data(), outs[r], nout * 4, hipMemcpyDeviceToHost));
+            long long n = 0;
+            int shown = 0;
+            for (size_t k = 0; k < nout; k++)
+                if (std::memcmp(&h0[k], &hr[k], 4) != 0) {
+                    n++;
+                    const size_t px = k / cout; const int ch = (int)(k % cout);
+                    if ((ch == 0 || ch == 63 % cout) && shown < 40) { fprintf(stderr, "  launch %d: out (y %zu, x %zu) ch %d: %.9g vs %.9g\n", r, px / Wo, px % Wo, ch, h0[k], hr[k]); shown++; }
+                }
+            mismatch[r] = n;
+        }
+    }
+    if (!rc && (ABL & 1024)) {      // which thread's gathered pixel differs, and in which of the 12 channels {warp0 rgb, warp1 rgb, t, M, F / S xyzw}
+        std::vector<float> d0(ndbg), dr(ndbg);
+        HIPCHK(hipMemcpy(d0.data(), dbgs[0], ndbg * 4, hipMemcpyDeviceToHost));
+        for (int r = 1; r < reps; r++) {
+            HIPCHK(hipMemcpy(dr.data(), dbgs[r], ndbg * 4, hipMemcpyDeviceToHost));
+            int shown = 0;
+            for (size_t k = 0; k < ndbg && shown < 60; k++)
+                if (std::memcmp(&d0[k], &dr[k], 4) != 0) {
+                    const size_t t = k / 12;
+                    fprintf(stderr, "  dbg launch %d: workgroup %zu tid %zu (halo row %zu col %zu) channel %d: %.9g vs %.9g\n", r, t / 512, t % 512, (t % 512) / 65, (t % 512) % 65, (int)(k % 12), d0[k], dr[k]);
+                    shown++;
+                }
+        }
+    }
+    for (float* o : dbgs) (void)hipFree(o);
+    for (float* o : outs) (void)hipFree(o);
+    (void)hipFree(i0); (void)hipFree(i1); (void)hipFree(F); (void)hipFree(M); (void)hipFree(bias); (void)hipFree(slope); (void)hipFree(wh);
+    return rc;
+}
+
 // bench-only: ablations of stem0_fused_kernel<1,1> on a wp x hp frame (variant = ABL bits, see stem_fused.h)
 int rife_hip_bench_stemf(int gpuid, int wp, int hp, int variant, int iters, float* ms_out) {
     int rc;

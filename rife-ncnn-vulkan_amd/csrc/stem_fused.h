@@ -22,6 +22,7 @@ struct StemFusedArgs {
     const float* tsp;      // != null: timestep read from device memory (hipGraph replays)
     int wp, hp;            // padded full resolution
     int Ho, Wo, out_ld, Cout, tiles_x;
+    float* dbg = nullptr;  // bench builds (ABL & 1024): the gathered block-input pixel of every thread, [workgroup][512][12]
 };
 
 // LDS pixel record: 32 B hi + 32 B lo (+ 16 B pad: 80-byte records are conflict-free for the 16-byte staging writes and 2-way for
@@ -91,11 +92,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((ABL & 256)
         float o0[12], o1[12];
         STEM_GATHER(tid, o0)
         STEM_GATHER(tid + 512, o1)
+        if (ABL & 1024) { _Pragma("unroll") for (int c = 0; c < 12; c++) a.dbg[((size_t)blockIdx.x * 512 + tid) * 12 + c] = o0[c]; }
         STEM_STAGE(tid, o0)
         if (tid + 512 < NPIX) STEM_STAGE(tid + 512, o1)
     } else {
         float o0[12];
         STEM_GATHER(tid, o0)
+        if (ABL & 1024) { _Pragma("unroll") for (int c = 0; c < 12; c++) a.dbg[((size_t)blockIdx.x * 512 + tid) * 12 + c] = o0[c]; }
         STEM_STAGE(tid, o0)
         if ((ABL & 2) && tid + 512 < NPIX) {     // A/B: the second pixel as a second, dependent round
             STEM_GATHER(tid + 512, o0)

@@ -157,3 +157,19 @@ def test_conv3x3_32ch_split_f16_path():
     want = np.where(want < 0, want * slope[:, None, None], want)
     got = amd.op_conv3x3(x, wt, b, stride=1, slope=slope)
     assert np.abs(got - want).max() <= 4e-6 * np.abs(want).max() + 1e-6
+
+
+@pytest.mark.parametrize("variant,name", [(4, "block 1 (S = 4)"), (2, "block 2 (S = 2)"), (1 + 16 * 256, "block 3 (S = 1, 64-byte records)")])
+def test_fused_stem_kernels_are_deterministic(variant, name):
+    """Identical launches of a fused stem kernel on the same random inputs (flows leaving the frame included) must give identical bytes.
+    Regression test for the round-2 finding that the kernels of blocks 1 / 2 were NOT run-to-run stable when built with SLP-vectorized
+    (packed fp32) arithmetic next to 8-byte warp-tap loads (csrc/Makefile); the probe runs the kernel alone at the 4K and 1080p geometry."""
+    import ctypes
+    from tools import benchlib
+    L = benchlib.lib()
+    L.rife_hip_probe_stem_det.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_longlong)]
+    reps = 10
+    for wp, hp in ((3840, 2176), (1920, 1088)):
+        mm = (ctypes.c_longlong * reps)()
+        assert L.rife_hip_probe_stem_det(0, variant, wp, hp, reps, mm) == 0, L.rife_hip_last_error()
+        assert list(mm) == [0] * reps, (name, wp, hp, list(mm))

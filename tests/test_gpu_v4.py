@@ -207,3 +207,18 @@ def test_device_frames_at_odd_addresses_equal_aligned_ones(engines):
         outs.append(out[off:off + n].cpu().numpy().reshape(h, w, 3))
     for o in outs:
         assert np.array_equal(o, want)
+
+
+def test_4k_pass_is_run_to_run_stable(engines):
+    """The same 3840x2160 pair four times through one engine: identical frames and identical block-1 / block-3 flows (the first stages that
+    go through the fused stem kernels and the fused tail)."""
+    g, _ = engines
+    a, b = gen_frames.smooth_pair(960, 540, 705)
+    a = np.ascontiguousarray(np.kron(a, np.ones((4, 4, 1), np.uint8))); b = np.ascontiguousarray(np.kron(b, np.ones((4, 4, 1), np.uint8)))
+    outs = [g.process(a, b, 0.5) for _ in range(4)]
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+    for fi in (1, 3):
+        fl = [g.v4_extract_flow(a, b, 0.5, fi) for _ in range(3)]
+        for f in fl[1:]:
+            assert np.array_equal(f, fl[0]), fi
