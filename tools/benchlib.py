@@ -6,7 +6,7 @@ import os
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "rife-ncnn-vulkan_amd", "librife_hip_bench.so")
+PATH = os.environ.get("RIFE_HIP_BENCH_LIB") or os.path.join(ROOT, "rife-ncnn-vulkan_amd", "librife_hip_bench.so")      # the override: A/B of two bench builds
 _lib = None
 
 
