@@ -13,9 +13,10 @@
 //     copies (S16 entries need no conversion) alternating between two buffers (52 / 35 KB: three workgroups per CU for block 1, so that the
 //     544 workgroups of a 4K layer are resident at once instead of 512 + a second round of 32), one barrier per phase and none inside the K loop;
 //   * every weight fragment is used by exactly one wave (its output block), so the weights never touch LDS: each wave streams its
-//     [chunk][tap][k half][32 rows][8 f16] slice from the L2 straight into MFMA operand registers, through a ring of 18 (chunk, tap) slots
-//     (two K chunks ahead of the matrix pipe).
-// Measured (MI355X, ms per pair for the 8 launches of a block, same-call A/B against the per-tile kernels): 4K block 1 0.255 vs 0.285,
+//     [chunk][tap][k half][32 rows][8 f16] slice from the L2 straight into MFMA operand registers, through a ring of 18 (block 0) / 10
+//     (block 1: 162 VGPRs = three waves per SIMD) (chunk, tap) slots, one to two K chunks ahead of the matrix pipe.
+// Measured (MI355X, ms per pair for the 8 launches of a block, same-call A/B against the per-tile kernels): 4K block 1 0.255 (0.242 with the
+// two-buffer phases and three workgroups per CU) vs 0.285,
 // block 0 0.239 vs 0.208 (272 workgroups streaming the same 663 KB of weights at once: the per-XCD L2 becomes the limit - the engine keeps
 // the per-tile kernel there); 1080p block 1 0.119 vs 0.156, block 0 0.133 vs 0.152: 1418 vs 1307 frames/s.
 // Output channels are permuted inside the 32-row block like in conv_t64_kernel (a lane ends up with 16 consecutive channels = one S16
