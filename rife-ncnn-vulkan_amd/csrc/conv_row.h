@@ -1,5 +1,5 @@
 // conv_row_kernel<C, ROWS>: the residual trunk convolutions of the two COARSE IFBlocks of rife-v4.6 (block 0: 192 -> 192 channels at 1/32
-// resolution, block 1: 128 -> 128 at 1/16; reference models/rife-v4.6/flownet.param:14-42, 66-94: Split, Convolution 3x3 pad 1, BinaryOp add,
+// resolution, block 1: 128 -> 128 at 1/16; and block 2, 96 -> 96 at 1/8, while its grid has fewer 8 x 32 tiles than the chip has CUs: 1080p; reference models/rife-v4.6/flownet.param:14-42, 66-94: Split, Convolution 3x3 pad 1, BinaryOp add,
 // ReLU slope 0.2), 16 launches per pair, on S16 tensors (conv_t64.h) with the split-f16 matrix scheme of conv_h2b_kernel.
 //
 // These layers are small (4K: 8,160 and 32,640 pixels; 5.4 and 9.6 GFLOP) and were latency bound: the per-tile kernels need 27 - 37 us per
@@ -47,7 +47,7 @@ __device__ __forceinline__ void for_each_slot(F&& f) {
 // K chunks per halo load phase; the phases alternate between two LDS buffers (phase p + 1 is written at the end of phase p into the buffer phase
 // p - 1 was read from: every wave has passed the barrier that ended phase p - 1 by then)
 // (TAG bit 16, A/B: block 1 with phases of 4 chunks = 70 KB, two workgroups per CU)
-template <int C, int TAG> constexpr int convrow_ph() { return C == 128 && !(TAG & 16) ? 2 : 4; }
+template <int C, int TAG> constexpr int convrow_ph() { return (C == 128 && !(TAG & 16)) || C < 128 ? 2 : 4; }
 template <int C, int ROWS, int TAG = 0> constexpr int convrow_lds_bytes() { return 2 * convrow_ph<C, TAG>() * (ROWS + 2) * 34 * 64; }
 
 // waves per SIMD the register budget is set for: block 0 two workgroups x 6 waves, block 1 three workgroups x 4 waves per CU
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(2 * C) __attribute__((amdgpu_waves_per_eu(convrow_w
 
     // weight fragments: a ring of RING (chunk, tap) slots, every slot refilled right after its use, i.e. always RING taps (two K chunks)
     // ahead of the matrix pipe: an L2 round trip is longer than the 18 MFMAs of one chunk
-    constexpr int RING = C == 128 && !(TAG & 16) ? 10 : 18, NJ = NCH * 9;       // block 1: 10 slots keep the kernel inside 168 VGPRs
+    constexpr int RING = (C == 128 && !(TAG & 16)) || C < 128 ? 10 : 18, NJ = NCH * 9;       // block 1: 10 slots keep the kernel inside 168 VGPRs
     f16x8 wr[RING];
 #define ROW_WSLOT(J) wr[(J) % RING] = *reinterpret_cast<const f16x8*>(wsrc + (J) * 1024);
 #define ROW_TAP(J)                                                                                           \

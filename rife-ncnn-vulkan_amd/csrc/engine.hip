@@ -67,6 +67,7 @@ struct ConvLayer {
     // stride-2 stem that writes the first S16 tensor
     bool want_t64 = false, want_s16out = false;
     unsigned char* d_t64 = nullptr;
+    unsigned char* d_row = nullptr;      // 96 channels: the conv_row image next to the conv_t64 one (small grids)
     uint16_t* d_whp = nullptr;
     double flops_per_pixel = 0;           // algorithmic: 2 * MAC per GEMM-M pixel
     std::string cls;                      // profile class
@@ -80,8 +81,9 @@ static void free_layer(ConvLayer& L) {
     if (L.d_w8) (void)hipFree(L.d_w8);
     if (L.d_wh) (void)hipFree(L.d_wh);
     if (L.d_t64) (void)hipFree(L.d_t64);
+    if (L.d_row) (void)hipFree(L.d_row);
     if (L.d_whp) (void)hipFree(L.d_whp);
-    L.d_w = L.d_bias = L.d_slope = L.d_w8 = nullptr; L.d_wh = nullptr; L.d_t64 = nullptr; L.d_whp = nullptr;
+    L.d_w = L.d_bias = L.d_slope = L.d_w8 = nullptr; L.d_wh = nullptr; L.d_t64 = nullptr; L.d_row = nullptr; L.d_whp = nullptr;
 }
 
 // Choose the kernel configuration for a layer (see conv_mfma.h for the meaning of MS / NS / CC).
@@ -333,6 +335,11 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
                 std::vector<unsigned char> img = pack_t64_image(w_orig, bias, uniform_slope, L.cout, L.cout >= 128 ? 1 : 0);
                 HIPCHK(hipMalloc(&L.d_t64, img.size()));
                 HIPCHK(hipMemcpy(L.d_t64, img.data(), img.size(), hipMemcpyHostToDevice));
+                if (L.cout == 96) {
+                    std::vector<unsigned char> ri = pack_t64_image(w_orig, bias, uniform_slope, L.cout, 1);
+                    HIPCHK(hipMalloc(&L.d_row, ri.size()));
+                    HIPCHK(hipMemcpy(L.d_row, ri.data(), ri.size(), hipMemcpyHostToDevice));
+                }
             }
         }
     }
@@ -664,7 +671,8 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
 
 // one C -> C (C = 128, 192) residual trunk convolution of a coarse block, S16 in / S16 out: one workgroup per ROWS x 32 pixels (conv_row.h)
 static int launch_row(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st) {
-    if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_row image");
+    const unsigned char* const rimg = L.cout == 96 ? L.d_row : L.d_t64;
+    if (!rimg) return fail(RIFE_HIP_EINVAL, "layer has no conv_row image");
     {
         int dev = 0; (void)hipGetDevice(&dev);
         static std::mutex mu; static std::map<int, bool> done;
@@ -677,13 +685,14 @@ static int launch_row(const ConvLayer& L, const unsigned char* in, unsigned char
     }
     const S16Geom G(H, W);
     RowArgs a;
-    a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x;
+    a.in = in; a.out = out; a.img = rimg; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x;
     if (L.cout == 192) { a.ntiles = a.tiles_x * H; hipLaunchKernelGGL((conv_row_kernel<192, 1, 0>), dim3(a.ntiles), dim3(384), (convrow_lds_bytes<192, 1>()), st, a); }
     else if (L.cout == 128) {
         a.ntiles = a.tiles_x * ((H + 1) / 2);
         hipLaunchKernelGGL((conv_row_kernel<128, 2, 1>), dim3(a.ntiles), dim3(256), (convrow_lds_bytes<128, 2>()), st, a);
     }
-    else return fail(RIFE_HIP_EINVAL, "conv_row serves 128 and 192 channels");
+    else if (L.cout == 96) { a.ntiles = a.tiles_x * ((H + 1) / 2); hipLaunchKernelGGL((conv_row_kernel<96, 2, 2>), dim3(a.ntiles), dim3(192), (convrow_lds_bytes<96, 2, 2>()), st, a); }
+    else return fail(RIFE_HIP_EINVAL, "conv_row serves 96, 128 and 192 channels");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_row launch: ") + hipGetErrorString(e));
     return 0;
@@ -1036,10 +1045,14 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
     const int ptiles = ((Ht + 7) / 8) * ((Wt + 31) / 32);
     // block 0 on the row kernel only while its grid is small: at 4K all 272 workgroups stream the same 663 KB of weights through the L2 at
     // once (0.239 vs 0.208 ms per pair for the per-tile kernel), at 1080p (68 workgroups) it wins (0.133 vs 0.152); block 1 wins at both
-    const bool rowk = (b == 1 && B.c == 128) || (b == 0 && B.c == 192 && ((Wt + 31) / 32) * Ht <= 160);
+    // block 2 on small grids (<= 256 tiles of 8 x 32: fewer tiles than CUs): the persistent kernel (one workgroup per CU for 96 channels) has at most one
+    // tile per workgroup there and fills only part of the chip: 1080p (136 tiles) trunk_b2 0.229 -> 0.179 ms per pair on the row kernel, 4K (510 tiles)
+    // 0.387 -> 0.401; block 3 (64 channels, two workgroups per CU) stays on the persistent kernel at every size (1080p 0.225 vs 0.233)
+    const bool row_small = b == 2 && B.c == 96 && ptiles <= 256;
+    const bool rowk = (b == 1 && B.c == 128) || (b == 0 && B.c == 192 && ((Wt + 31) / 32) * Ht <= 160) || row_small;
     bool s16 = E.t64 && !E.v40 && g_trunk_h2 && PA && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS &&
-               ((b == 3 && B.c == 64) || (b == 2 && B.c == 96 && ptiles >= 96) || rowk);
-    for (int i = 0; i < 8 && s16; i++) s16 = B.res[i].d_t64 != nullptr;
+               ((b == 3 && B.c == 64) || (b == 2 && B.c == 96) || rowk);
+    for (int i = 0; i < 8 && s16; i++) s16 = B.res[i].d_t64 != nullptr && (!row_small || B.res[i].d_row != nullptr);
     if (s16) {
         // stem-1 writes the first S16 tensor, eight persistent trunk launches ping-pong between the two, the head reads the last one
         const S16Geom G(Ht, Wt);
