@@ -386,6 +386,147 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
     return rc;
 }
 
+// bench-only: the row-streaming trunk kernel (conv_rs.h) on an h x w tensor of random records.  First its output (walking down, then walking
+// up) is compared byte for byte with conv_t64_kernel's on the same input: stats[0] / stats[1] = differing bytes (down / up), stats[2..5] = plane,
+// padded row, padded column, byte of the first difference (down), stats[6] = bytes compared.  Then `iters` launches ping-pong between two
+// tensors like consecutive trunk layers.  variant = ablation bits of conv_rs.h | 0x10000 (layers alternate direction) | 0x20000 (always up)
+// | 0x1000000 * g (g > 0: launch g workgroups instead of one per CU).
+int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms_out, long long* stats) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    std::vector<float> wts((size_t)64 * 64 * 9), bias(64);
+    uint32_t lcg = 12345u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((int)(lcg >> 9) - (1 << 22)) / (float)(1 << 22); };   // [-1, 1)
+    for (auto& v : wts) v = (float)(_Float16)(rnd() * 0.03f);
+    for (auto& v : bias) v = rnd() * 0.1f;
+    std::vector<unsigned char> img = pack_t64_image(wts.data(), bias.data(), 0.2f);
+    const S16Geom G(h, w);
+    const size_t nb = G.bytes(64);
+    unsigned char *x = nullptr, *y = nullptr, *yr = nullptr, *dimg = nullptr;
+    HIPCHK(hipMalloc(&x, nb)); HIPCHK(hipMalloc(&y, nb)); HIPCHK(hipMalloc(&yr, nb)); HIPCHK(hipMalloc(&dimg, img.size()));
+    HIPCHK(hipMemcpy(dimg, img.data(), img.size(), hipMemcpyHostToDevice));
+    {   // random {hi, lo} entries in the interior of every plane, zero border
+        std::vector<_Float16> hx(nb / 2, (_Float16)0.f);
+        const size_t pl = G.plane() / 2;
+        for (int yy = 0; yy < h; yy++)
+            for (int xx = 0; xx < w; xx++)
+                for (int c = 0; c < 4; c++)
+                    for (int e = 0; e < 16; e++) {
+                        const float v = rnd(); const _Float16 hh = (_Float16)v;
+                        const size_t px = ((size_t)(yy + 1) * G.pitch + xx + 1) * 16 + e;
+                        hx[(2 * c) * pl + px] = hh; hx[(2 * c + 1) * pl + px] = (_Float16)(v - (float)hh);
+                    }
+        HIPCHK(hipMemcpy(x, hx.data(), nb, hipMemcpyHostToDevice));
+    }
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpuid));
+    RsArgs a;
+    a.in = x; a.out = y; a.img = dimg; a.H = h; a.W = w; a.pitch = G.pitch; a.plane = G.plane();
+    a.npairs = (h + 1) / 2; a.nunits = G.tiles_x * a.npairs; a.descend = 0;
+    const int gover = (variant >> 24) & 0xff;
+    const int nwg = std::min(gover ? gover : cus, a.nunits);
+    const bool alternate = (variant & 0x10000) != 0, up = (variant & 0x20000) != 0;
+    variant &= 0xffff | RS_CLK;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS));
+    if (stats) {
+        for (int i = 0; i < 8; i++) stats[i] = -1;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_t64_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, T64_LDS));
+        T64Args t;
+        t.in = x; t.out = yr; t.img = dimg; t.H = h; t.W = w; t.pitch = G.pitch; t.plane = G.plane(); t.tiles_x = G.tiles_x; t.ntiles = G.tiles_x * G.tiles_y; t.reverse = 0; t.nchunks = 4; t.nnt = 1;
+        const int twg = std::min(t64_wg_per_cu(2) * (cus / 8 * 8), (t.ntiles + 7) / 8 * 8);
+        HIPCHK(hipMemset(yr, 0, nb));
+        hipLaunchKernelGGL((conv_t64_kernel<3, 2>), dim3(twg), dim3(T64_NTHR), T64_LDS, 0, t);
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<unsigned char> ref(nb), got(nb);
+        HIPCHK(hipMemcpy(ref.data(), yr, nb, hipMemcpyDeviceToHost));
+        for (int dir = 0; dir < 2; dir++) {
+            HIPCHK(hipMemset(y, 0, nb));
+            a.descend = dir;
+            hipLaunchKernelGGL((conv_rs_kernel<0>), dim3(nwg), dim3(RS_NTHR), RS_LDS, 0, a);
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMemcpy(got.data(), y, nb, hipMemcpyDeviceToHost));
+            long long bad = 0;
+            for (size_t i = 0; i < nb; i++)
+                if (ref[i] != got[i]) {
+                    if (!bad && dir == 0) {
+                        const size_t pli = i / G.plane(), rem = i % G.plane();
+                        stats[2] = (long long)pli; stats[3] = (long long)(rem / ((size_t)G.pitch * 32)); stats[4] = (long long)(rem % ((size_t)G.pitch * 32) / 32); stats[5] = (long long)(rem % 32);
+                    }
+                    bad++;
+                }
+            stats[dir] = bad;
+        }
+        stats[6] = (long long)nb;
+        a.descend = 0;
+    }
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    long long* clk_base = nullptr;
+    auto run = [&](auto kfn) -> int {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS));
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(RS_NTHR), RS_LDS, 0, a);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) {
+            a.in = (i & 1) ? y : x; a.out = (i & 1) ? x : y;
+            a.descend = up ? 1 : (alternate ? (i & 1) : 0);
+            if (clk_base) a.stamps = clk_base + (size_t)std::min(i, 255) * nwg * 4;
+            hipLaunchKernelGGL(kfn, dim3(nwg), dim3(RS_NTHR), RS_LDS, 0, a);
+        }
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    if (variant & RS_CLK) {
+        HIPCHK(hipMalloc(&clk_base, (size_t)nwg * 32 * 256));
+        HIPCHK(hipMemset(clk_base, 0, (size_t)nwg * 32 * 256));
+        a.stamps = clk_base;
+        switch (variant & ~RS_CLK) {
+            case 0: rc = run(conv_rs_kernel<RS_CLK>); break;
+            case RS_NOMATH: rc = run(conv_rs_kernel<RS_CLK | RS_NOMATH>); break;
+            case RS_NODMA | RS_NOSTORE: rc = run(conv_rs_kernel<RS_CLK | RS_NODMA | RS_NOSTORE>); break;
+            default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+        }
+        const int nl = std::min(iters, 255);
+        std::vector<long long> hs((size_t)nwg * 4 * nl);
+        HIPCHK(hipMemcpy(hs.data(), clk_base, hs.size() * 8, hipMemcpyDeviceToHost));
+        long long prev_end = 0;
+        fprintf(stderr, "rs clk: variant 0x%x  launch: workgroup life median us | first start -> last end us | gap to the previous launch us | GHz\n", variant & ~RS_CLK);
+        for (int l = 0; l < nl; l++) {
+            const long long* p = hs.data() + (size_t)l * nwg * 4;
+            std::vector<long long> rt;
+            long long s0 = LLONG_MAX, e1c = 0, cyc = 0, tk = 0;
+            for (int i = 0; i < nwg; i++) {
+                rt.push_back(p[4 * i + 2] - p[4 * i + 1]); cyc += p[4 * i]; tk += p[4 * i + 2] - p[4 * i + 1];
+                s0 = std::min(s0, p[4 * i + 1]); e1c = std::max(e1c, p[4 * i + 2]);
+            }
+            std::sort(rt.begin(), rt.end());
+            if (l < 4 || l % 20 == 0 || l == nl - 1)
+                fprintf(stderr, "   %3d: %.2f | %.2f | %.2f | %.3f\n", l, rt[nwg / 2] * 0.01, (e1c - s0) * 0.01, l ? (s0 - prev_end) * 0.01 : 0.0, (double)cyc / (double)std::max(1LL, tk) * 0.1);
+            prev_end = e1c;
+        }
+        (void)hipFree(clk_base);
+    } else switch (variant) {
+        case 0: rc = run(conv_rs_kernel<0>); break;
+        case RS_NOSTORE: rc = run(conv_rs_kernel<RS_NOSTORE>); break;
+        case RS_NODMA: rc = run(conv_rs_kernel<RS_NODMA>); break;
+        case RS_NOMATH: rc = run(conv_rs_kernel<RS_NOMATH>); break;
+        case RS_NOPRIO: rc = run(conv_rs_kernel<RS_NOPRIO>); break;
+        case RS_NOEPI: rc = run(conv_rs_kernel<RS_NOEPI>); break;
+        case RS_NODMA | RS_NOSTORE: rc = run(conv_rs_kernel<RS_NODMA | RS_NOSTORE>); break;
+        case RS_NOMATH | RS_NOSTORE: rc = run(conv_rs_kernel<RS_NOMATH | RS_NOSTORE>); break;
+        case RS_NOMATH | RS_NODMA: rc = run(conv_rs_kernel<RS_NOMATH | RS_NODMA>); break;
+        case RS_NODMA | RS_NOSTORE | RS_NOEPI: rc = run(conv_rs_kernel<RS_NODMA | RS_NOSTORE | RS_NOEPI>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    (void)hipFree(x); (void)hipFree(y); (void)hipFree(yr); (void)hipFree(dimg); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
+// tools/stem_bisect.py: path of a code object whose stem0_fused_kernel<4, 2, 0> / <2, 2, 0> rife_hip_probe_stem_det launches instead of the built-in ones
+static std::string g_stem_hsaco;
+int rife_hip_probe_set_stem_hsaco(const char* path) { g_stem_hsaco = path ? path : ""; return 0; }
+
 // probe: is the fused stem kernel deterministic in isolation?  Random frames, flows (some leaving the frame), mask and weights; `reps` launches
 // into separate outputs, compared on the host: mismatch[r] = floats of launch r that differ from launch 0.  variant = S + 16 x ABL.
 int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, long long* mismatch) {
@@ -430,6 +571,21 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
         HIPCHK(hipDeviceSynchronize());
         return 0;
     };
+    if (!g_stem_hsaco.empty() && (variant == 4 || variant == 2)) {
+        // the kernel from an externally assembled code object (tools/stem_bisect.py: the compiler's assembly with wait states inserted)
+        hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
+        HIPCHK(hipModuleLoad(&mod, g_stem_hsaco.c_str()));
+        HIPCHK(hipModuleGetFunction(&fn, mod, variant == 4 ? "_ZN4rife18stem0_fused_kernelILi4ELi2ELi0EEEvNS_13StemFusedArgsE" : "_ZN4rife18stem0_fused_kernelILi2ELi2ELi0EEEvNS_13StemFusedArgsE"));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+        for (int r = 0; r < reps; r++) {
+            fa.out = outs[r]; fa.dbg = dbgs[r];
+            size_t sz = sizeof(fa);
+            void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &fa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+            HIPCHK(hipModuleLaunchKernel(fn, nb, 1, 1, 512, 1, 1, stemf_lds_bytes<2>(), 0, nullptr, cfg));
+        }
+        HIPCHK(hipDeviceSynchronize());
+        (void)hipModuleUnload(mod);
+    } else
     switch (variant) {
         case 4: rc = run(stem0_fused_kernel<4, 2, 0>, stemf_lds_bytes<2>()); break;
         case 2: rc = run(stem0_fused_kernel<2, 2, 0>, stemf_lds_bytes<2>()); break;
@@ -452,7 +608,7 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
                 if (std::memcmp(&h0[k], &hr[k], 4) != 0) {
                     n++;
                     const size_t px = k / cout; const int ch = (int)(k % cout);
-                    if ((ch == 0 || ch == 63 % cout) && shown < 40) { fprintf(stderr, "  launch %d: out (y %zu, x %zu) ch %d: %.9g vs %.9g\n", r, px / Wo, px % Wo, ch, h0[k], hr[k]); shown++; }
+                    if ((ch == 0 || ch == 63 % cout) && shown < (getenv("RIFE_HIP_PROBE_QUIET") ? 0 : 40)) { fprintf(stderr, "  launch %d: out (y %zu, x %zu) ch %d: %.9g vs %.9g\n", r, px / Wo, px % Wo, ch, h0[k], hr[k]); shown++; }
                 }
             mismatch[r] = n;
         }

@@ -1,0 +1,326 @@
+// conv_rs_kernel: the 64 -> 64 channel residual trunk convolution of the finest IFBlock of rife-v4.6 (reference
+// models/rife-v4.6/flownet.param:169-197: Split, Convolution 3x3 pad 1, BinaryOp add, ReLU slope 0.2; 8 launches per pair, 44 % of the pair's
+// MACs) as a ROW-STREAMING persistent kernel with specialised waves.  Round 3; replaces conv_t64_kernel<3, 2> (conv_t64.h), whose load, store
+// and matrix phases added up (22 + 27 + 43 us = the 82 - 88 us of a 4K launch) instead of overlapping, because every wave both fed the matrix
+// pipe and issued the tile's LDS-DMA pieces and stores, and a wave that waits for a slot in the CU's memory queue issues no MFMAs.
+//
+// One workgroup per CU, 8 waves, no two of which do the same job:
+//   * waves 0-3, "consumers" (one per SIMD): wave k owns output block n = k & 1 (32 channels) of output row (k >> 1) of the current row
+//     pair.  Its 36 weight fragments ([K chunk 4][tap 9] x 16 bytes per lane = 144 VGPRs) are loaded ONCE per launch and stay in registers:
+//     no weight ever passes through LDS (conv_t64 re-streamed the 72 KB of weights per 8 x 32 tile: 1.2 GB of L2 -> LDS traffic per 4K
+//     launch, 4 x the activations).  A consumer only issues ds_read_b128 (pixel fragments) and MFMAs, plus the epilogue of the PREVIOUS
+//     row (bias, LeakyReLU, split into {hi, lo}; VALU work the scheduler spreads between this row's MFMAs) whose result goes to an LDS
+//     staging buffer.  It never touches vector memory after the prologue.
+//   * waves 4-5, "loaders": LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, no registers) of the halo ROWS two steps ahead into a
+//     ring of 12 row slots.  A workgroup walks DOWN (or up) a 32-column strip, so every input row is loaded once per strip instead of once
+//     per 8-row tile: 34 / 32 of the tensor instead of 10 x 34 / (8 x 32) = 1.33 x.
+//   * waves 6-7, "storers": copy the staged output rows of two steps ago to global memory (1 KiB contiguous per instruction).
+//   Loads and stores are issued by different waves because vmcnt only retires in order within one kind of access: the loaders' counted
+//   waits (vmcnt(9) / vmcnt(18): the rows of the step after next may still be in flight) would be meaningless with stores in the same queue.
+// A step = one row pair of one strip = 76 MFMAs per consumer (2,432 cycles of its SIMD's matrix pipe) and ends with ONE s_barrier:
+//   iteration it:  consumers  MFMAs of step it, epilogue of step it - 1 -> staging[(it - 1) & 1]
+//                  loaders    rows of step it + 2 -> ring; wait for the rows of step it + 1
+//                  storers    staging[it & 1] (= step it - 2) -> global
+// Work split: the tiles_x x ceil(H / 2) (strip, row pair) units in strip-major order are cut into gridDim.x equal contiguous ranges (4K: 8,160
+// units over 256 workgroups = 31 or 32 steps each); a range that crosses into the next strip restarts the ring there (4 fresh rows).
+// Tensors are the S16 tensors of conv_t64.h ({hi, lo} f16 planes per 16-channel chunk, one pixel of zero border), the weight image is
+// conv_t64's (pack_t64_image), products / accumulation order / epilogue are those of conv_t64_kernel: results are bit-identical to it
+// (tests/test_gpu_t64.py, tools/rs_bench.py).
+// LDS: ring 12 x 8,704 B (row slot = [chunk 4][hi | lo][34 px][32 B], halves swapped where bit 3 of the column is set: conflict-free
+// ds_read_b128, applied to the DMA source addresses) + staging 2 x 2 rows x 8 KiB + bias / slopes = 137,728 B.
+#pragma once
+#include <type_traits>
+#include "conv_t64.h"
+#include "conv_row.h"
+
+namespace rife {
+
+constexpr int RS_NR = 12;                                  // ring row slots
+constexpr int RS_SEG = 34 * 32;                            // one (chunk, hi | lo) segment of a halo row: 1,088 B
+constexpr int RS_ROWB = 8 * RS_SEG;                        // 8,704 B per halo row (64 channels x {hi, lo})
+constexpr int RS_STG_ROW = 8 * 1024;                       // staged output row: [chunk 4][hi | lo][32 px][32 B]
+constexpr int RS_LDS_RING = 0;
+constexpr int RS_LDS_STG = RS_NR * RS_ROWB;                // 104,448
+constexpr int RS_LDS_BS = RS_LDS_STG + 2 * 2 * RS_STG_ROW; // 137,216: bias[64] | slope[64]
+constexpr int RS_LDS = RS_LDS_BS + 512;                    // 137,728 B: one workgroup per CU
+constexpr int RS_NTHR = 512;
+
+struct RsArgs {
+    const unsigned char* in;     // S16 tensor, allocation start (= pixel (-1, -1) of plane 0)
+    unsigned char* out;          // S16 tensor of the same geometry
+    const unsigned char* img;    // conv_t64's weight image of a 64 -> 64 layer (T64_IMG bytes)
+    int H, W;                    // valid pixels
+    int pitch;                   // pixels per plane row
+    unsigned plane;              // bytes per plane
+    int npairs;                  // row pairs per strip = ceil(H / 2)
+    int nunits;                  // tiles_x * npairs
+    int descend;                 // 1: every workgroup walks its range last unit first, rows bottom-up (consecutive layers alternate)
+    long long* stamps = nullptr; // bench builds (TAG & RS_CLK): [workgroup][4] = shader cycles of the workgroup's life, start, end (100 MHz counter)
+};
+// bench-only ablation bits of TAG (timing experiments; results are garbage).  The product instantiates TAG = 0.
+enum { RS_NOSTORE = 0x100, RS_NODMA = 0x200, RS_NOMATH = 0x400, RS_CLK = 0x40000, RS_NOPRIO = 0x2000, RS_NOEPI = 0x4000 };
+
+// (strip, pair) cursor over a workgroup's unit range, walking up or down
+struct RsCursor {
+    int strip, p;
+    __device__ __forceinline__ void init(int u, int npairs) { strip = u / npairs; p = u - strip * npairs; }
+    // advance by one step; returns true if the next step starts a new strip (its ring rows are all fresh)
+    __device__ __forceinline__ bool advance(int npairs, int descend) {
+        if (descend) { if (--p < 0) { p = npairs - 1; --strip; return true; } }
+        else if (++p >= npairs) { p = 0; ++strip; return true; }
+        return false;
+    }
+};
+
+// 64 lanes x 16 bytes global -> LDS, not tracked by the compiler: LDS destination = dst (wave-uniform) + lane * 16, source = base + voff
+__device__ __forceinline__ void rs_dma16(const unsigned char* base, unsigned voff, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+}
+
+#define RS_SYNC_LGKM() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define RS_SYNC_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")
+
+// The matrix work of one (row, output block N) is a fixed sequence of 38 MFMA pairs (A fragment, pixel fragment {hi, lo}): per K chunk c the
+// nine taps in order, then - if chunk c carries the input channels of output block N - the identity tap of the skip connection
+// (conv_t64_kernel's order: the accumulation is bit-identical).
+struct RsPairDesc { int c, t; bool idn; };
+__host__ __device__ constexpr RsPairDesc rs_pair(int N, int m) {
+    for (int c = 0; c < 4; c++) {
+        const int cnt = 9 + ((c >> 1) == N ? 1 : 0);
+        if (m < cnt) return m < 9 ? RsPairDesc{c, m, false} : RsPairDesc{c, 4, true};
+        m -= cnt;
+    }
+    return RsPairDesc{0, 0, false};
+}
+constexpr int RS_NPAIR = 38, RS_PF = 2;      // pairs per row; fragment prefetch distance in pairs (RS_PF + 1 fragment register sets)
+
+// consumer wave: output block N of row `ro` of every row pair of the workgroup's range (see the header of this file)
+template <int N, int TAG>
+__device__ __forceinline__ void rs_consumer(const RsArgs& a, unsigned char* const ldsb, const int ro, const int lane, const int S, const int ufirst) {
+    const int h = lane >> 5, li = lane & 31;
+    // weights of output block N: [chunk][tap] A fragments, lane (li, h) = row li, k half h (conv_t64's image: [chunk][tap][k half][64 rows][8 f16])
+    f16x8 W[4][9];
+    {
+        const unsigned char* wsrc = a.img + h * 1024 + (N * 32 + li) * 16;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int t = 0; t < 9; t++) W[c][t] = *reinterpret_cast<const f16x8*>(wsrc + c * t64_wch(2) + t * 2048);
+    }
+    f16x8 idf[2];                                                        // identity A fragments of the skip connection (conv_t64.h)
+    {
+        const int ch = s16_row_channel(li);
+#pragma unroll
+        for (int hc = 0; hc < 2; hc++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) idf[hc][e] = ch == 16 * hc + 8 * h + e ? (_Float16)1.f : (_Float16)0.f;
+    }
+    unsigned colo[3];                                                    // column part of the fragment addresses
+#pragma unroll
+    for (int dx = 0; dx < 3; dx++) { const int px = li + dx; colo[dx] = (unsigned)(px * 32 + ((h ^ ((px >> 3) & 1)) << 4)); }
+    const float* const bs = reinterpret_cast<const float*>(ldsb + RS_LDS_BS) + 32 * N + 16 * h;
+    const float slope = reinterpret_cast<const float*>(a.img + 4 * t64_wch(2))[64];      // one LeakyReLU slope for the whole layer (pack_t64_image)
+    unsigned char* const stg = ldsb + RS_LDS_STG + ro * RS_STG_ROW + (2 * N + h) * 2048 + li * 32;
+
+    RsCursor cur; cur.init(ufirst, a.npairs);
+    int sq = 0;                                                          // rows loaded through the current step, mod RS_NR
+    f32x16 accA, accB;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { accA[q] = 0.f; accB[q] = 0.f; }
+
+    // One iteration: the matrix work of the current step into acc and (EPI) the epilogue of the previous step's row - y = slope(prev + bias),
+    // split into {hi, lo}, zeros outside the valid pixels -> staging[par] - one output value per MFMA pair, so that the VALU work rides in
+    // the shadow of the matrix pipe (<= 5 issue slots are free per MFMA with one wave per SIMD).  The pixel fragments are read RS_PF pairs
+    // ahead of their MFMAs; sched_barrier keeps the compiler from sinking the reads back to their uses.
+    auto step = [&](auto math_c, auto epi_c, f32x16& acc, const f32x16& prev, const bool fresh, const int par, const int py, const int px0) {
+        constexpr bool MATH = decltype(math_c)::value && !(TAG & RS_NOMATH), EPI = decltype(epi_c)::value && !(TAG & RS_NOEPI);
+        unsigned ad[9];
+        if (MATH) {
+            sq += fresh ? 4 : 2; if (sq >= RS_NR) sq -= RS_NR;
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                const int j = ro + dy;                                   // row of the step's four halo rows, from the top
+                int sl = a.descend ? sq + RS_NR - 1 - j : sq + RS_NR - 4 + j;
+                if (sl >= RS_NR) sl -= RS_NR;
+                const unsigned rb = (unsigned)(RS_LDS_RING + sl * RS_ROWB);
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) ad[dy * 3 + dx] = rb + colo[dx];
+            }
+        }
+        const unsigned okmask = py + ro < a.H && px0 + li < a.W ? 0xffffffffu : 0u;
+        f16x8 fh[RS_PF + 1], fl[RS_PF + 1];
+        f16x8 hv[2], lv[2];
+        f32x4 bq[2];
+        f16x8* const dh = reinterpret_cast<f16x8*>(stg + par * (2 * RS_STG_ROW));
+        f16x8* const dl = reinterpret_cast<f16x8*>(stg + par * (2 * RS_STG_ROW) + 1024);
+        auto frag_read = [&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr RsPairDesc d = rs_pair(N, m);
+            fh[m % (RS_PF + 1)] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG));
+            fl[m % (RS_PF + 1)] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG) + RS_SEG);
+        };
+        // the bias of quad q + 1 is read while quad q is worked on (no LDS round trip in front of an MFMA)
+        auto epi_bias = [&](auto qc) { constexpr int q = decltype(qc)::value; bq[q & 1] = *reinterpret_cast<const f32x4*>(bs + 4 * q); };
+        auto epi_value = [&](auto ec) {
+            constexpr int e = decltype(ec)::value, q = e >> 2, k = e & 3;
+            if constexpr (k == 0 && q < 3) epi_bias(std::integral_constant<int, q + 1>{});
+            const float y = prev[e] + bq[q & 1][k];
+            float v = y < 0.f ? y * slope : y;
+            v = __uint_as_float(__float_as_uint(v) & okmask);
+            const _Float16 hh = (_Float16)v;
+            hv[e >> 3][e & 7] = hh;
+            lv[e >> 3][e & 7] = (_Float16)(v - (float)hh);
+            if (e == 7) { dh[0] = hv[0]; dl[0] = lv[0]; }
+            if (e == 15) { dh[1] = hv[1]; dl[1] = lv[1]; }
+        };
+        if (EPI) epi_bias(std::integral_constant<int, 0>{});
+        if (MATH) for_each_slot<0, RS_PF>(frag_read);
+        for_each_slot<0, RS_NPAIR>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (MATH) {
+                constexpr RsPairDesc d = rs_pair(N, m);
+                if constexpr (m + RS_PF < RS_NPAIR) frag_read(std::integral_constant<int, m + RS_PF>{});
+                const f16x8 A = d.idn ? idf[d.c & 1] : W[d.c][d.t];
+                if constexpr (m == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) z[q] = 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[0], z, 0, 0, 0);
+                } else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[m % (RS_PF + 1)], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[m % (RS_PF + 1)], acc, 0, 0, 0);
+            }
+            if constexpr (EPI && m >= 3 && m < 19) epi_value(std::integral_constant<int, m - 3>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+
+    RS_SYNC_LGKM();                                                      // ring rows of step 0 landed (loaders), bias / slopes in LDS
+    step(T_{}, F_{}, accA, accB, true, 0, 0, 0);                         // iteration 0: matrix work only
+    RS_SYNC_LGKM();
+    // iterations 1 .. S - 1, two per trip so that the accumulators swap roles without copies: odd iterations accumulate into accB
+    int it = 1;
+#define RS_ITER(ACC, PREV)                                                                                   \
+    {                                                                                                        \
+        const int py = 2 * cur.p, px0 = 32 * cur.strip;                  /* step it - 1 */                    \
+        const bool fresh = cur.advance(a.npairs, a.descend);                                                 \
+        step(T_{}, T_{}, ACC, PREV, fresh, (it - 1) & 1, py, px0);                                           \
+        RS_SYNC_LGKM();                                                                                      \
+        it++;                                                                                                \
+    }
+    while (it + 1 < S) { RS_ITER(accB, accA) RS_ITER(accA, accB) }
+    if (it < S) {
+        RS_ITER(accB, accA)
+        step(F_{}, T_{}, accA, accB, false, (S - 1) & 1, 2 * cur.p, 32 * cur.strip);     // iteration S: the last step's epilogue
+    } else step(F_{}, T_{}, accB, accA, false, (S - 1) & 1, 2 * cur.p, 32 * cur.strip);
+#undef RS_ITER
+    RS_SYNC_LGKM();
+}
+
+template <int TAG>
+__global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_rs_kernel(RsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave role (wave-uniform by construction)
+    long long clk0 = 0, rt0 = 0;
+    if (TAG & RS_CLK) { clk0 = (long long)__builtin_readcyclecounter(); rt0 = (long long)__builtin_amdgcn_s_memrealtime(); }
+
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int u0 = (int)((long long)a.nunits * b / nwg), u1 = (int)((long long)a.nunits * (b + 1) / nwg);
+    const int S = u1 - u0;                                               // steps of this workgroup
+    if (S <= 0) return;
+    const int ufirst = a.descend ? u1 - 1 : u0;
+    // every iteration ends with RS_SYNC_*: all eight waves execute the same S + 2 of them
+
+    if (wv < 4) {
+        // ------------------------------------------------------------------------------------------------ consumers
+        if (!(TAG & RS_NOPRIO)) __builtin_amdgcn_s_setprio(2);          // the matrix waves win the issue arbitration against their SIMD's loader / storer
+        if (wv == 0 && lane < 32) reinterpret_cast<f32x4*>(ldsb + RS_LDS_BS)[lane] = reinterpret_cast<const f32x4*>(a.img + 4 * t64_wch(2))[lane];
+        if (wv & 1) rs_consumer<1, TAG>(a, ldsb, wv >> 1, lane, S, ufirst);
+        else rs_consumer<0, TAG>(a, ldsb, wv >> 1, lane, S, ufirst);
+    } else if (wv < 6) {
+        // ------------------------------------------------------------------------------------------------ loaders
+        const int j = wv - 4;
+        // piece i of a row covers LDS units 64 i .. 64 i + 63 (16 bytes each) of the 544 of a row slot: unit = (segment, pixel, half)
+        unsigned soff[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int u = min(i * 64 + lane, 543);
+            const int seg = u / 68, within = u - seg * 68;
+            const int px = within >> 1, pos = within & 1;
+            const int kh = pos ^ ((px >> 3) & 1);
+            soff[i] = (unsigned)seg * a.plane + (unsigned)(px * 32 + kh * 16);
+        }
+        RsCursor cur; cur.init(ufirst, a.npairs);
+        int sq = 0;                                                      // rows loaded so far, mod RS_NR
+        // the new rows of the step at `cur` (4 if fresh, else 2), in ring order; this wave takes rows j and j + 2.  Returns its piece count.
+        auto load_step = [&](bool fresh) -> int {
+            const int nnew = fresh ? 4 : 2;
+            const int y = 2 * cur.p, x0 = 32 * cur.strip;
+            int mine = 0;
+            for (int i = j; i < nnew; i += 2) {
+                const int prow = a.descend ? y + nnew - 1 - i : y + 4 - nnew + i;       // padded row index (pixel row prow - 1)
+                int sl = sq + i; if (sl >= RS_NR) sl -= RS_NR;
+                if (!(TAG & RS_NODMA)) {
+                    const unsigned rowoff = (unsigned)(prow * a.pitch + x0) * 32u;
+                    const unsigned dst = (unsigned)(RS_LDS_RING + sl * RS_ROWB);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) rs_dma16(a.in, rowoff + soff[k], dst + k * 1024);
+                    if (lane < 32) rs_dma16(a.in, rowoff + soff[8], dst + 8 * 1024);
+                }
+                mine += 9;
+            }
+            sq += nnew; if (sq >= RS_NR) sq -= RS_NR;
+            return mine;
+        };
+        if (TAG & RS_NODMA) { for (int i = lane + 64 * j; i < RS_LDS_STG / 16; i += 128) reinterpret_cast<f32x4*>(ldsb)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // prologue: rows of steps 0 and 1
+        load_step(true);
+        int ahead = 0;                                                   // my pieces of the newest step issued
+        if (S > 1) { const bool f = cur.advance(a.npairs, a.descend); ahead = load_step(f); }
+#define RS_WAIT_AHEAD()                                                                                      \
+        if (TAG & RS_NODMA) RS_SYNC_LGKM();                                                                  \
+        else if (ahead == 0) RS_SYNC_VM(0);                                                                  \
+        else if (ahead == 9) RS_SYNC_VM(9);                                                                  \
+        else RS_SYNC_VM(18);
+        RS_WAIT_AHEAD()                                                  // rows of step 0 landed
+        for (int it = 0; it <= S; it++) {
+            if (it + 2 < S) { const bool f = cur.advance(a.npairs, a.descend); ahead = load_step(f); }
+            else ahead = 0;
+            RS_WAIT_AHEAD()                                              // rows of step it + 1 landed
+        }
+#undef RS_WAIT_AHEAD
+    } else {
+        // ------------------------------------------------------------------------------------------------ storers
+        const int j = wv - 6;                                            // output row of the pair
+        RsCursor cur; cur.init(ufirst, a.npairs);
+        RS_SYNC_LGKM();
+        for (int it = 0; it <= S + 1; it++) {
+            if (it >= 2) {                                               // step it - 2, staged during iteration it - 1
+                const int y = 2 * cur.p + j, x0 = 32 * cur.strip;
+                if (y < a.H && !(TAG & RS_NOSTORE)) {
+                    const unsigned char* src = ldsb + RS_LDS_STG + (it & 1) * (2 * RS_STG_ROW) + j * RS_STG_ROW + lane * 16;
+                    unsigned char* dst = a.out + ((unsigned)((y + 1) * a.pitch + x0 + 1) * 32u + (unsigned)(lane * 16));
+                    f32x4 v[8];
+#pragma unroll
+                    for (int sg = 0; sg < 8; sg++) v[sg] = *reinterpret_cast<const f32x4*>(src + sg * 1024);
+#pragma unroll
+                    for (int sg = 0; sg < 8; sg++) *reinterpret_cast<f32x4*>(dst + (size_t)sg * a.plane) = v[sg];
+                }
+                cur.advance(a.npairs, a.descend);
+            }
+            if (it <= S) RS_SYNC_LGKM();
+        }
+    }
+#undef RS_SYNC_LGKM
+#undef RS_SYNC_VM
+    if ((TAG & RS_CLK) && tid == 0) {
+        a.stamps[4 * blockIdx.x] = (long long)__builtin_readcyclecounter() - clk0;
+        a.stamps[4 * blockIdx.x + 1] = rt0;
+        a.stamps[4 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+}
+
+}  // namespace rife

@@ -29,6 +29,7 @@
 #include "head_h2.h"
 #include "conv_t64.h"
 #include "conv_row.h"
+#include "conv_rs.h"
 #include "graph_kernels.h"
 #include "model_hashes.h"
 #include "ncnn_model.h"
@@ -669,6 +670,35 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
     return 0;
 }
 
+// the same 64 -> 64 layer on the row-streaming kernel (conv_rs.h): one workgroup per CU, specialised waves.  descend: walk every
+// workgroup's range bottom-up; consecutive layers alternate so that a layer starts on the rows its predecessor wrote last.
+static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool descend = false) {
+    if (!L.d_t64 || L.cout != 64) return fail(RIFE_HIP_EINVAL, "layer has no 64-channel conv_t64 image");
+    int dev = 0; (void)hipGetDevice(&dev);
+    static std::mutex mu; static std::map<int, int> ncu;
+    int cus;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = ncu.find(dev);
+        if (it == ncu.end()) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS));
+            int n = 0;
+            HIPCHK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+            it = ncu.emplace(dev, std::max(1, n)).first;
+        }
+        cus = it->second;
+    }
+    const S16Geom G(H, W);
+    RsArgs a;
+    a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane();
+    a.npairs = (H + 1) / 2; a.nunits = G.tiles_x * a.npairs; a.descend = descend ? 1 : 0;
+    const int nwg = std::min(cus, a.nunits);                             // one workgroup per CU (137 KB of LDS), all resident
+    hipLaunchKernelGGL((conv_rs_kernel<0>), dim3(nwg), dim3(RS_NTHR), RS_LDS, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_rs launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
 // one C -> C (C = 128, 192) residual trunk convolution of a coarse block, S16 in / S16 out: one workgroup per ROWS x 32 pixels (conv_row.h)
 static int launch_row(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st) {
     const unsigned char* const rimg = L.cout == 96 ? L.d_row : L.d_t64;
@@ -850,6 +880,8 @@ struct rife_hip {
     // finest-block trunk on S16 tensors + the persistent conv_t64 kernel (RIFE_HIP_T64=0 at create time keeps conv_h2b: A/B and
     // the bit-equality test of the two trunk implementations)
     bool t64 = true;
+    // block-3 trunk on the row-streaming kernel (conv_rs.h) instead of conv_t64 (RIFE_HIP_RS=0 at create time: A/B, bit-equality test)
+    bool rs = true;
     int flow_div(int b) const { return v40 ? 2 * blk[b].scale : blk[b].scale; }
     // rife-v2.x schedule (IFNet + ContextNet + FusionNet)
     struct V2Block { ConvLayer stem0, stem1, conv[6], head; int c = 0, scale = 1; } fblk[4];
@@ -1063,7 +1095,10 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         unsigned char *pc = PA, *pn = PB;
         for (int i = 0; i < 8; i++) {
             Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
-            if ((rc = rowk ? launch_row(B.res[i], pc, pn, Ht, Wt, st) : launch_t64(B.res[i], pc, pn, Ht, Wt, st, (i & 1) == 0))) return rc;
+            if (rowk) rc = launch_row(B.res[i], pc, pn, Ht, Wt, st);
+            else if (E.rs && B.c == 64) rc = launch_rs(B.res[i], pc, pn, Ht, Wt, st, (i & 1) != 0);
+            else rc = launch_t64(B.res[i], pc, pn, Ht, Wt, st, (i & 1) == 0);
+            if (rc) return rc;
             std::swap(pc, pn);
         }
         Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);
@@ -1883,6 +1918,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     E->frame_pool = std::make_shared<FramePool>();
     E->frame_pool->gpuid = gpuid;
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
+    { const char* e = getenv("RIFE_HIP_RS"); E->rs = !(e && e[0] == '0'); }
     return E;
 }
 

@@ -41,7 +41,7 @@ def pair(modeldirs):
                                         (1920, 1080, 0.5, 6), (1000, 520, 0.3, 7), (3840, 2160, 0.5, 8)])
 def test_t64_output_is_bit_identical_to_the_per_tile_trunk(pair, w, h, t, seed):
     new, old = pair
-    a, b = gen_frames.smooth_pair(w, h, seed) if w * h < 4000000 else [np.kron(f, np.ones((4, 4, 1), np.uint8)) for f in gen_frames.smooth_pair(w // 4, h // 4, seed)]
+    a, b = gen_frames.smooth_pair(w, h, seed) if w * h < 4000000 else gen_frames.smooth_pair_native(w, h, seed)
     def check(x, y, what):
         d = np.abs(x.astype(np.int32) - y.astype(np.int32))
         report = "%s: %d of %d bytes differ, max %d" % (what, int((d > 0).sum()), d.size, int(d.max()))
@@ -69,3 +69,47 @@ def test_t64_tta_passes_match(modeldirs):
     a, b = gen_frames.smooth_pair(100, 60, 11)
     d = np.abs(new.process(a, b, 0.4).astype(np.int32) - old.process(a, b, 0.4).astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+# ---- round 3: the row-streaming kernel (csrc/conv_rs.h) that serves the block-3 trunk by default, against conv_t64 (RIFE_HIP_RS=0) ----
+def _engine_rs(modeldir, rs, **kw):
+    old = os.environ.get("RIFE_HIP_RS")
+    os.environ["RIFE_HIP_RS"] = "1" if rs else "0"      # read by rife_hip_create
+    try:
+        g = amd.RIFE(0, rife_v4=True, **kw)
+    finally:
+        if old is None:
+            del os.environ["RIFE_HIP_RS"]
+        else:
+            os.environ["RIFE_HIP_RS"] = old
+    g.load(modeldir)
+    return g
+
+
+@pytest.fixture(scope="module")
+def pair_rs(modeldirs):
+    d = modeldirs["rife-v4.6"]
+    return _engine_rs(d, True), _engine_rs(d, False)
+
+
+@pytest.mark.parametrize("w,h,t,seed", [(640, 360, 0.5, 1), (256, 192, 0.125, 2), (100, 60, 0.7, 3), (33, 47, 0.9, 4), (1, 1, 0.5, 5), (130, 9, 0.5, 12),
+                                        (1920, 1080, 0.5, 6), (1000, 520, 0.3, 7), (3840, 2160, 0.5, 8)])
+def test_rs_output_is_bit_identical_to_conv_t64(pair_rs, w, h, t, seed):
+    """Same products, same accumulation order, same epilogue (conv_rs.h header): every byte of the frame and every float of the block-3 flow
+    must be equal at every size - both engines run the same kernels everywhere else."""
+    new, old = pair_rs
+    a, b = gen_frames.smooth_pair(w, h, seed) if w * h < 4000000 else gen_frames.smooth_pair_native(w, h, seed)
+    for x, y, tt in ((a, b, t), (b, a, 1.0 - t)):          # the second call runs on a used workspace: zero borders of the S16 tensors intact
+        assert np.array_equal(new.process(x, y, tt), old.process(x, y, tt)), "frames differ at %dx%d" % (w, h)
+    if w * h <= 1920 * 1080:
+        assert np.array_equal(new.v4_extract_flow(a, b, t, 3), old.v4_extract_flow(a, b, t, 3)), "block-3 flows differ at %dx%d" % (w, h)
+    x = new.process(a, b, t)
+    for _ in range(3):
+        assert np.array_equal(x, new.process(a, b, t)), "the row-streaming kernel is not deterministic"
+
+
+def test_rs_tta_passes_match(modeldirs):
+    d = modeldirs["rife-v4.6"]
+    new, old = _engine_rs(d, True, tta_mode=True, tta_temporal_mode=True), _engine_rs(d, False, tta_mode=True, tta_temporal_mode=True)
+    a, b = gen_frames.smooth_pair(100, 60, 11)
+    assert np.array_equal(new.process(a, b, 0.4), old.process(a, b, 0.4))
