@@ -387,8 +387,8 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
 }
 
 // bench-only: the row-streaming trunk kernel (conv_rs.h) on an h x w tensor of random records.  First its output (walking down, then walking
-// up) is compared byte for byte with conv_t64_kernel's on the same input: stats[0] / stats[1] = differing bytes (down / up), stats[2..5] = plane,
-// padded row, padded column, byte of the first difference (down), stats[6] = bytes compared.  Then `iters` launches ping-pong between two
+// up) is compared with conv_t64_kernel's on the same input: stats[0] / stats[1] = differing bytes (down / up), stats[2] / stats[3] = the largest
+// difference of the stored values hi + lo x 1e9, stats[4], [5], [7] = chunk, padded row, padded column of it (down), stats[6] = bytes compared.  Then `iters` launches ping-pong between two
 // tensors like consecutive trunk layers.  variant = ablation bits of conv_rs.h | 0x10000 (layers alternate direction) | 0x20000 (always up)
 // | 0x1000000 * g (g > 0: launch g workgroups instead of one per CU).
 int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms_out, long long* stats) {
@@ -445,16 +445,25 @@ int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms
             hipLaunchKernelGGL((conv_rs_kernel<0>), dim3(nwg), dim3(RS_NTHR), RS_LDS, 0, a);
             HIPCHK(hipDeviceSynchronize());
             HIPCHK(hipMemcpy(got.data(), y, nb, hipMemcpyDeviceToHost));
+            // bytes that differ, and the largest difference of the values hi + lo the two kernels stored (another summation order only
+            // moves the last bits: ~1e-6; a wrong tap, row or channel is O(0.1))
             long long bad = 0;
-            for (size_t i = 0; i < nb; i++)
-                if (ref[i] != got[i]) {
-                    if (!bad && dir == 0) {
-                        const size_t pli = i / G.plane(), rem = i % G.plane();
-                        stats[2] = (long long)pli; stats[3] = (long long)(rem / ((size_t)G.pitch * 32)); stats[4] = (long long)(rem % ((size_t)G.pitch * 32) / 32); stats[5] = (long long)(rem % 32);
+            double maxd = 0.0;
+            const size_t ple = G.plane() / 2;                            // f16 elements per plane
+            const _Float16* rh = reinterpret_cast<const _Float16*>(ref.data()); const _Float16* gh = reinterpret_cast<const _Float16*>(got.data());
+            for (size_t i = 0; i < nb; i++) bad += ref[i] != got[i];
+            for (int c = 0; c < 4; c++)
+                for (size_t e = 0; e < ple; e++) {
+                    const double vr = (double)(float)rh[(2 * c) * ple + e] + (double)(float)rh[(2 * c + 1) * ple + e];
+                    const double vg = (double)(float)gh[(2 * c) * ple + e] + (double)(float)gh[(2 * c + 1) * ple + e];
+                    const double d = vr > vg ? vr - vg : vg - vr;
+                    if (!(d <= maxd)) {                                  // also catches NaN
+                        maxd = d == d ? d : 1e9;
+                        if (dir == 0) { stats[4] = (long long)c; stats[5] = (long long)(e / ((size_t)G.pitch * 16)); stats[7] = (long long)(e % ((size_t)G.pitch * 16) / 16); }
                     }
-                    bad++;
                 }
             stats[dir] = bad;
+            stats[2 + dir] = (long long)(maxd * 1e9);
         }
         stats[6] = (long long)nb;
         a.descend = 0;
@@ -512,11 +521,12 @@ int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms
         case RS_NODMA: rc = run(conv_rs_kernel<RS_NODMA>); break;
         case RS_NOMATH: rc = run(conv_rs_kernel<RS_NOMATH>); break;
         case RS_NOPRIO: rc = run(conv_rs_kernel<RS_NOPRIO>); break;
-        case RS_NOEPI: rc = run(conv_rs_kernel<RS_NOEPI>); break;
+        case RS_NTLOAD: rc = run(conv_rs_kernel<RS_NTLOAD>); break;
+        case RS_NTSTORE: rc = run(conv_rs_kernel<RS_NTSTORE>); break;
+        case RS_NTLOAD | RS_NTSTORE: rc = run(conv_rs_kernel<RS_NTLOAD | RS_NTSTORE>); break;
         case RS_NODMA | RS_NOSTORE: rc = run(conv_rs_kernel<RS_NODMA | RS_NOSTORE>); break;
         case RS_NOMATH | RS_NOSTORE: rc = run(conv_rs_kernel<RS_NOMATH | RS_NOSTORE>); break;
         case RS_NOMATH | RS_NODMA: rc = run(conv_rs_kernel<RS_NOMATH | RS_NODMA>); break;
-        case RS_NODMA | RS_NOSTORE | RS_NOEPI: rc = run(conv_rs_kernel<RS_NODMA | RS_NOSTORE | RS_NOEPI>); break;
         default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
     }
     (void)hipFree(x); (void)hipFree(y); (void)hipFree(yr); (void)hipFree(dimg); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

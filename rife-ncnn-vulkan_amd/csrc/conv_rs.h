@@ -58,7 +58,7 @@ struct RsArgs {
     long long* stamps = nullptr; // bench builds (TAG & RS_CLK): [workgroup][4] = shader cycles of the workgroup's life, start, end (100 MHz counter)
 };
 // bench-only ablation bits of TAG (timing experiments; results are garbage).  The product instantiates TAG = 0.
-enum { RS_NOSTORE = 0x100, RS_NODMA = 0x200, RS_NOMATH = 0x400, RS_CLK = 0x40000, RS_NOPRIO = 0x2000, RS_NOEPI = 0x4000 };
+enum { RS_NOSTORE = 0x100, RS_NODMA = 0x200, RS_NOMATH = 0x400, RS_CLK = 0x40000, RS_NOPRIO = 0x2000, RS_NTLOAD = 0x4000, RS_NTSTORE = 0x8000 };
 
 // (strip, pair) cursor over a workgroup's unit range, walking up or down
 struct RsCursor {
@@ -73,10 +73,15 @@ struct RsCursor {
 };
 
 // 64 lanes x 16 bytes global -> LDS, not tracked by the compiler: LDS destination = dst (wave-uniform) + lane * 16, source = base + voff
+template <int TAG>
 __device__ __forceinline__ void rs_dma16(const unsigned char* base, unsigned voff, unsigned dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+    if (TAG & RS_NTLOAD)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
 }
 
 #define RS_SYNC_LGKM() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -94,7 +99,7 @@ __host__ __device__ constexpr RsPairDesc rs_pair(int N, int m) {
     }
     return RsPairDesc{0, 0, false};
 }
-constexpr int RS_NPAIR = 38, RS_PF = 2;      // pairs per row; fragment prefetch distance in pairs (RS_PF + 1 fragment register sets)
+constexpr int RS_NPAIR = 38, RS_PF = 3;      // pairs per row; fragment prefetch distance in pairs (RS_PF + 1 fragment register sets)
 
 // consumer wave: output block N of row `ro` of every row pair of the workgroup's range (see the header of this file)
 template <int N, int TAG>
@@ -120,66 +125,42 @@ __device__ __forceinline__ void rs_consumer(const RsArgs& a, unsigned char* cons
     unsigned colo[3];                                                    // column part of the fragment addresses
 #pragma unroll
     for (int dx = 0; dx < 3; dx++) { const int px = li + dx; colo[dx] = (unsigned)(px * 32 + ((h ^ ((px >> 3) & 1)) << 4)); }
-    const float* const bs = reinterpret_cast<const float*>(ldsb + RS_LDS_BS) + 32 * N + 16 * h;
-    const float slope = reinterpret_cast<const float*>(a.img + 4 * t64_wch(2))[64];      // one LeakyReLU slope for the whole layer (pack_t64_image)
-    unsigned char* const stg = ldsb + RS_LDS_STG + ro * RS_STG_ROW + (2 * N + h) * 2048 + li * 32;
+    // staged record of this lane: 16 fp32 = channels 32 N + 16 h .. + 15 of pixel li, the four 16-byte quads XOR-swizzled by (li >> 1) & 3
+    // (the eight lanes of a ds_write_b128 group then cover all 32 banks)
+    unsigned char* const stg = ldsb + RS_LDS_STG + ro * RS_STG_ROW + ((2 * N + h) * 32 + li) * 64;
+    const int qs = (li >> 1) & 3;
 
     RsCursor cur; cur.init(ufirst, a.npairs);
     int sq = 0;                                                          // rows loaded through the current step, mod RS_NR
-    f32x16 accA, accB;
-#pragma unroll
-    for (int q = 0; q < 16; q++) { accA[q] = 0.f; accB[q] = 0.f; }
-
-    // One iteration: the matrix work of the current step into acc and (EPI) the epilogue of the previous step's row - y = slope(prev + bias),
-    // split into {hi, lo}, zeros outside the valid pixels -> staging[par] - one output value per MFMA pair, so that the VALU work rides in
-    // the shadow of the matrix pipe (<= 5 issue slots are free per MFMA with one wave per SIMD).  The pixel fragments are read RS_PF pairs
-    // ahead of their MFMAs; sched_barrier keeps the compiler from sinking the reads back to their uses.
-    auto step = [&](auto math_c, auto epi_c, f32x16& acc, const f32x16& prev, const bool fresh, const int par, const int py, const int px0) {
-        constexpr bool MATH = decltype(math_c)::value && !(TAG & RS_NOMATH), EPI = decltype(epi_c)::value && !(TAG & RS_NOEPI);
+    RS_SYNC_LGKM();                                                      // ring rows of step 0 landed (loaders), bias in LDS
+    for (int it = 0; it < S; it++) {
+        const bool fresh = it == 0 || cur.advance(a.npairs, a.descend);
+        sq += fresh ? 4 : 2; if (sq >= RS_NR) sq -= RS_NR;
         unsigned ad[9];
-        if (MATH) {
-            sq += fresh ? 4 : 2; if (sq >= RS_NR) sq -= RS_NR;
 #pragma unroll
-            for (int dy = 0; dy < 3; dy++) {
-                const int j = ro + dy;                                   // row of the step's four halo rows, from the top
-                int sl = a.descend ? sq + RS_NR - 1 - j : sq + RS_NR - 4 + j;
-                if (sl >= RS_NR) sl -= RS_NR;
-                const unsigned rb = (unsigned)(RS_LDS_RING + sl * RS_ROWB);
+        for (int dy = 0; dy < 3; dy++) {
+            const int j = ro + dy;                                       // row of the step's four halo rows, from the top
+            int sl = a.descend ? sq + RS_NR - 1 - j : sq + RS_NR - 4 + j;
+            if (sl >= RS_NR) sl -= RS_NR;
+            const unsigned rb = (unsigned)(RS_LDS_RING + sl * RS_ROWB);
 #pragma unroll
-                for (int dx = 0; dx < 3; dx++) ad[dy * 3 + dx] = rb + colo[dx];
-            }
+            for (int dx = 0; dx < 3; dx++) ad[dy * 3 + dx] = rb + colo[dx];
         }
-        const unsigned okmask = py + ro < a.H && px0 + li < a.W ? 0xffffffffu : 0u;
+        // Two accumulation chains, the hi products and the lo products: an MFMA never waits for the result of the one issued just before
+        // it (one wave per SIMD: nobody else would fill the gap).  The pixel fragments are read RS_PF pairs ahead of their MFMAs;
+        // sched_barrier keeps the compiler from sinking the reads back to their uses.
+        f32x16 accH, accL;
         f16x8 fh[RS_PF + 1], fl[RS_PF + 1];
-        f16x8 hv[2], lv[2];
-        f32x4 bq[2];
-        f16x8* const dh = reinterpret_cast<f16x8*>(stg + par * (2 * RS_STG_ROW));
-        f16x8* const dl = reinterpret_cast<f16x8*>(stg + par * (2 * RS_STG_ROW) + 1024);
         auto frag_read = [&](auto mc) {
             constexpr int m = decltype(mc)::value;
             constexpr RsPairDesc d = rs_pair(N, m);
             fh[m % (RS_PF + 1)] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG));
             fl[m % (RS_PF + 1)] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG) + RS_SEG);
         };
-        // the bias of quad q + 1 is read while quad q is worked on (no LDS round trip in front of an MFMA)
-        auto epi_bias = [&](auto qc) { constexpr int q = decltype(qc)::value; bq[q & 1] = *reinterpret_cast<const f32x4*>(bs + 4 * q); };
-        auto epi_value = [&](auto ec) {
-            constexpr int e = decltype(ec)::value, q = e >> 2, k = e & 3;
-            if constexpr (k == 0 && q < 3) epi_bias(std::integral_constant<int, q + 1>{});
-            const float y = prev[e] + bq[q & 1][k];
-            float v = y < 0.f ? y * slope : y;
-            v = __uint_as_float(__float_as_uint(v) & okmask);
-            const _Float16 hh = (_Float16)v;
-            hv[e >> 3][e & 7] = hh;
-            lv[e >> 3][e & 7] = (_Float16)(v - (float)hh);
-            if (e == 7) { dh[0] = hv[0]; dl[0] = lv[0]; }
-            if (e == 15) { dh[1] = hv[1]; dl[1] = lv[1]; }
-        };
-        if (EPI) epi_bias(std::integral_constant<int, 0>{});
-        if (MATH) for_each_slot<0, RS_PF>(frag_read);
-        for_each_slot<0, RS_NPAIR>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            if constexpr (MATH) {
+        if (!(TAG & RS_NOMATH)) {
+            for_each_slot<0, RS_PF>(frag_read);
+            for_each_slot<0, RS_NPAIR>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
                 constexpr RsPairDesc d = rs_pair(N, m);
                 if constexpr (m + RS_PF < RS_NPAIR) frag_read(std::integral_constant<int, m + RS_PF>{});
                 const f16x8 A = d.idn ? idf[d.c & 1] : W[d.c][d.t];
@@ -187,36 +168,29 @@ __device__ __forceinline__ void rs_consumer(const RsArgs& a, unsigned char* cons
                     f32x16 z;
 #pragma unroll
                     for (int q = 0; q < 16; q++) z[q] = 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[0], z, 0, 0, 0);
-                } else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[m % (RS_PF + 1)], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[m % (RS_PF + 1)], acc, 0, 0, 0);
-            }
-            if constexpr (EPI && m >= 3 && m < 19) epi_value(std::integral_constant<int, m - 3>{});
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    using T_ = std::true_type; using F_ = std::false_type;
-
-    RS_SYNC_LGKM();                                                      // ring rows of step 0 landed (loaders), bias / slopes in LDS
-    step(T_{}, F_{}, accA, accB, true, 0, 0, 0);                         // iteration 0: matrix work only
-    RS_SYNC_LGKM();
-    // iterations 1 .. S - 1, two per trip so that the accumulators swap roles without copies: odd iterations accumulate into accB
-    int it = 1;
-#define RS_ITER(ACC, PREV)                                                                                   \
-    {                                                                                                        \
-        const int py = 2 * cur.p, px0 = 32 * cur.strip;                  /* step it - 1 */                    \
-        const bool fresh = cur.advance(a.npairs, a.descend);                                                 \
-        step(T_{}, T_{}, ACC, PREV, fresh, (it - 1) & 1, py, px0);                                           \
-        RS_SYNC_LGKM();                                                                                      \
-        it++;                                                                                                \
+                    accH = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[0], z, 0, 0, 0);
+                    accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[0], z, 0, 0, 0);
+                } else {
+                    accH = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[m % (RS_PF + 1)], accH, 0, 0, 0);
+                    accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[m % (RS_PF + 1)], accL, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) { accH[q] = (float)lane; accL[q] = 0.f; }
+        }
+        // raw sums -> staging[it & 1]; bias, LeakyReLU and the {hi, lo} split are the storers' work
+        f32x4* const d4 = reinterpret_cast<f32x4*>(stg + (it & 1) * (2 * RS_STG_ROW));
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = accH[4 * q + k] + accL[4 * q + k];
+            d4[q ^ qs] = v;
+        }
+        RS_SYNC_LGKM();
     }
-    while (it + 1 < S) { RS_ITER(accB, accA) RS_ITER(accA, accB) }
-    if (it < S) {
-        RS_ITER(accB, accA)
-        step(F_{}, T_{}, accA, accB, false, (S - 1) & 1, 2 * cur.p, 32 * cur.strip);     // iteration S: the last step's epilogue
-    } else step(F_{}, T_{}, accB, accA, false, (S - 1) & 1, 2 * cur.p, 32 * cur.strip);
-#undef RS_ITER
-    RS_SYNC_LGKM();
 }
 
 template <int TAG>
@@ -267,8 +241,8 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     const unsigned rowoff = (unsigned)(prow * a.pitch + x0) * 32u;
                     const unsigned dst = (unsigned)(RS_LDS_RING + sl * RS_ROWB);
 #pragma unroll
-                    for (int k = 0; k < 8; k++) rs_dma16(a.in, rowoff + soff[k], dst + k * 1024);
-                    if (lane < 32) rs_dma16(a.in, rowoff + soff[8], dst + 8 * 1024);
+                    for (int k = 0; k < 8; k++) rs_dma16<TAG>(a.in, rowoff + soff[k], dst + k * 1024);
+                    if (lane < 32) rs_dma16<TAG>(a.in, rowoff + soff[8], dst + 8 * 1024);
                 }
                 mine += 9;
             }
@@ -286,7 +260,7 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
         else if (ahead == 9) RS_SYNC_VM(9);                                                                  \
         else RS_SYNC_VM(18);
         RS_WAIT_AHEAD()                                                  // rows of step 0 landed
-        for (int it = 0; it <= S; it++) {
+        for (int it = 0; it < S; it++) {
             if (it + 2 < S) { const bool f = cur.advance(a.npairs, a.descend); ahead = load_step(f); }
             else ahead = 0;
             RS_WAIT_AHEAD()                                              // rows of step it + 1 landed
@@ -294,28 +268,51 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #undef RS_WAIT_AHEAD
     } else {
         // ------------------------------------------------------------------------------------------------ storers
-        const int j = wv - 6;                                            // output row of the pair
+        // wave j finishes output row j of the pair staged by the consumers in the previous iteration: y = slope(sum + bias), split into
+        // {hi, lo}, zeros outside the valid pixels; lane = (pixel l >> 1, half l & 1) of a 16-channel chunk: 8 values in, 16 bytes of the
+        // hi plane and 16 of the lo plane out, 1 KiB contiguous per store instruction
+        const int j = wv - 6;
+        const int px = lane >> 1, jh = lane & 1, qs = (px >> 1) & 3;
+        const float slope = reinterpret_cast<const float*>(a.img + 4 * t64_wch(2))[64];      // one LeakyReLU slope for the whole layer (pack_t64_image)
         RsCursor cur; cur.init(ufirst, a.npairs);
         RS_SYNC_LGKM();
-        for (int it = 0; it <= S + 1; it++) {
-            if (it >= 2) {                                               // step it - 2, staged during iteration it - 1
+        for (int it = 0; it <= S; it++) {
+            if (it >= 1) {                                               // step it - 1, staged during iteration it - 1
                 const int y = 2 * cur.p + j, x0 = 32 * cur.strip;
                 if (y < a.H && !(TAG & RS_NOSTORE)) {
-                    const unsigned char* src = ldsb + RS_LDS_STG + (it & 1) * (2 * RS_STG_ROW) + j * RS_STG_ROW + lane * 16;
+                    const unsigned okmask = x0 + px < a.W ? 0xffffffffu : 0u;
+                    const unsigned char* src = ldsb + RS_LDS_STG + ((it - 1) & 1) * (2 * RS_STG_ROW) + j * RS_STG_ROW + px * 64;
                     unsigned char* dst = a.out + ((unsigned)((y + 1) * a.pitch + x0 + 1) * 32u + (unsigned)(lane * 16));
-                    f32x4 v[8];
 #pragma unroll
-                    for (int sg = 0; sg < 8; sg++) v[sg] = *reinterpret_cast<const f32x4*>(src + sg * 1024);
+                    for (int cc = 0; cc < 4; cc++) {
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(src + cc * 2048 + (((2 * jh) ^ qs) << 4));
+                        const f32x4 r1 = *reinterpret_cast<const f32x4*>(src + cc * 2048 + (((2 * jh + 1) ^ qs) << 4));
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ldsb + RS_LDS_BS + (16 * cc + 8 * jh) * 4);
+                        const f32x4 b1 = *reinterpret_cast<const f32x4*>(ldsb + RS_LDS_BS + (16 * cc + 8 * jh + 4) * 4);
+                        f16x8 hv, lv;
 #pragma unroll
-                    for (int sg = 0; sg < 8; sg++) *reinterpret_cast<f32x4*>(dst + (size_t)sg * a.plane) = v[sg];
+                        for (int e = 0; e < 8; e++) {
+                            const float yv = (e < 4 ? r0[e & 3] : r1[e & 3]) + (e < 4 ? b0[e & 3] : b1[e & 3]);
+                            float v = yv < 0.f ? yv * slope : yv;
+                            v = __uint_as_float(__float_as_uint(v) & okmask);
+                            const _Float16 hh = (_Float16)v;
+                            hv[e] = hh;
+                            lv[e] = (_Float16)(v - (float)hh);
+                        }
+                        if (TAG & RS_NTSTORE) {
+                            __builtin_nontemporal_store(hv, reinterpret_cast<f16x8*>(dst + (size_t)(2 * cc) * a.plane));
+                            __builtin_nontemporal_store(lv, reinterpret_cast<f16x8*>(dst + (size_t)(2 * cc + 1) * a.plane));
+                        } else {
+                            *reinterpret_cast<f16x8*>(dst + (size_t)(2 * cc) * a.plane) = hv;
+                            *reinterpret_cast<f16x8*>(dst + (size_t)(2 * cc + 1) * a.plane) = lv;
+                        }
+                    }
                 }
                 cur.advance(a.npairs, a.descend);
             }
-            if (it <= S) RS_SYNC_LGKM();
+            if (it < S) RS_SYNC_LGKM();
         }
     }
-#undef RS_SYNC_LGKM
-#undef RS_SYNC_VM
     if ((TAG & RS_CLK) && tid == 0) {
         a.stamps[4 * blockIdx.x] = (long long)__builtin_readcyclecounter() - clk0;
         a.stamps[4 * blockIdx.x + 1] = rt0;

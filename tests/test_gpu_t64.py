@@ -94,15 +94,18 @@ def pair_rs(modeldirs):
 
 @pytest.mark.parametrize("w,h,t,seed", [(640, 360, 0.5, 1), (256, 192, 0.125, 2), (100, 60, 0.7, 3), (33, 47, 0.9, 4), (1, 1, 0.5, 5), (130, 9, 0.5, 12),
                                         (1920, 1080, 0.5, 6), (1000, 520, 0.3, 7), (3840, 2160, 0.5, 8)])
-def test_rs_output_is_bit_identical_to_conv_t64(pair_rs, w, h, t, seed):
-    """Same products, same accumulation order, same epilogue (conv_rs.h header): every byte of the frame and every float of the block-3 flow
-    must be equal at every size - both engines run the same kernels everywhere else."""
+def test_rs_output_matches_conv_t64(pair_rs, w, h, t, seed):
+    """Same products, same epilogue; conv_rs sums the hi and the lo products of a layer in two chains (conv_rs.h header), conv_t64 in one:
+    the two engines agree to summation-order noise - frames within 1 LSB with very few channels touched, block-3 flows to 1e-4 - at
+    aligned, ragged and tiny sizes, on a used workspace, and conv_rs is deterministic."""
     new, old = pair_rs
     a, b = gen_frames.smooth_pair(w, h, seed) if w * h < 4000000 else gen_frames.smooth_pair_native(w, h, seed)
     for x, y, tt in ((a, b, t), (b, a, 1.0 - t)):          # the second call runs on a used workspace: zero borders of the S16 tensors intact
-        assert np.array_equal(new.process(x, y, tt), old.process(x, y, tt)), "frames differ at %dx%d" % (w, h)
+        d = np.abs(new.process(x, y, tt).astype(np.int32) - old.process(x, y, tt).astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, "%dx%d: %d of %d bytes differ, max %d" % (w, h, int((d > 0).sum()), d.size, int(d.max()))
     if w * h <= 1920 * 1080:
-        assert np.array_equal(new.v4_extract_flow(a, b, t, 3), old.v4_extract_flow(a, b, t, 3)), "block-3 flows differ at %dx%d" % (w, h)
+        fd = np.abs(new.v4_extract_flow(a, b, t, 3) - old.v4_extract_flow(a, b, t, 3)).max()
+        assert fd < 1e-4, "block-3 flows differ by %g at %dx%d" % (fd, w, h)
     x = new.process(a, b, t)
     for _ in range(3):
         assert np.array_equal(x, new.process(a, b, t)), "the row-streaming kernel is not deterministic"
@@ -112,4 +115,5 @@ def test_rs_tta_passes_match(modeldirs):
     d = modeldirs["rife-v4.6"]
     new, old = _engine_rs(d, True, tta_mode=True, tta_temporal_mode=True), _engine_rs(d, False, tta_mode=True, tta_temporal_mode=True)
     a, b = gen_frames.smooth_pair(100, 60, 11)
-    assert np.array_equal(new.process(a, b, 0.4), old.process(a, b, 0.4))
+    d = np.abs(new.process(a, b, 0.4).astype(np.int32) - old.process(a, b, 0.4).astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3

@@ -1,7 +1,7 @@
 """GPU box: the row-streaming block-3 trunk kernel (csrc/conv_rs.h) against conv_t64_kernel (csrc/conv_t64.h).
 
     python tools/rs_bench.py [quick]
-1. byte equality with conv_t64 on random S16 tensors at aligned, ragged and tiny sizes, walking down and up, with 1 .. #CU workgroups;
+1. agreement with conv_t64 (same products, another summation order: |difference| ~1e-6) on random S16 tensors at aligned, ragged and tiny sizes, walking down and up, with 1 .. #CU workgroups;
 2. per-launch time of both kernels (interleaved rounds in one process), ablations of conv_rs (no stores / no LDS-DMA / no matrix work /
    no epilogue / no priority), the clock probe."""
 import ctypes, os, sys
@@ -10,7 +10,7 @@ from tools import benchlib
 L = benchlib.lib()
 L.rife_hip_bench_rs.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_longlong)]
 L.rife_hip_bench_t64.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float)]
-NOSTORE, NODMA, NOMATH, NOPRIO, NOEPI, CLK = 0x100, 0x200, 0x400, 0x2000, 0x4000, 0x40000
+NOSTORE, NODMA, NOMATH, NOPRIO, NTLOAD, NTSTORE, CLK = 0x100, 0x200, 0x400, 0x2000, 0x4000, 0x8000, 0x40000
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 
 def rs(h, w, variant, iters, check=False):
@@ -24,19 +24,19 @@ def rs(h, w, variant, iters, check=False):
 bad = 0
 for h, w, g in ((544, 960, 0), (272, 480, 0), (135, 241, 0), (17, 33, 0), (1, 1, 0), (2, 70, 0), (9, 32, 3), (544, 960, 7), (271, 479, 255), (68, 120, 0)):
     rc, us, st = rs(h, w, g << 24, 1, check=True)
-    ok = rc == 0 and st[0] == 0 and st[1] == 0
+    ok = rc == 0 and 0 <= st[2] < 20000 and 0 <= st[3] < 20000      # |difference of the stored values| < 2e-5 (summation order only)
     bad += not ok
-    print("%4dx%-4d workgroups %-3s bytes differing from conv_t64: down %d, up %d of %d %s%s" % (h, w, g or "CUs", st[0], st[1], st[6], "OK" if ok else "MISMATCH",
-          "" if ok else " first at plane %d padded row %d col %d byte %d" % tuple(st[2:6])), flush=True)
-print("parity: %s" % ("all equal" if not bad else "%d cases differ" % bad), flush=True)
+    print("%4dx%-4d workgroups %-3s vs conv_t64: bytes differing down %d, up %d of %d; max |value difference| down %.2e, up %.2e %s%s" % (h, w, g or "CUs", st[0], st[1], st[6],
+          st[2] * 1e-9, st[3] * 1e-9, "OK" if ok else "MISMATCH", "" if ok else " worst at chunk %d padded row %d col %d" % (st[4], st[5], st[7])), flush=True)
+print("parity: %s" % ("all within summation-order noise" if not bad else "%d cases differ" % bad), flush=True)
 sizes = ((544, 960),) if quick else ((544, 960), (272, 480))
 for h, w in sizes:
     for rep in range(2 if quick else 3):
         ms = ctypes.c_float()
         rc = L.rife_hip_bench_t64(0, h, w, 0, 40, ctypes.byref(ms))
         print("%dx%d conv_t64 full                               rc=%d %.1f us" % (h, w, rc, ms.value * 1e3), flush=True)
-        for name, v in (("full (down)", 0), ("full, layers alternate direction", 0x10000), ("full (up)", 0x20000), ("no priority", NOPRIO), ("no epilogue", NOEPI),
-                        ("no stores", NOSTORE), ("no DMA", NODMA), ("no DMA, no stores (math only)", NODMA | NOSTORE), ("math only, no epilogue", NODMA | NOSTORE | NOEPI),
+        for name, v in (("full (down)", 0), ("full, layers alternate direction", 0x10000), ("full (up)", 0x20000), ("no priority", NOPRIO), ("nt loads", NTLOAD), ("nt stores", NTSTORE), ("nt loads + stores", NTLOAD | NTSTORE),
+                        ("no stores", NOSTORE), ("no DMA", NODMA), ("no DMA, no stores (math only)", NODMA | NOSTORE),
                         ("no math", NOMATH), ("no math, no stores (loads only)", NOMATH | NOSTORE), ("no math, no DMA (stores only)", NOMATH | NODMA)):
             rc, us, _ = rs(h, w, v, 40)
             print("%dx%d conv_rs  %-36s rc=%d %.1f us" % (h, w, name, rc, us), flush=True)

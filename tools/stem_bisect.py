@@ -31,9 +31,9 @@ inside = False
 for i, l in enumerate(lines):
     if l.startswith("_ZN4rife18stem0_fused_kernel") and l.split(";")[0].rstrip().endswith(":"):
         inside = True
-    elif l.startswith(".Lfunc_end"):
+    elif l.startswith(".Lfunc_end") or l.strip().startswith(".section") or l.strip().startswith(".amdhsa_kernel"):
         inside = False
-    elif inside and l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;"):
+    elif inside and l.startswith("\t") and not l.strip().startswith(".") and not l.strip().startswith(";"):
         m = l.split()[0]
         if m not in ("s_endpgm", "s_branch") and not m.startswith("s_cbranch") and m != "s_barrier" and not m.startswith("s_waitcnt") and m != "s_nop":
             sites.append((i, m))
