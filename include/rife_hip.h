@@ -90,6 +90,16 @@ int rife_hip_v4_extract_flow(const rife_hip_t* r, const uint8_t* in0_rgb, const 
 /* shape of blob flow{fi} for frames of w x h: rife-v4.6 6 x hp/s x wp/s (PixelShuffle output, models/rife-v4.6/flownet.param:46),
  * rife-v4 5 x hp/2s x wp/2s (Deconvolution output, models/rife-v4/flownet.param:33); s = 8, 4, 2, 1. */
 int rife_hip_v4_flow_dims(const rife_hip_t* r, int w, int h, int fi, int* channels, int* fh, int* fw);
+/* Taps of the gather code on injected flows (rife-v4.6; parity tests of rife.Warp + Interp + Concat as the hot path runs them,
+ * src/warp.cpp:96-168, models/rife-v4.6/flownet.param:52-62, 107-115, 160-165, 202-217).  what = 0: the 12-channel input of IFBlock b
+ * (1..3) from the unfused assembly kernel; 1: the same tensor read back through the product's fused stem kernel (one-hot weights; values
+ * to 2^-22 relative); both 12 x hp/S x wp/S, n_inject = b.  what = 2: blob out0 before the postproc, 3 x hp x wp, n_inject = 4. */
+int rife_hip_v4_tap(const rife_hip_t* r, const uint8_t* in0_rgb, const uint8_t* in1_rgb, int w, int h, float timestep, int what, int b,
+                    const float* const* inject, int n_inject, float* out_chw);
+/* The plain pass with blobs flow0 .. flow{n_inject - 1} injected (n_inject = 0..3): the remaining blocks and the fused tail run as in
+ * rife_hip_process.  out_rgb: w x h u8 RGB. */
+int rife_hip_v4_process_injected(const rife_hip_t* r, const uint8_t* in0_rgb, const uint8_t* in1_rgb, int w, int h, float timestep,
+                                 const float* const* inject, int n_inject, uint8_t* out_rgb);
 
 /* Dry run of the generic graph executor's loader on one ncnn .param file (no GPU needed): 0 if every layer of the graph has a
  * kernel, RIFE_HIP_EMODEL with the offending layer in rife_hip_last_error() otherwise.  The v1 family (models/rife, rife-HD,

@@ -93,7 +93,7 @@ class OracleRIFE:
         in1 = np.ascontiguousarray(in1, dtype=np.uint8)
         h, w, _ = in0.shape
         wp, hp = (w + 31) // 32 * 32, (h + 31) // 32 * 32
-        cap = 8 * wp * hp
+        cap = 16 * wp * hp
         out = np.empty(cap, dtype=np.float32)
         flows = [np.ascontiguousarray(f, dtype=np.float32) for f in flows]
         arr = (ctypes.c_void_p * max(1, len(flows)))(*[f.ctypes.data for f in flows])

@@ -25,7 +25,7 @@ C_ABI_SYMBOLS = [
     "rife_hip_process_device", "rife_hip_process_batch", "rife_hip_frame_upload", "rife_hip_process_frames", "rife_hip_frame_release",
     "rife_hip_last_error", "rife_hip_profile_enable", "rife_hip_profile_read",
     "rife_hip_host_alloc", "rife_hip_host_free", "rife_hip_host_register", "rife_hip_host_unregister",
-    "rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_graph_check", "rife_hip_param_hash", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
+    "rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_v4_tap", "rife_hip_v4_process_injected", "rife_hip_graph_check", "rife_hip_param_hash", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
 ]
 
 
@@ -67,6 +67,8 @@ def lib():
     L.rife_hip_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, vp, vp, vp, ci]
     L.rife_hip_v4_extract_flow.argtypes = [vp, vp, vp, ci, ci, cf, ci, vp, ci, vp]
     L.rife_hip_v4_flow_dims.argtypes = [vp, ci, ci, ci, vp, vp, vp]
+    L.rife_hip_v4_tap.argtypes = [vp, vp, vp, ci, ci, cf, ci, ci, vp, ci, vp]
+    L.rife_hip_v4_process_injected.argtypes = [vp, vp, vp, ci, ci, cf, vp, ci, vp]
     L.rife_hip_graph_check.argtypes = [ctypes.c_char_p]
     L.rife_hip_process_batch.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci]
     L.rife_hip_frame_upload.argtypes = [vp, vp, ci, ci, vp]
@@ -242,6 +244,28 @@ class RIFE:
         inj = [np.ascontiguousarray(f, dtype=np.float32) for f in inject]
         arr = (ctypes.c_void_p * max(1, len(inj)))(*[f.ctypes.data for f in inj])
         _check(lib().rife_hip_v4_extract_flow(self._h, _p(a), _p(b), w, h, float(timestep), fi, arr, len(inj), _p(out)), "v4_extract_flow")
+        return out
+
+
+    def v4_tap(self, in0image, in1image, timestep, what, b, inject):
+        """what 0 / 1: 12-channel input of IFBlock b (unfused kernel / through the fused stem kernel); 2: blob out0 before the postproc."""
+        a = np.ascontiguousarray(in0image, dtype=np.uint8); bb = np.ascontiguousarray(in1image, dtype=np.uint8)
+        h, w, _ = a.shape
+        wp, hp = (w + 31) // 32 * 32, (h + 31) // 32 * 32
+        s = {1: 4, 2: 2, 3: 1}.get(b, 1)
+        out = np.empty((3, hp, wp) if what == 2 else (12, hp // s, wp // s), np.float32)
+        inj = [np.ascontiguousarray(f, dtype=np.float32) for f in inject]
+        arr = (ctypes.c_void_p * max(1, len(inj)))(*[f.ctypes.data for f in inj])
+        _check(lib().rife_hip_v4_tap(self._h, _p(a), _p(bb), w, h, float(timestep), int(what), int(b), arr, len(inj), _p(out)), "v4_tap")
+        return out
+
+    def v4_process_injected(self, in0image, in1image, timestep, inject):
+        a = np.ascontiguousarray(in0image, dtype=np.uint8); bb = np.ascontiguousarray(in1image, dtype=np.uint8)
+        h, w, _ = a.shape
+        out = np.empty((h, w, 3), np.uint8)
+        inj = [np.ascontiguousarray(f, dtype=np.float32) for f in inject]
+        arr = (ctypes.c_void_p * max(1, len(inj)))(*[f.ctypes.data for f in inj])
+        _check(lib().rife_hip_v4_process_injected(self._h, _p(a), _p(bb), w, h, float(timestep), arr, len(inj), _p(out)), "v4_process_injected")
         return out
 
 

@@ -520,7 +520,7 @@ int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms
         case RS_NOSTORE: rc = run(conv_rs_kernel<RS_NOSTORE>); break;
         case RS_NODMA: rc = run(conv_rs_kernel<RS_NODMA>); break;
         case RS_NOMATH: rc = run(conv_rs_kernel<RS_NOMATH>); break;
-        case RS_NOPRIO: rc = run(conv_rs_kernel<RS_NOPRIO>); break;
+        case RS_PRIO: rc = run(conv_rs_kernel<RS_PRIO>); break;
         case RS_NTLOAD: rc = run(conv_rs_kernel<RS_NTLOAD>); break;
         case RS_NTSTORE: rc = run(conv_rs_kernel<RS_NTSTORE>); break;
         case RS_NTLOAD | RS_NTSTORE: rc = run(conv_rs_kernel<RS_NTLOAD | RS_NTSTORE>); break;

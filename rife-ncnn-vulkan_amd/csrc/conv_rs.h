@@ -58,7 +58,7 @@ struct RsArgs {
     long long* stamps = nullptr; // bench builds (TAG & RS_CLK): [workgroup][4] = shader cycles of the workgroup's life, start, end (100 MHz counter)
 };
 // bench-only ablation bits of TAG (timing experiments; results are garbage).  The product instantiates TAG = 0.
-enum { RS_NOSTORE = 0x100, RS_NODMA = 0x200, RS_NOMATH = 0x400, RS_CLK = 0x40000, RS_NOPRIO = 0x2000, RS_NTLOAD = 0x4000, RS_NTSTORE = 0x8000 };
+enum { RS_NOSTORE = 0x100, RS_NODMA = 0x200, RS_NOMATH = 0x400, RS_CLK = 0x40000, RS_PRIO = 0x2000, RS_NTLOAD = 0x4000, RS_NTSTORE = 0x8000 };
 
 // (strip, pair) cursor over a workgroup's unit range, walking up or down
 struct RsCursor {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     if (wv < 4) {
         // ------------------------------------------------------------------------------------------------ consumers
-        if (!(TAG & RS_NOPRIO)) __builtin_amdgcn_s_setprio(2);          // the matrix waves win the issue arbitration against their SIMD's loader / storer
+        if (TAG & RS_PRIO) __builtin_amdgcn_s_setprio(2);             // A/B only: raised priority of the matrix waves measured 3 - 5 % SLOWER (their loader / storer starve, the barrier waits)
         if (wv == 0 && lane < 32) reinterpret_cast<f32x4*>(ldsb + RS_LDS_BS)[lane] = reinterpret_cast<const f32x4*>(a.img + 4 * t64_wch(2))[lane];
         if (wv & 1) rs_consumer<1, TAG>(a, ldsb, wv >> 1, lane, S, ufirst);
         else rs_consumer<0, TAG>(a, ldsb, wv >> 1, lane, S, ufirst);

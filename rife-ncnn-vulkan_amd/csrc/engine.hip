@@ -2390,6 +2390,143 @@ int rife_hip_v4_extract_flow(const rife_hip_t* E, const uint8_t* in0, const uint
     return 0;
 }
 
+// ---- parity taps of the gather code (round 3): the 12-channel block input and the tail of the graph, on injected flows --------------------
+// Shared prologue: frames -> padded RGBX, then for every block k < n_inject the injected blob flow{k} goes through the hot path's own
+// k_flow_update into F, M (flownet.param:47-58, 99-105, 152-158).
+static int tap_prologue(const rife_hip_t* E, Ctx& c, const uint8_t* in0, const uint8_t* in1, int w, int h, const float* const* inject, int n_inject, float*& tmp) {
+    int rc;
+    if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
+    c.own_stream = true;
+    if ((rc = ensure_ctx(c, w, h))) return rc;
+    const size_t nbytes = (size_t)w * h * 3;
+    HIPCHK(hipMemcpyAsync(c.d_in0, in0, nbytes, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(c.d_in1, in1, nbytes, hipMemcpyHostToDevice, c.stream));
+    launch_preproc(c.stream, c.d_in0, c.w, c.h, c.img0, c.wp, c.hp);
+    launch_preproc(c.stream, c.d_in1, c.w, c.h, c.img1, c.wp, c.hp);
+    if ((rc = dalloc(c, tmp, (size_t)c.wp * c.hp * 16))) return rc;
+    for (int k = 0; k < n_inject; k++) {
+        const int s = E->blk[k].scale, Hb = c.hp / s, Wb = c.wp / s;
+        HIPCHK(hipMemcpyAsync(tmp, inject[k], (size_t)Hb * Wb * 6 * 4, hipMemcpyHostToDevice, c.stream));
+        hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(Wb, Hb), dim3(256), 0, c.stream, tmp, c.flow[k], 6, Hb, Wb, 8);
+        if (k < 3 && (rc = run_flow_update(*E, c, k))) return rc;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// what = 0: block input of IFBlock b (1..3; blobs 99 / 199 / 262 of models/rife-v4.6/flownet.param:62, 115, 165) as k_assemble<S> computes it
+//           (the unfused form of the same assemble_pixel<S> / warp_rgbx code);
+// what = 1: the same tensor read back THROUGH THE PRODUCT'S FUSED STEM KERNEL stem0_fused_kernel<S, ...> (stem_fused.h), which keeps it in
+//           LDS only: the kernel is run with one-hot weights (output channel 12 p + k = input channel k under tap (1 + p / 2, 1 + p % 2), bias 0,
+//           slope 1), so that its stride-2 output holds the block input's four pixel parities; the split-f16 matrix path returns hi + lo of
+//           every value, i.e. the value to 2^-22 relative;
+// what = 2: blob out0 (flownet.param:217) before the postproc, from the unfused float tail k_final_float (b ignored; n_inject = 4).
+// out: planar CHW fp32, 12 x hp/S x wp/S (what 0, 1) or 3 x hp x wp (what 2).  n_inject must be b (what 0, 1) or 4 (what 2).
+static int rife_hip_v4_tap_impl(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, int what, int b,
+                                const float* const* inject, int n_inject, float* out) {
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (!E->v4 || E->v40) return fail(RIFE_HIP_EINVAL, "the gather taps exist for the rife-v4.6 graph only");
+    if (what < 0 || what > 2) return fail(RIFE_HIP_EINVAL, "bad tap");
+    if (what == 2 ? n_inject != 4 : (b < 1 || b > 3 || n_inject != b)) return fail(RIFE_HIP_EINVAL, "bad block / injection count");
+    if ((rc = check_device(E->gpuid))) return rc;
+    Ctx c; float* tmp = nullptr;
+    if ((rc = tap_prologue(E, c, in0, in1, w, h, inject, n_inject, tmp))) return rc;
+    hipStream_t st = c.stream;
+    if (what == 2) {
+        float4* outf = nullptr;
+        if ((rc = dalloc(c, outf, (size_t)c.wp * c.hp))) return rc;
+        hipLaunchKernelGGL(k_final_float, grid2d(c.wp, c.hp), dim3(256), 0, st, c.img0, c.img1, c.F, c.M, c.flow[3], outf, c.wp, c.hp);
+        hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(c.wp, c.hp), dim3(256), 0, st, reinterpret_cast<const float*>(outf), tmp, 3, c.hp, c.wp, 4);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, tmp, (size_t)c.wp * c.hp * 3 * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
+    const rife_hip::Block& B = E->blk[b];
+    const int s = B.scale, Hb = c.hp / s, Wb = c.wp / s;
+    if (what == 0) {
+        if ((rc = run_assemble(*E, c, b, timestep))) return rc;
+        hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(Wb, Hb), dim3(256), 0, st, c.X, tmp, 12, Hb, Wb, 16);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, tmp, (size_t)Hb * Wb * 12 * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
+    // what == 1: the fused stem kernel of the product with one-hot weights
+    const int NT = s == 1 ? 32 : 64, cout = B.c / 2, per = std::min(4, cout / 12), nlaunch = (4 + per - 1) / per;
+    const int Ho = Hb / 2, Wo = Wb / 2;
+    std::vector<float> hbias(64, 0.f), hslope(64, 1.f), host((size_t)Ho * Wo * cout);
+    float *dbias = nullptr, *dslope = nullptr; uint16_t* dw = nullptr;
+    if ((rc = dalloc(c, dbias, 64)) || (rc = dalloc(c, dslope, 64)) || (rc = dalloc(c, dw, (size_t)9 * 2 * NT * 8))) return rc;
+    HIPCHK(hipMemcpyAsync(dbias, hbias.data(), 256, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dslope, hslope.data(), 256, hipMemcpyHostToDevice, st));
+    for (int l = 0; l < nlaunch; l++) {
+        std::vector<uint16_t> hw((size_t)9 * 2 * NT * 8, 0);
+        for (int q = 0; q < per && l * per + q < 4; q++) {
+            const int p = l * per + q, t = (1 + p / 2) * 3 + 1 + p % 2;
+            for (int k = 0; k < 12; k++) hw[(((size_t)t * 2 + k / 8) * NT + 12 * q + k) * 8 + k % 8] = f2h(1.f);
+        }
+        HIPCHK(hipMemcpyAsync(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice, st));
+        StemFusedArgs fa;
+        fa.img0 = c.img0; fa.img1 = c.img1; fa.F = c.F; fa.M = c.M; fa.wpk = dw; fa.bias = dbias; fa.slope = dslope;
+        fa.out = c.S1; fa.timestep = timestep; fa.tsp = nullptr; fa.wp = c.wp; fa.hp = c.hp; fa.Ho = Ho; fa.Wo = Wo; fa.out_ld = cout; fa.Cout = cout;
+        fa.tiles_x = (Wo + 31) / 32;
+        const int nb = fa.tiles_x * ((Ho + 3) / 4);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+        if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+        else if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+        else hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(host.data(), c.S1, host.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int q = 0; q < per && l * per + q < 4; q++) {
+            const int p = l * per + q, py = p / 2, px = p % 2;
+            for (int k = 0; k < 12; k++)
+                for (int y = 0; y < Ho; y++)
+                    for (int x = 0; x < Wo; x++)
+                        out[((size_t)k * Hb + 2 * y + py) * Wb + 2 * x + px] = host[((size_t)y * Wo + x) * cout + 12 * q + k];
+        }
+    }
+    return 0;
+}
+int rife_hip_v4_tap(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, int what, int b,
+                    const float* const* inject, int n_inject, float* out) {      // nothing may throw across the C boundary
+    try { return rife_hip_v4_tap_impl(E, in0, in1, w, h, timestep, what, b, inject, n_inject, out); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EINVAL, std::string("v4_tap: ") + e.what()); }
+}
+
+// The plain v4 pass with the first n_inject (0..3) blobs flow{k} injected instead of computed: the remaining blocks and the tail run on the
+// product's own schedule (fused stems, fused tail of head_h2_kernel<EPI_FINAL>), so that flows which leave the frame by hundreds of pixels
+// reach exactly the gather code a real pass runs.  out: w x h u8 RGB.
+static int rife_hip_v4_process_injected_impl(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep,
+                                             const float* const* inject, int n_inject, uint8_t* out) {
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (!E->v4 || E->v40) return fail(RIFE_HIP_EINVAL, "flow injection into the plain pass exists for the rife-v4.6 graph only");
+    if (n_inject < 0 || n_inject > 3) return fail(RIFE_HIP_EINVAL, "bad injection count");
+    if ((rc = check_device(E->gpuid))) return rc;
+    Ctx c; float* tmp = nullptr;
+    if ((rc = tap_prologue(E, c, in0, in1, w, h, inject, n_inject, tmp))) return rc;
+    const bool fuse_tail = g_trunk_h2 && g_head_h2 && g_fuse_tail && E->blk[3].head.d_wh != nullptr;
+    FinalArgs fin{c.img0, c.img1, c.F, c.M, c.d_out, c.w, c.h, c.wp, c.hp};
+    for (int b = n_inject; b < 4; b++) {
+        if ((rc = run_block_convs(*E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr))) return rc;
+        if (b < 3 && (rc = run_flow_update(*E, c, b))) return rc;
+    }
+    if (!fuse_tail) hipLaunchKernelGGL(k_final, grid2d(c.w, c.h), dim3(256), 0, c.stream, c.img0, c.img1, c.F, c.M, c.flow[3], c.d_out, c.w, c.h, c.wp, c.hp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c.d_out, (size_t)w * h * 3, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+int rife_hip_v4_process_injected(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep,
+                                 const float* const* inject, int n_inject, uint8_t* out) {      // nothing may throw across the C boundary
+    try { return rife_hip_v4_process_injected_impl(E, in0, in1, w, h, timestep, inject, n_inject, out); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EINVAL, std::string("v4_process_injected: ") + e.what()); }
+}
+
 static int rife_hip_graph_check_impl(const char* base) {
     if (!base) return fail(RIFE_HIP_EINVAL, "null argument");
     GraphNet n;

@@ -18,15 +18,17 @@ amd = importlib.import_module("rife-ncnn-vulkan_amd")
 
 
 def _engine(modeldir, t64, **kw):
-    old = os.environ.get("RIFE_HIP_T64")
+    old = os.environ.get("RIFE_HIP_T64"), os.environ.get("RIFE_HIP_RS")
     os.environ["RIFE_HIP_T64"] = "1" if t64 else "0"      # read by rife_hip_create
+    os.environ["RIFE_HIP_RS"] = "0"                        # conv_t64 itself, not the row-streaming kernel that serves block 3 by default (tests below)
     try:
         g = amd.RIFE(0, rife_v4=True, **kw)
     finally:
-        if old is None:
-            del os.environ["RIFE_HIP_T64"]
-        else:
-            os.environ["RIFE_HIP_T64"] = old
+        for k, v in zip(("RIFE_HIP_T64", "RIFE_HIP_RS"), old):
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     g.load(modeldir)
     return g
 

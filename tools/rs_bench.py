@@ -3,14 +3,14 @@
     python tools/rs_bench.py [quick]
 1. agreement with conv_t64 (same products, another summation order: |difference| ~1e-6) on random S16 tensors at aligned, ragged and tiny sizes, walking down and up, with 1 .. #CU workgroups;
 2. per-launch time of both kernels (interleaved rounds in one process), ablations of conv_rs (no stores / no LDS-DMA / no matrix work /
-   no epilogue / no priority), the clock probe."""
+   raised priority / non-temporal loads and stores), the clock probe."""
 import ctypes, os, sys
 sys.path.insert(0, os.getcwd())
 from tools import benchlib
 L = benchlib.lib()
 L.rife_hip_bench_rs.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_longlong)]
 L.rife_hip_bench_t64.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float)]
-NOSTORE, NODMA, NOMATH, NOPRIO, NTLOAD, NTSTORE, CLK = 0x100, 0x200, 0x400, 0x2000, 0x4000, 0x8000, 0x40000
+NOSTORE, NODMA, NOMATH, PRIO, NTLOAD, NTSTORE, CLK = 0x100, 0x200, 0x400, 0x2000, 0x4000, 0x8000, 0x40000
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 
 def rs(h, w, variant, iters, check=False):
@@ -35,7 +35,7 @@ for h, w in sizes:
         ms = ctypes.c_float()
         rc = L.rife_hip_bench_t64(0, h, w, 0, 40, ctypes.byref(ms))
         print("%dx%d conv_t64 full                               rc=%d %.1f us" % (h, w, rc, ms.value * 1e3), flush=True)
-        for name, v in (("full (down)", 0), ("full, layers alternate direction", 0x10000), ("full (up)", 0x20000), ("no priority", NOPRIO), ("nt loads", NTLOAD), ("nt stores", NTSTORE), ("nt loads + stores", NTLOAD | NTSTORE),
+        for name, v in (("full (down)", 0), ("full, layers alternate direction", 0x10000), ("full (up)", 0x20000), ("matrix waves at s_setprio 2", PRIO), ("nt loads", NTLOAD), ("nt stores", NTSTORE), ("nt loads + stores", NTLOAD | NTSTORE),
                         ("no stores", NOSTORE), ("no DMA", NODMA), ("no DMA, no stores (math only)", NODMA | NOSTORE),
                         ("no math", NOMATH), ("no math, no stores (loads only)", NOMATH | NOSTORE), ("no math, no DMA (stores only)", NOMATH | NODMA)):
             rc, us, _ = rs(h, w, v, 40)

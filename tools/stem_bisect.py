@@ -77,6 +77,14 @@ r0 = test(tag="base")
 say("unmodified SLP build: mismatching floats over %d launches (S=4, S=2): %s" % (REPS, r0))
 r0b = test(tag="base")
 say("unmodified SLP build, again: %s" % (r0b,))
+# what do the differences look like?  (the probe prints the first mismatching floats of channels 0 and 63 per launch to stderr)
+del os.environ["RIFE_HIP_PROBE_QUIET"]
+L.rife_hip_probe_set_stem_hsaco(os.path.join(OUT, "base.hsaco").encode())
+mm3 = (ctypes.c_longlong * 3)(); L.rife_hip_probe_stem_det(0, 2, 1920, 1088, 3, mm3)
+say("S=2 at 1920x1088, 3 launches: %s (values on stderr)" % list(mm3))
+os.environ["RIFE_HIP_PROBE_QUIET"] = "1"
+if len(sys.argv) > 2 and sys.argv[2] == "values-only":
+    sys.exit(0)
 L.rife_hip_probe_set_stem_hsaco(None)
 mm = (ctypes.c_longlong * REPS)(); L.rife_hip_probe_stem_det(0, 4, 3840, 2176, REPS, mm)
 say("built-in kernel (library flags, no SLP): %s" % (sum(mm),))
