@@ -38,7 +38,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA pea
 HBM_PEAK_TBPS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak
 # dominant kernel per family: (profile class, kernel symbol, channels C of the C->C 3x3 trunk conv, MFMA instructions issued per
 # algorithmic product: 2 for the split-f16 scheme (hi and lo) x the identity tap of the folded skip connection)
-DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_t64_kernel<3> (IFNet block-3 trunk: 3x3 conv 64->64 + skip + LeakyReLU; split-f16 MFMA, S16 {hi, lo} tensors)", 64, 2.0 * 38 / 36),
+DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_rs_kernel (IFNet block-3 trunk: 3x3 conv 64->64 + skip + LeakyReLU; row-streaming, specialised waves; split-f16 MFMA, S16 {hi, lo} tensors)", 64, 2.0 * 38 / 36),
             "rife-v2.3": ("v2_flow_trunk_b3", "conv_h2_kernel<3,9,0> (IFNet block-3 trunk: 3x3 conv 96->96 + PReLU, split-f16)", 96, 2.0)}
 
 
@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the second region (1 pair in flight, clean per-launch kernel timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive legs (rife_hip_process from pageable host buffers)")
+    ap.add_argument("--frames", default="f1", choices=["f1", "f2"], help="synthetic frame content (SURVEY 8(d)): f1 = the reference's real frame pair tiled to size, f2 = smooth synthetic at native resolution")
     ap.add_argument("--dry-run", action="store_true", help="CPU plumbing check (gloo): launcher, sharding, barrier, MAX over ranks, JSON; no HIP work")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -144,12 +145,20 @@ def main():
     eng = amd.RIFE(local, tta_mode=tta, tta_temporal_mode=tta_temporal, rife_v2=family.startswith("rife-v2"), rife_v4=family.startswith("rife-v4"))
     eng.load(modeldir)
 
-    # a short synthetic stream of distinct pairs, resident in HBM (consecutive pairs share a frame like a video)
+    # a short synthetic stream of distinct pairs at NATIVE resolution, resident in HBM (consecutive pairs share a frame like a video):
+    # F1 of SURVEY 8(d) - the reference's real 640x360 frame pair tiled to the workload's size (6 x 6 = 3840x2160) - or, --frames f2, the smooth
+    # synthetic pair generated at full size; frames 2, 3 = frames 0, 1 shifted by a few pixels (no upsampled content: the matrix pipe clocks with
+    # the toggle rate of its operands)
     nfr = 4
-    base = gen_frames.smooth_pair(w // 4, h // 4, 1000 + rank)
+    if args.frames == "f1" and w % 640 == 0 and h % 360 == 0 and w // 640 == h // 360:
+        base = gen_frames.tiled_real_pair(w // 640)
+        frame_kind = "F1: images/0.png, 1.png of the reference tiled %d x %d" % (w // 640, w // 640)
+    else:
+        base = gen_frames.smooth_pair_native(w, h, 1000 + rank)
+        frame_kind = "F2: smooth synthetic pair generated at %dx%d" % (w, h)
     frames = []
     for i in range(nfr):
-        f = np.kron(np.roll(base[i % 2], 3 * i, axis=1), np.ones((4, 4, 1), np.uint8))       # cheap 4x upsample, shifted per frame
+        f = np.roll(base[i % 2], (2 * (i // 2), 5 * (i // 2)), axis=(0, 1))
         frames.append(torch.from_numpy(np.ascontiguousarray(f)).cuda())
     timesteps = [0.5, 0.125, 0.25, 0.7, 0.9]
     nstreams = max(1, args.streams)
@@ -182,10 +191,9 @@ def main():
         [t.join() for t in th]
 
     sh = importlib.import_module("rife-ncnn-vulkan_amd.sharding")
-    # untimed: workspace allocation, kernel attributes and clock ramp (the first timed region after only W = 5 warm-up pairs ran 4 % below
-    # the following ones), then the W warm-up steps the contract asks for
-    PREWARM = 12
-    run_steps(0, PREWARM)
+    # untimed set-up: one pair per stream (workspace allocation, kernel attributes), then exactly the W warm-up steps the contract asks for
+    SETUP = nstreams
+    run_steps(0, SETUP)
     for i in range(args.warmup):
         step(i)
     sh.barrier(dist, torch.cuda.synchronize)
@@ -244,6 +252,18 @@ def main():
         for kind, bufs in (("pageable", pageable), ("page_locked", pinned)):
             for nt in (1, 2, 3):
                 host["%s_caller_threads_%d" % (kind, nt)] = round(world * args.steps / host_run(bufs, nt), 3)
+
+        def batch_run(bufs):
+            """ONE caller thread, rife_hip_process_batch over the K pairs of the region (internal workers overlap copies and passes)"""
+            hin, _ = bufs
+            bouts = [np.empty((h, w, 3), np.uint8) for _ in range(args.steps)]
+            a0 = [hin[i % nfr] for i in range(args.steps)]; a1 = [hin[(i + 1) % nfr] for i in range(args.steps)]
+            ts = [timesteps[i % len(timesteps)] for i in range(args.steps)]
+            eng.process_batch(a0[:3], a1[:3], ts[:3], bouts[:3])
+            return sh.timed_steps(lambda _: eng.process_batch(a0, a1, ts, bouts), 1, dist=dist, device_sync=torch.cuda.synchronize,
+                                  make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+        host["process_batch_one_thread_pageable"] = round(world * args.steps / batch_run(pageable), 3)
+        host["process_batch_one_thread_page_locked"] = round(world * args.steps / batch_run(pinned), 3)
     # ... and the same K steps again with HIP events around every launch on its stream (`roofline_in_timed_region`)
     sh.barrier(dist, torch.cuda.synchronize)
     eng.profile_enable(True)
@@ -280,8 +300,8 @@ def main():
             roof = roofline_of(prof1.get(DOMINANT[family][0], dict(ms=0.0, launches=0, flops=0.0)), family, w, h, f32_mode)
             if roof is not None:
                 roof["measured_in"] = "HIP events on the launch stream over a region of the same %d steps with 1 pair in flight (non-overlapping launches); roofline_in_timed_region = the timed region repeated with the events on" % args.steps
-        traffic_file = os.path.join(ROOT, "profiles", "r2", "pmc_%s.json" % args.workload)
-        if roof is not None and os.path.exists(traffic_file):
+        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "pmc_%s.json" % args.workload) for r in ("r3", "r2")) if os.path.exists(f)), "")
+        if roof is not None and traffic_file:
             tf = json.load(open(traffic_file))                   # from the committed rocprofv3 --pmc passes (not live)
             roof["traffic"] = tf["hbm_bytes_per_launch"]
             roof["traffic_source"] = tf["source"]
@@ -295,13 +315,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if f32_mode else "f16x2-split MFMA + f32 accumulate (fp32-equivalent; activations stored f32 or as {hi, lo} f16 pairs)", "data": "synthetic",
             "config": {"workload": "%s %dx%d%s frame pairs resident in HBM, timestep sweep %s, synthetic seeded weights" % (family, w, h, " -x -z (TTA)" if tta else "", timesteps),
-                       "pairs_in_flight_per_gpu": nstreams, "untimed_prewarm_pairs": PREWARM, "parallelism": "frame pairs sharded over ranks, no data-path collective"},
+                       "pairs_in_flight_per_gpu": nstreams, "frames": frame_kind, "untimed_setup_pairs": SETUP, "parallelism": "frame pairs sharded over ranks, no data-path collective"},
             "roofline": roof,
             "roofline_in_timed_region": roof_timed if prof1 is not None else None,
             "cpu_baseline": cpu,
             "extra": {"frames_per_s_repeated_regions": dict(percentiles(region_fps), pairs_measured=reps * args.steps * world,
                                                             note="the K-step timed region repeated %d times back to back; `value` is the first" % reps),
-                      "frames_per_s_host_buffers": None if host is None else dict(host, note="rife_hip_process on host frames: 2 x H2D + pass + D2H inside the call (PCIe-inclusive; never `value`); page_locked = frames from rife_hip_host_alloc"),
+                      "frames_per_s_host_buffers": None if host is None else dict(host, note="rife_hip_process on host frames: 2 x H2D + pass + D2H inside the call (PCIe-inclusive; never `value`); page_locked = frames from rife_hip_host_alloc; process_batch_one_thread = ONE caller, rife_hip_process_batch over the region's K pairs"),
                       "frames_per_s_same_region_with_per_launch_events": round(world * args.steps / elapsed_instr, 3),
                       "frames_per_s_with_1_pair_in_flight": None if fps1 is None else round(fps1, 3), "kernel_ms_per_pair": round(all_ms / args.steps, 4), "conv_ms_per_pair": round(conv_ms / args.steps, 4),
                       "conv_tflops_overall": round(gflop_pair / max(conv_ms / args.steps, 1e-9), 2),
