@@ -394,6 +394,7 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
 int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms_out, long long* stats) {
     int rc;
     if ((rc = check_device(gpuid))) return rc;
+    if ((h + 1) / 2 < RS_MIN_PAIRS) return fail(RIFE_HIP_EINVAL, "conv_rs needs at least 7 rows");
     std::vector<float> wts((size_t)64 * 64 * 9), bias(64);
     uint32_t lcg = 12345u;
     auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((int)(lcg >> 9) - (1 << 22)) / (float)(1 << 22); };   // [-1, 1)
@@ -535,7 +536,9 @@ int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms
 
 // tools/stem_bisect.py: path of a code object whose stem0_fused_kernel<4, 2, 0> / <2, 2, 0> rife_hip_probe_stem_det launches instead of the built-in ones
 static std::string g_stem_hsaco;
+static long long g_probe_extra[2] = {0, 0};      // launch 0 of the external kernel vs the built-in one: differing floats, NaNs
 int rife_hip_probe_set_stem_hsaco(const char* path) { g_stem_hsaco = path ? path : ""; return 0; }
+int rife_hip_probe_last_extra(long long* out2) { out2[0] = g_probe_extra[0]; out2[1] = g_probe_extra[1]; return 0; }
 
 // probe: is the fused stem kernel deterministic in isolation?  Random frames, flows (some leaving the frame), mask and weights; `reps` launches
 // into separate outputs, compared on the host: mismatch[r] = floats of launch r that differ from launch 0.  variant = S + 16 x ABL.
@@ -595,6 +598,19 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
         }
         HIPCHK(hipDeviceSynchronize());
         (void)hipModuleUnload(mod);
+        {   // launch 0 of the external kernel against the built-in (library flags) kernel on the same inputs: differing floats, NaNs
+            float* refo = nullptr;
+            HIPCHK(hipMalloc(&refo, nout * 4)); HIPCHK(hipMemset(refo, 0, nout * 4));
+            fa.out = refo; fa.dbg = nullptr;
+            if (variant == 4) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<4, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>())); hipLaunchKernelGGL((stem0_fused_kernel<4, 2, 0>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), 0, fa); }
+            else { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>())); hipLaunchKernelGGL((stem0_fused_kernel<2, 2, 0>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), 0, fa); }
+            HIPCHK(hipDeviceSynchronize());
+            std::vector<float> a0(nout), a1(nout);
+            HIPCHK(hipMemcpy(a0.data(), outs[0], nout * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(a1.data(), refo, nout * 4, hipMemcpyDeviceToHost));
+            g_probe_extra[0] = g_probe_extra[1] = 0;
+            for (size_t k = 0; k < nout; k++) { g_probe_extra[0] += std::memcmp(&a0[k], &a1[k], 4) != 0; g_probe_extra[1] += a0[k] != a0[k]; }
+            (void)hipFree(refo);
+        }
     } else
     switch (variant) {
         case 4: rc = run(stem0_fused_kernel<4, 2, 0>, stemf_lds_bytes<2>()); break;

@@ -41,8 +41,11 @@ constexpr int RS_ROWB = 8 * RS_SEG;                        // 8,704 B per halo r
 constexpr int RS_STG_ROW = 8 * 1024;                       // staged output row: [chunk 4][hi | lo][32 px][32 B]
 constexpr int RS_LDS_RING = 0;
 constexpr int RS_LDS_STG = RS_NR * RS_ROWB;                // 104,448
-constexpr int RS_LDS_BS = RS_LDS_STG + 2 * 2 * RS_STG_ROW; // 137,216: bias[64] | slope[64]
-constexpr int RS_LDS = RS_LDS_BS + 512;                    // 137,728 B: one workgroup per CU
+constexpr int RS_NSTG = 3;                                 // staging buffers (a row pair each): written in iteration it, read in it + 2
+constexpr int RS_LDS_BS = RS_LDS_STG + RS_NSTG * 2 * RS_STG_ROW; // 153,600: bias[64] | slope[64]
+constexpr int RS_LDS = RS_LDS_BS + 512;                    // 154,112 B: one workgroup per CU
+constexpr int RS_AHEAD = 3;                                // the loaders run three steps ahead of the consumers
+constexpr int RS_MIN_PAIRS = 4;                            // ring capacity: at most one strip change among RS_AHEAD + 1 consecutive steps (4 + 4 + 2 + 2 rows)
 constexpr int RS_NTHR = 512;
 
 struct RsArgs {
@@ -86,6 +89,7 @@ __device__ __forceinline__ void rs_dma16(const unsigned char* base, unsigned vof
 
 #define RS_SYNC_LGKM() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define RS_SYNC_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")
+#define RS_SYNC_BARE() asm volatile("s_barrier" ::: "memory")
 
 // The matrix work of one (row, output block N) is a fixed sequence of 38 MFMA pairs (A fragment, pixel fragment {hi, lo}): per K chunk c the
 // nine taps in order, then - if chunk c carries the input channels of output block N - the identity tap of the skip connection
@@ -131,12 +135,11 @@ __device__ __forceinline__ void rs_consumer(const RsArgs& a, unsigned char* cons
     const int qs = (li >> 1) & 3;
 
     RsCursor cur; cur.init(ufirst, a.npairs);
-    int sq = 0;                                                          // rows loaded through the current step, mod RS_NR
-    RS_SYNC_LGKM();                                                      // ring rows of step 0 landed (loaders), bias in LDS
-    for (int it = 0; it < S; it++) {
-        const bool fresh = it == 0 || cur.advance(a.npairs, a.descend);
+    int sq = 0;                                                          // rows loaded through the step `cur` points at, mod RS_NR
+    unsigned ad[9];                                                      // fragment addresses of the nine taps, chunk 0, hi plane
+    // addresses of the step at `cur` (fresh: it starts a strip, all four halo rows are new)
+    auto step_addresses = [&](const bool fresh) {
         sq += fresh ? 4 : 2; if (sq >= RS_NR) sq -= RS_NR;
-        unsigned ad[9];
 #pragma unroll
         for (int dy = 0; dy < 3; dy++) {
             const int j = ro + dy;                                       // row of the step's four halo rows, from the top
@@ -146,33 +149,42 @@ __device__ __forceinline__ void rs_consumer(const RsArgs& a, unsigned char* cons
 #pragma unroll
             for (int dx = 0; dx < 3; dx++) ad[dy * 3 + dx] = rb + colo[dx];
         }
-        // Two accumulation chains, the hi products and the lo products: an MFMA never waits for the result of the one issued just before
-        // it (one wave per SIMD: nobody else would fill the gap).  The pixel fragments are read RS_PF pairs ahead of their MFMAs;
-        // sched_barrier keeps the compiler from sinking the reads back to their uses.
-        f32x16 accH, accL;
-        f16x8 fh[RS_PF + 1], fl[RS_PF + 1];
-        auto frag_read = [&](auto mc) {
+    };
+    constexpr int NF = RS_PF + 1;                                        // fragment register sets; pair m of a step of parity PAR uses set (m + 2 PAR) % NF (38 % 4 = 2)
+    static_assert(NF == 4 && RS_NPAIR % NF == 2, "fragment set rotation across steps");
+    f16x8 fh[NF], fl[NF];
+    int it = 0;
+    // One step.  Two accumulation chains, the hi products and the lo products: an MFMA never waits for the result of the one issued just
+    // before it (one wave per SIMD: nobody else would fill the gap).  The pixel fragments are read RS_PF pairs ahead of their MFMAs -
+    // across the step boundary too: the last RS_PF pairs of a step read the first fragments of the NEXT step, whose rows the loaders
+    // guarantee one barrier early - and sched_barrier keeps the compiler from sinking the reads back to their uses.
+    auto step = [&](auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
+        auto frag_read = [&](auto mc) {                                  // pair m of the step whose addresses are in ad[]
             constexpr int m = decltype(mc)::value;
-            constexpr RsPairDesc d = rs_pair(N, m);
-            fh[m % (RS_PF + 1)] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG));
-            fl[m % (RS_PF + 1)] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG) + RS_SEG);
+            constexpr RsPairDesc d = rs_pair(N, m % RS_NPAIR);
+            constexpr int st = (m + 2 * PAR) % NF;
+            fh[st] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG));
+            fl[st] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG) + RS_SEG);
         };
+        f32x16 accH, accL;
         if (!(TAG & RS_NOMATH)) {
-            for_each_slot<0, RS_PF>(frag_read);
             for_each_slot<0, RS_NPAIR>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 constexpr RsPairDesc d = rs_pair(N, m);
-                if constexpr (m + RS_PF < RS_NPAIR) frag_read(std::integral_constant<int, m + RS_PF>{});
+                constexpr int st = (m + 2 * PAR) % NF;
+                if constexpr (m == RS_NPAIR - RS_PF) step_addresses(cur.advance(a.npairs, a.descend));     // ad[] is dead: every read of this step is issued
+                frag_read(std::integral_constant<int, m + RS_PF>{});     // m + RS_PF >= 38: pair m + RS_PF - 38 of the next step (sets continue to rotate)
                 const f16x8 A = d.idn ? idf[d.c & 1] : W[d.c][d.t];
                 if constexpr (m == 0) {
                     f32x16 z;
 #pragma unroll
                     for (int q = 0; q < 16; q++) z[q] = 0.f;
-                    accH = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[0], z, 0, 0, 0);
-                    accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[0], z, 0, 0, 0);
+                    accH = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[st], z, 0, 0, 0);
+                    accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[st], z, 0, 0, 0);
                 } else {
-                    accH = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[m % (RS_PF + 1)], accH, 0, 0, 0);
-                    accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[m % (RS_PF + 1)], accL, 0, 0, 0);
+                    accH = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[st], accH, 0, 0, 0);
+                    accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[st], accL, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -180,8 +192,10 @@ __device__ __forceinline__ void rs_consumer(const RsArgs& a, unsigned char* cons
 #pragma unroll
             for (int q = 0; q < 16; q++) { accH[q] = (float)lane; accL[q] = 0.f; }
         }
-        // raw sums -> staging[it & 1]; bias, LeakyReLU and the {hi, lo} split are the storers' work
-        f32x4* const d4 = reinterpret_cast<f32x4*>(stg + (it & 1) * (2 * RS_STG_ROW));
+        // raw sums -> staging[it % 3]; bias, LeakyReLU and the {hi, lo} split are the storers' work two iterations later, by when these
+        // writes have long completed (no wait here: the LDS executes a wave's operations in order, and the next step's reads follow them)
+        int sb = it % RS_NSTG;
+        f32x4* const d4 = reinterpret_cast<f32x4*>(stg + sb * (2 * RS_STG_ROW));
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             f32x4 v;
@@ -189,8 +203,20 @@ __device__ __forceinline__ void rs_consumer(const RsArgs& a, unsigned char* cons
             for (int k = 0; k < 4; k++) v[k] = accH[4 * q + k] + accL[4 * q + k];
             d4[q ^ qs] = v;
         }
-        RS_SYNC_LGKM();
-    }
+        RS_SYNC_BARE();
+        it++;
+    };
+    RS_SYNC_LGKM();                                                      // ring rows of steps 0 and 1 landed (loaders), bias in LDS
+    step_addresses(true);
+    if (!(TAG & RS_NOMATH)) for_each_slot<0, RS_PF>([&](auto mc) {       // first fragments of step 0 (parity 0)
+        constexpr int m = decltype(mc)::value;
+        constexpr RsPairDesc d = rs_pair(N, m);
+        fh[m % NF] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG));
+        fl[m % NF] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG) + RS_SEG);
+    });
+    while (it + 1 < S) { step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); }
+    if (it < S) step(std::integral_constant<int, 0>{});
+    RS_SYNC_LGKM();                                                      // the last step's staging writes have landed
 }
 
 template <int TAG>
@@ -250,21 +276,24 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
             return mine;
         };
         if (TAG & RS_NODMA) { for (int i = lane + 64 * j; i < RS_LDS_STG / 16; i += 128) reinterpret_cast<f32x4*>(ldsb)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        // prologue: rows of steps 0 and 1
+        // prologue: rows of steps 0 .. RS_AHEAD - 1; steps 0 and 1 must have landed before the first barrier
         load_step(true);
         int ahead = 0;                                                   // my pieces of the newest step issued
-        if (S > 1) { const bool f = cur.advance(a.npairs, a.descend); ahead = load_step(f); }
+        int loaded = 1;                                                  // steps issued
+        for (; loaded < RS_AHEAD && loaded < S; loaded++) { const bool f = cur.advance(a.npairs, a.descend); ahead = load_step(f); }
+        if (loaded < RS_AHEAD) ahead = 0;                                // fewer than RS_AHEAD steps in the range: wait for everything
 #define RS_WAIT_AHEAD()                                                                                      \
         if (TAG & RS_NODMA) RS_SYNC_LGKM();                                                                  \
         else if (ahead == 0) RS_SYNC_VM(0);                                                                  \
         else if (ahead == 9) RS_SYNC_VM(9);                                                                  \
         else RS_SYNC_VM(18);
-        RS_WAIT_AHEAD()                                                  // rows of step 0 landed
+        RS_WAIT_AHEAD()                                                  // rows of steps 0 and 1 landed
         for (int it = 0; it < S; it++) {
-            if (it + 2 < S) { const bool f = cur.advance(a.npairs, a.descend); ahead = load_step(f); }
+            if (it + RS_AHEAD < S) { const bool f = cur.advance(a.npairs, a.descend); ahead = load_step(f); }
             else ahead = 0;
-            RS_WAIT_AHEAD()                                              // rows of step it + 1 landed
+            RS_WAIT_AHEAD()                                              // rows of step it + 2 landed: the consumers prefetch step it + 1's first fragments before the NEXT barrier
         }
+        RS_SYNC_BARE();                                                  // the consumers' final barrier
 #undef RS_WAIT_AHEAD
     } else {
         // ------------------------------------------------------------------------------------------------ storers
@@ -276,12 +305,12 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const float slope = reinterpret_cast<const float*>(a.img + 4 * t64_wch(2))[64];      // one LeakyReLU slope for the whole layer (pack_t64_image)
         RsCursor cur; cur.init(ufirst, a.npairs);
         RS_SYNC_LGKM();
-        for (int it = 0; it <= S; it++) {
-            if (it >= 1) {                                               // step it - 1, staged during iteration it - 1
+        for (int it = 0; it <= S + 1; it++) {
+            if (it >= 2) {                                               // step it - 2, staged at the end of iteration it - 2
                 const int y = 2 * cur.p + j, x0 = 32 * cur.strip;
                 if (y < a.H && !(TAG & RS_NOSTORE)) {
                     const unsigned okmask = x0 + px < a.W ? 0xffffffffu : 0u;
-                    const unsigned char* src = ldsb + RS_LDS_STG + ((it - 1) & 1) * (2 * RS_STG_ROW) + j * RS_STG_ROW + px * 64;
+                    const unsigned char* src = ldsb + RS_LDS_STG + ((it - 2) % RS_NSTG) * (2 * RS_STG_ROW) + j * RS_STG_ROW + px * 64;
                     unsigned char* dst = a.out + ((unsigned)((y + 1) * a.pitch + x0 + 1) * 32u + (unsigned)(lane * 16));
 #pragma unroll
                     for (int cc = 0; cc < 4; cc++) {
@@ -310,7 +339,8 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
                 cur.advance(a.npairs, a.descend);
             }
-            if (it < S) RS_SYNC_LGKM();
+            if (it < S) RS_SYNC_LGKM();                                  // barrier of iteration it
+            else if (it == S) RS_SYNC_LGKM();                            // the consumers' final barrier: the last step's staging writes have landed
         }
     }
     if ((TAG & RS_CLK) && tid == 0) {

@@ -674,6 +674,7 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
 // workgroup's range bottom-up; consecutive layers alternate so that a layer starts on the rows its predecessor wrote last.
 static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool descend = false) {
     if (!L.d_t64 || L.cout != 64) return fail(RIFE_HIP_EINVAL, "layer has no 64-channel conv_t64 image");
+    if ((H + 1) / 2 < RS_MIN_PAIRS) return fail(RIFE_HIP_EINVAL, "conv_rs needs at least 7 rows");
     int dev = 0; (void)hipGetDevice(&dev);
     static std::mutex mu; static std::map<int, int> ncu;
     int cus;
@@ -1096,7 +1097,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         for (int i = 0; i < 8; i++) {
             Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
             if (rowk) rc = launch_row(B.res[i], pc, pn, Ht, Wt, st);
-            else if (E.rs && B.c == 64) rc = launch_rs(B.res[i], pc, pn, Ht, Wt, st, (i & 1) != 0);
+            else if (E.rs && B.c == 64 && (Ht + 1) / 2 >= RS_MIN_PAIRS) rc = launch_rs(B.res[i], pc, pn, Ht, Wt, st, (i & 1) != 0);      // tiny tensors: conv_t64
             else rc = launch_t64(B.res[i], pc, pn, Ht, Wt, st, (i & 1) == 0);
             if (rc) return rc;
             std::swap(pc, pn);
