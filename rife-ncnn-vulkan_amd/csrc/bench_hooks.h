@@ -584,11 +584,12 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
         HIPCHK(hipDeviceSynchronize());
         return 0;
     };
-    if (!g_stem_hsaco.empty() && (variant == 4 || variant == 2)) {
+    if (!g_stem_hsaco.empty() && (S == 4 || S == 2) && (ABL == 0 || ABL == 4096)) {
         // the kernel from an externally assembled code object (tools/stem_bisect.py: the compiler's assembly with wait states inserted)
         hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
         HIPCHK(hipModuleLoad(&mod, g_stem_hsaco.c_str()));
-        HIPCHK(hipModuleGetFunction(&fn, mod, variant == 4 ? "_ZN4rife18stem0_fused_kernelILi4ELi2ELi0EEEvNS_13StemFusedArgsE" : "_ZN4rife18stem0_fused_kernelILi2ELi2ELi0EEEvNS_13StemFusedArgsE"));
+        const std::string fname = std::string("_ZN4rife18stem0_fused_kernelILi") + (S == 4 ? "4" : "2") + "ELi2ELi" + (ABL ? "4096" : "0") + "EEEvNS_13StemFusedArgsE";
+        HIPCHK(hipModuleGetFunction(&fn, mod, fname.c_str()));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
         for (int r = 0; r < reps; r++) {
             fa.out = outs[r]; fa.dbg = dbgs[r];
@@ -602,7 +603,7 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
             float* refo = nullptr;
             HIPCHK(hipMalloc(&refo, nout * 4)); HIPCHK(hipMemset(refo, 0, nout * 4));
             fa.out = refo; fa.dbg = nullptr;
-            if (variant == 4) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<4, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>())); hipLaunchKernelGGL((stem0_fused_kernel<4, 2, 0>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), 0, fa); }
+            if (S == 4) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<4, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>())); hipLaunchKernelGGL((stem0_fused_kernel<4, 2, 0>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), 0, fa); }
             else { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>())); hipLaunchKernelGGL((stem0_fused_kernel<2, 2, 0>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), 0, fa); }
             HIPCHK(hipDeviceSynchronize());
             std::vector<float> a0(nout), a1(nout);
@@ -621,6 +622,8 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
         case 4 + 16 * 64: rc = run(stem0_fused_kernel<4, 2, 64>, stemf_lds_bytes<2>()); break;
         case 4 + 16 * 66: rc = run(stem0_fused_kernel<4, 2, 66>, stemf_lds_bytes<2>()); break;
         case 4 + 16 * 1024: rc = run(stem0_fused_kernel<4, 2, 1024>, stemf_lds_bytes<2>()); break;
+        case 4 + 16 * 4096: rc = run(stem0_fused_kernel<4, 2, 4096>, stemf_lds_bytes<2>()); break;
+        case 2 + 16 * 4096: rc = run(stem0_fused_kernel<2, 2, 4096>, stemf_lds_bytes<2>()); break;
         default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
     }
     if (!rc) {

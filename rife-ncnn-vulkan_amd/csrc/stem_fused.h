@@ -29,9 +29,9 @@ struct StemFusedArgs {
 // the stride-2 operand reads; 64-byte records are 4-way / 8-way).  ABL bit 128 selects the unpadded record for A/B runs.
 template <int ABL> constexpr int stemf_pixb() { return (ABL & (128 | 256)) ? 64 : 80; }
 template <int NS, int ABL = 0>
-constexpr int stemf_lds_bytes() { return 9 * 65 * stemf_pixb<ABL>() + 9 * 2 * NS * 32 * 16; }
+constexpr int stemf_lds_bytes() { return (9 * 65 + 1) * stemf_pixb<ABL>() + 9 * 2 * NS * 32 * 16; }      // + one dummy pixel record
 
-// ABL (bench only): 1 = skip MFMA + epilogue, 2 = second halo pixel in a second round, 16 = skip stores, 32 = skip MFMAs, 64 = direct-store epilogue, 128 = 64-byte LDS records
+// ABL (bench only): 4096 = round-2 staging of the second halo pixel under a lane-divergent branch; 1 = skip MFMA + epilogue, 2 = second halo pixel in a second round, 16 = skip stores, 32 = skip MFMAs, 64 = direct-store epilogue, 128 = 64-byte LDS records
 // ABL 256: 64-byte records with the 16-byte quarters XOR-swizzled by pixel index (quarter q of pixel P at position q ^ ((P >> 2) & 3): 2-way on the
 // stride-2 operand reads like the padded records, conflict-free staging writes) -> 46.6 KB for NS = 1: three workgroups (24 waves) per CU
 template <int S, int NS, int ABL = 0>
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((ABL & 256)
     constexpr int NPIX = IH * IW;
     constexpr int W_16 = 9 * 2 * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    unsigned char* const lw = ldsb + NPIX * PIXB;
+    unsigned char* const lw = ldsb + (NPIX + 1) * PIXB;                  // record NPIX: dummy target of the lanes without a second pixel
 
     const float timestep = a.tsp ? *a.tsp : a.timestep;
     const int tid = threadIdx.x;
@@ -88,13 +88,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((ABL & 256)
         *reinterpret_cast<f16x8*>(dst + ((0 ^ sw_) << 4)) = h0; *reinterpret_cast<f16x8*>(dst + ((1 ^ sw_) << 4)) = h1; \
         *reinterpret_cast<f16x8*>(dst + ((2 ^ sw_) << 4)) = l0; *reinterpret_cast<f16x8*>(dst + ((3 ^ sw_) << 4)) = l1; \
     }
-    if (wv8 < 2 && !(ABL & 2)) {
+    // Round 3: no lane-divergent control flow around the staging.  The 73 second pixels (waves 0-1) used to be staged under
+    // `if (tid + 512 < NPIX)`; built with the SLP vectorizer the compiler tail-merged that store block with the other paths' and the kernel
+    // was not run-to-run stable (whole groups of 16 halo pixels came out with stale LDS contents: tools/stem_bisect.py, stem_poison.py,
+    // DESIGN.md (d)-8).  Now the wave role is a scalar (readfirstlane) and the lanes without a second pixel write a dummy record instead
+    // of branching.
+    const bool two_px = __builtin_amdgcn_readfirstlane(wv8) < 2;
+    if ((ABL & 4096) && wv8 < 2) {                                       // bench builds: the round-2 form (tools/stem_det_both.py reproduces the instability with it)
+        float o0[12], o1[12];
+        STEM_GATHER(tid, o0)
+        STEM_GATHER(tid + 512, o1)
+        STEM_STAGE(tid, o0)
+        if (tid + 512 < NPIX) STEM_STAGE(tid + 512, o1)
+    } else if (two_px && !(ABL & 2)) {
         float o0[12], o1[12];
         STEM_GATHER(tid, o0)
         STEM_GATHER(tid + 512, o1)
         if (ABL & 1024) { _Pragma("unroll") for (int c = 0; c < 12; c++) a.dbg[((size_t)blockIdx.x * 512 + tid) * 12 + c] = o0[c]; }
         STEM_STAGE(tid, o0)
-        if (tid + 512 < NPIX) STEM_STAGE(tid + 512, o1)
+        const int p1 = tid + 512 < NPIX ? tid + 512 : NPIX;              // record NPIX is the dummy
+        STEM_STAGE(p1, o1)
     } else {
         float o0[12];
         STEM_GATHER(tid, o0)
