@@ -46,16 +46,16 @@ os.environ["RIFE_HIP_PROBE_QUIET"] = "1"
 REPS = 10
 ntest = 0
 
-def test(after=(), before=(), tag="v"):
+def test(after=(), before=(), tag="v", ins="s_nop 7"):
     """assemble the variant with s_nop 7 after / before the given line indices; returns mismatching floats summed over REPS launches of both kernels at 4K"""
     global ntest
     ntest += 1
     A, B = set(after), set(before)
     out = []
     for i, l in enumerate(lines):
-        if i in B: out.append("\ts_nop 7")
+        if i in B: out.append("\t" + ins)
         out.append(l)
-        if i in A: out.append("\ts_nop 7")
+        if i in A: out.append("\t" + ins)
     s = os.path.join(OUT, tag + ".s"); o = os.path.join(OUT, tag + ".o"); h = os.path.join(OUT, tag + ".hsaco")
     open(s, "w").write("\n".join(out))
     subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s, "-o", o])
@@ -85,6 +85,7 @@ say("S=2 at 1920x1088, 3 launches: %s (values on stderr)" % list(mm3))
 os.environ["RIFE_HIP_PROBE_QUIET"] = "1"
 if len(sys.argv) > 2 and sys.argv[2] == "values-only":
     sys.exit(0)
+os.environ["RIFE_HIP_PROBE_QUIET"] = "1"
 L.rife_hip_probe_set_stem_hsaco(None)
 mm = (ctypes.c_longlong * REPS)(); L.rife_hip_probe_stem_det(0, 4, 3840, 2176, REPS, mm)
 say("built-in kernel (library flags, no SLP): %s" % (sum(mm),))
@@ -92,6 +93,46 @@ if r0[0] == 0 and r0b[0] == 0:
     say("the instability did not reproduce on this box with this toolchain: nothing to bisect")
     sys.exit(0)
 
+# ---- stage W: full waits for memory instead of wait states (is a counted s_waitcnt of the compiler too weak somewhere?)
+vm = [i for i, m in sites if m.startswith("global_load")]
+ds = [i for i, m in sites if m.startswith("ds_")]
+sm = [i for i, m in sites if m.startswith("s_load")]
+rw = test(after=vm, tag="w_vm", ins="s_waitcnt vmcnt(0)")
+say("s_waitcnt vmcnt(0) after every global_load (%d sites): %s" % (len(vm), rw))
+rl = test(after=ds + sm, tag="w_lgkm", ins="s_waitcnt lgkmcnt(0)")
+say("s_waitcnt lgkmcnt(0) after every ds_* / s_load (%d sites): %s" % (len(ds) + len(sm), rl))
+if rw != -1 and rw[0] == 0 and test(after=vm, tag="w_vm", ins="s_waitcnt vmcnt(0)")[0] == 0:
+    say("a full vmcnt wait behind every load cures it -> which load's consumer is under-waited?  delta debugging over the %d loads" % len(vm))
+    cur = list(vm)
+    def okw(sub):
+        r = test(after=sub, tag="ddw", ins="s_waitcnt vmcnt(0)")
+        if r != -1 and r[0] == 0: r = test(after=sub, tag="ddw", ins="s_waitcnt vmcnt(0)")
+        return r != -1 and r[0] == 0
+    n = 2
+    while len(cur) >= 2 and left() > 40:
+        chunk = max(1, len(cur) // n)
+        subsets = [cur[k:k + chunk] for k in range(0, len(cur), chunk)]
+        reduced = False
+        for sub in subsets:
+            if left() < 40: break
+            if okw(sub): cur = sub; n = 2; reduced = True; break
+        if not reduced:
+            for sub in subsets:
+                if left() < 40: break
+                comp = [x for x in cur if x not in set(sub)]
+                if comp and okw(comp): cur = comp; n = max(n - 1, 2); reduced = True; break
+        if not reduced:
+            if n >= len(cur): break
+            n = min(len(cur), 2 * n)
+        say("  %d loads left (%d tests, %.0f s)" % (len(cur), ntest, time.time() - T0))
+    say("1-minimal (or budget-limited) set of loads whose full wait cures the instability: %d" % len(cur))
+    for i in cur[:12]:
+        say("---- line %d" % i)
+        for k in range(max(0, i - 3), min(len(lines), i + 40)):
+            say(("  >> " if k == i else "     ") + lines[k])
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "waits-only":
+    sys.exit(0)
 idx = [i for i, _ in sites]
 cls = {
     "every instruction": idx,
