@@ -534,11 +534,21 @@ int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms
     return rc;
 }
 
+// fills the workgroup's whole LDS allocation with a pattern and leaves: launched between the probe's launches, it decides what the next
+// kernel finds in LDS locations it does not write itself
+__global__ void k_lds_scrub(uint32_t pattern, int ndw, uint32_t* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    uint32_t* l = reinterpret_cast<uint32_t*>(ldsb);
+    for (int i = threadIdx.x; i < ndw; i += blockDim.x) l[i] = pattern;
+    __syncthreads();
+    if (pattern == 0x12345678u && l[(threadIdx.x * 7) % ndw] != pattern) sink[0] = 1;      // keeps the stores alive
+}
+
 // tools/stem_bisect.py: path of a code object whose stem0_fused_kernel<4, 2, 0> / <2, 2, 0> rife_hip_probe_stem_det launches instead of the built-in ones
 static std::string g_stem_hsaco;
-static long long g_probe_extra[2] = {0, 0};      // launch 0 of the external kernel vs the built-in one: differing floats, NaNs
+static long long g_probe_extra[3] = {0, 0, 0};      // launch 0 of the external kernel vs the built-in one: differing floats, NaNs
 int rife_hip_probe_set_stem_hsaco(const char* path) { g_stem_hsaco = path ? path : ""; return 0; }
-int rife_hip_probe_last_extra(long long* out2) { out2[0] = g_probe_extra[0]; out2[1] = g_probe_extra[1]; return 0; }
+int rife_hip_probe_last_extra(long long* out3) { out3[0] = g_probe_extra[0]; out3[1] = g_probe_extra[1]; out3[2] = g_probe_extra[2]; return 0; }      // [2]: input buffers modified by the launches
 
 // probe: is the fused stem kernel deterministic in isolation?  Random frames, flows (some leaving the frame), mask and weights; `reps` launches
 // into separate outputs, compared on the host: mismatch[r] = floats of launch r that differ from launch 0.  variant = S + 16 x ABL.
@@ -591,7 +601,14 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
         const std::string fname = std::string("_ZN4rife18stem0_fused_kernelILi") + (S == 4 ? "4" : "2") + "ELi2ELi" + (ABL ? "4096" : "0") + "EEEvNS_13StemFusedArgsE";
         HIPCHK(hipModuleGetFunction(&fn, mod, fname.c_str()));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+        const char* scrub = getenv("RIFE_HIP_PROBE_SCRUB");
+        uint32_t* sink = nullptr;
+        if (scrub) { HIPCHK(hipMalloc(&sink, 4)); HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds_scrub), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
         for (int r = 0; r < reps; r++) {
+            if (scrub) {      // every CU's LDS (one 160 KB workgroup per CU at a time, many rounds) <- pattern, alternating if "alt"
+                const uint32_t pat = std::strcmp(scrub, "alt") == 0 ? ((r & 1) ? 0x7fc00000u : 0u) : (uint32_t)std::strtoul(scrub, nullptr, 16);
+                hipLaunchKernelGGL(k_lds_scrub, dim3(2048), dim3(512), 160 * 1024, 0, pat, 160 * 1024 / 4, sink);
+            }
             fa.out = outs[r]; fa.dbg = dbgs[r];
             size_t sz = sizeof(fa);
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &fa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
@@ -599,6 +616,15 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
         }
         HIPCHK(hipDeviceSynchronize());
         (void)hipModuleUnload(mod);
+        if (sink) (void)hipFree(sink);
+        {   // did the launches modify their INPUTS (an out-of-bounds store would explain launches that differ from launch 0)?
+            std::vector<uint32_t> c0(P), c1(P); std::vector<float> cF(P * 4), cM(P);
+            HIPCHK(hipMemcpy(c0.data(), i0, P * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(c1.data(), i1, P * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(cF.data(), F, P * 16, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(cM.data(), M, P * 4, hipMemcpyDeviceToHost));
+            std::vector<_Float16> cw(hw.size()); HIPCHK(hipMemcpy(cw.data(), wh, hw.size() * 2, hipMemcpyDeviceToHost));
+            g_probe_extra[2] = (long long)(std::memcmp(c0.data(), hi0.data(), P * 4) != 0) + (std::memcmp(c1.data(), hi1.data(), P * 4) != 0) + (std::memcmp(cF.data(), hF.data(), P * 16) != 0)
+                               + (std::memcmp(cM.data(), hM.data(), P * 4) != 0) + (std::memcmp(cw.data(), hw.data(), hw.size() * 2) != 0);
+        }
         {   // launch 0 of the external kernel against the built-in (library flags) kernel on the same inputs: differing floats, NaNs
             float* refo = nullptr;
             HIPCHK(hipMalloc(&refo, nout * 4)); HIPCHK(hipMemset(refo, 0, nout * 4));
