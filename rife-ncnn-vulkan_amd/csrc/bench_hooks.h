@@ -600,7 +600,8 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
         HIPCHK(hipModuleLoad(&mod, g_stem_hsaco.c_str()));
         const std::string fname = std::string("_ZN4rife18stem0_fused_kernelILi") + (S == 4 ? "4" : "2") + "ELi2ELi" + (ABL ? "4096" : "0") + "EEEvNS_13StemFusedArgsE";
         HIPCHK(hipModuleGetFunction(&fn, mod, fname.c_str()));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+        const int ldsb_ext = getenv("RIFE_HIP_PROBE_LDS") ? std::atoi(getenv("RIFE_HIP_PROBE_LDS")) : stemf_lds_bytes<2>();      // > 80 KB: one workgroup per CU
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb_ext));
         const char* scrub = getenv("RIFE_HIP_PROBE_SCRUB");
         uint32_t* sink = nullptr;
         if (scrub) { HIPCHK(hipMalloc(&sink, 4)); HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds_scrub), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
@@ -612,7 +613,7 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
             fa.out = outs[r]; fa.dbg = dbgs[r];
             size_t sz = sizeof(fa);
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &fa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-            HIPCHK(hipModuleLaunchKernel(fn, nb, 1, 1, 512, 1, 1, stemf_lds_bytes<2>(), 0, nullptr, cfg));
+            HIPCHK(hipModuleLaunchKernel(fn, nb, 1, 1, 512, 1, 1, ldsb_ext, 0, nullptr, cfg));
         }
         HIPCHK(hipDeviceSynchronize());
         (void)hipModuleUnload(mod);

@@ -55,6 +55,21 @@ def unpack(line):
     out.append("\tv_mov_b32 v%d, v129" % dhi)
     return out
 
+def unpack_in_place(line):
+    """the same without scratch registers (the kernel keeps its 128 VGPRs): the half whose destination is not read by the other half goes
+    second; None if both orders would clobber a source (the instruction stays packed)"""
+    u = unpack(line)
+    if u is None:
+        return None
+    lo, hi, mlo, mhi = u
+    dlo = mlo.split()[1].rstrip(","); dhi = mhi.split()[1].rstrip(",")
+    def reads(ins, reg):
+        return re.search(r"[\s,-]%s\b" % reg, ins.split(None, 2)[2]) is not None
+    a = lo.replace("v128", dlo); b = hi.replace("v129", dhi)
+    if not reads(b, dlo): return [a, b]
+    if not reads(a, dhi): return [b, a]
+    return False
+
 def transform(lines):
     out = []; n = 0
     for l in lines:
