@@ -64,7 +64,7 @@ def unpack_in_place(line):
     lo, hi, mlo, mhi = u
     dlo = mlo.split()[1].rstrip(","); dhi = mhi.split()[1].rstrip(",")
     def reads(ins, reg):
-        return re.search(r"[\s,-]%s\b" % reg, ins.split(None, 2)[2]) is not None
+        return re.search(r"[\s,-]%s\b" % reg, " " + ins.split(None, 2)[2]) is not None
     a = lo.replace("v128", dlo); b = hi.replace("v129", dhi)
     if not reads(b, dlo): return [a, b]
     if not reads(a, dhi): return [b, a]
