@@ -36,6 +36,11 @@ struct RowArgs {
     int pitch;                   // pixels per plane row
     unsigned plane;              // bytes per plane
     int tiles_x, ntiles;
+    // batched launch (rife_hip_process_batch): gridDim.y = nb > 0 pairs in flight, one S16 tensor pair each; the weights are shared,
+    // so the workgroups of all pairs stream them from the L2 together and the small grids of the coarse blocks fill the chip in one round
+    int nb = 0;
+    const unsigned char* inb[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned char* outb[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
@@ -63,6 +68,8 @@ __global__ __launch_bounds__(2 * C) __attribute__((amdgpu_waves_per_eu(convrow_w
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* const lds = ldsb;
     const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned char* const tin = a.nb ? a.inb[blockIdx.y] : a.in;   // batched: the tensors of pair blockIdx.y
+    unsigned char* const tout = a.nb ? a.outb[blockIdx.y] : a.out;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);              // wave = 32-channel output block
     const int h = lane >> 5, li = lane & 31;
     int L;
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(2 * C) __attribute__((amdgpu_waves_per_eu(convrow_w
     f32x4 stage[NLD];
 #define ROW_LOAD(PHASE)                                                                                      \
     _Pragma("unroll") for (int k = 0; k < NLD; k++)                                                          \
-        stage[k] = *reinterpret_cast<const f32x4*>(a.in + (tb + (unsigned)(2 * PH * (PHASE)) * a.plane + soff[k]));
+        stage[k] = *reinterpret_cast<const f32x4*>(tin + (tb + (unsigned)(2 * PH * (PHASE)) * a.plane + soff[k]));
 #define ROW_STORE(PHASE)                                                                                     \
     _Pragma("unroll") for (int k = 0; k < NLD; k++)                                                          \
         if (PSLOTS % NTHR == 0 || tid + k * NTHR < PSLOTS) *reinterpret_cast<f32x4*>(lds + ((PHASE) & 1) * PH * CHB + (tid + k * NTHR) * 16) = stage[k];
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(2 * C) __attribute__((amdgpu_waves_per_eu(convrow_w
                 v[4 * q + k] = y < 0.f ? y * s4[k] : y;
             }
         }
-        s16_store_chunk(v, a.out + ((size_t)(2 * (2 * w + h)) * a.plane + ((size_t)(oy + 1) * a.pitch + ox + 1) * 32), a.plane, ok);
+        s16_store_chunk(v, tout + ((size_t)(2 * (2 * w + h)) * a.plane + ((size_t)(oy + 1) * a.pitch + ox + 1) * 32), a.plane, ok);
     }
 }
 

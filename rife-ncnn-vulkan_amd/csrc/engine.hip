@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <array>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -701,7 +702,9 @@ static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char*
 }
 
 // one C -> C (C = 128, 192) residual trunk convolution of a coarse block, S16 in / S16 out: one workgroup per ROWS x 32 pixels (conv_row.h)
-static int launch_row(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st) {
+// nb > 0: one launch for the tensors inb[k] -> outb[k] of nb pairs in flight (gridDim.y = nb)
+static int launch_row(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, int nb = 0,
+                      const unsigned char* const* inb = nullptr, unsigned char* const* outb = nullptr) {
     const unsigned char* const rimg = L.cout == 96 ? L.d_row : L.d_t64;
     if (!rimg) return fail(RIFE_HIP_EINVAL, "layer has no conv_row image");
     {
@@ -717,12 +720,16 @@ static int launch_row(const ConvLayer& L, const unsigned char* in, unsigned char
     const S16Geom G(H, W);
     RowArgs a;
     a.in = in; a.out = out; a.img = rimg; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x;
-    if (L.cout == 192) { a.ntiles = a.tiles_x * H; hipLaunchKernelGGL((conv_row_kernel<192, 1, 0>), dim3(a.ntiles), dim3(384), (convrow_lds_bytes<192, 1>()), st, a); }
+    if (nb > 4) return fail(RIFE_HIP_EINVAL, "conv_row batches at most four pairs");
+    a.nb = nb;
+    for (int k = 0; k < nb; k++) { a.inb[k] = inb[k]; a.outb[k] = outb[k]; }
+    const unsigned gy = nb > 0 ? nb : 1;
+    if (L.cout == 192) { a.ntiles = a.tiles_x * H; hipLaunchKernelGGL((conv_row_kernel<192, 1, 0>), dim3(a.ntiles, gy), dim3(384), (convrow_lds_bytes<192, 1>()), st, a); }
     else if (L.cout == 128) {
         a.ntiles = a.tiles_x * ((H + 1) / 2);
-        hipLaunchKernelGGL((conv_row_kernel<128, 2, 1>), dim3(a.ntiles), dim3(256), (convrow_lds_bytes<128, 2>()), st, a);
+        hipLaunchKernelGGL((conv_row_kernel<128, 2, 1>), dim3(a.ntiles, gy), dim3(256), (convrow_lds_bytes<128, 2>()), st, a);
     }
-    else if (L.cout == 96) { a.ntiles = a.tiles_x * ((H + 1) / 2); hipLaunchKernelGGL((conv_row_kernel<96, 2, 2>), dim3(a.ntiles), dim3(192), (convrow_lds_bytes<96, 2, 2>()), st, a); }
+    else if (L.cout == 96) { a.ntiles = a.tiles_x * ((H + 1) / 2); hipLaunchKernelGGL((conv_row_kernel<96, 2, 2>), dim3(a.ntiles, gy), dim3(192), (convrow_lds_bytes<96, 2, 2>()), st, a); }
     else return fail(RIFE_HIP_EINVAL, "conv_row serves 96, 128 and 192 channels");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_row launch: ") + hipGetErrorString(e));
@@ -799,6 +806,7 @@ struct Ctx {
     // hipGraph replay of the plain v4 schedule for launch-bound frame sizes: fixed staging buffers (d_in0 / d_in1 / d_out), the
     // timestep in device memory, one warm-up pass (lazy allocations, kernel attributes), then capture once and replay
     float* d_ts = nullptr;
+    hipEvent_t ev_group = nullptr;                                    // rife_hip_process_batch: cross-stream hand-off around a batched coarse trunk
     hipGraphExec_t gexec = nullptr;
     bool g_warm = false;
     // rife-v2.x only
@@ -818,6 +826,7 @@ struct Ctx {
     std::vector<void*> allocs;
     ~Ctx() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (ev_group) (void)hipEventDestroy(ev_group);
         for (void* p : allocs) (void)hipFree(p);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -1034,12 +1043,24 @@ static int run_assemble(const rife_hip& E, Ctx& c, int b, float timestep, const 
 }
 
 // One IFBlock: stems, 8 residual convs, head -> flow[b]   (flownet.param:11-46, 63-98, 116-151, 166-201)
-static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, const FinalArgs* fin = nullptr, const float* tsp = nullptr) {
+// which trunk kernel serves block b at this frame size: 0 = conv_t64 / conv_rs (fine blocks), 1 = conv_row (coarse blocks, small grids)
+static bool block_on_row_kernel(const rife_hip& E, const Ctx& c, int b) {
+    const rife_hip::Block& B = E.blk[b];
+    const int s = B.scale, Ht = c.hp / s / 4, Wt = c.wp / s / 4;
+    const int ptiles = ((Ht + 7) / 8) * ((Wt + 31) / 32);
+    const bool row_small = b == 2 && B.c == 96 && ptiles <= 256;
+    return (b == 1 && B.c == 128) || (b == 0 && B.c == 192 && ((Wt + 31) / 32) * Ht <= 160) || row_small;
+}
+
+enum { PH_STEMS = 1, PH_TRUNK = 2, PH_HEAD = 4, PH_ALL = 7 };
+// phases != PH_ALL (rife_hip_process_batch): the S16 path only; PH_TRUNK is then the caller's batched launch
+static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, const FinalArgs* fin = nullptr, const float* tsp = nullptr, int phases = PH_ALL) {
     const rife_hip::Block& B = E.blk[b];
     hipStream_t st = c.stream;
     const int s = B.scale, Hb = c.hp / s, Wb = c.wp / s;
     const int xin_ld = b == 0 ? 8 : 16;
     int rc;
+    if (!(phases & PH_STEMS)) goto after_stem0;
     if (b == 0 && (rc = run_assemble(E, c, 0, timestep, tsp))) return rc;
     if (b > 0 && B.stem0.d_wh && g_trunk_h2 && g_fuse_stem) {
         // assemble + stem-0 in one kernel (stem_fused.h): the block input never goes to HBM
@@ -1068,6 +1089,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
         Timed t(E.prof, B.stem0.cls, B.stem0.flops_per_pixel * (Hb / 2) * (Wb / 2), st);
         if ((rc = launch_conv(B.stem0, {c.X, xin_ld, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, nullptr, st))) return rc;
     }
+after_stem0:
     const int Ht = Hb / 4, Wt = Wb / 4;
     // S16 trunk tensors: blocks 3 / 2 on the persistent LDS-DMA kernel (conv_t64.h; block 2 only when its grid fills a good part of the
     // chip), the coarse blocks 1 / 0 on the one-pass row kernel (conv_row.h).  (Blocks 1 / 0 as N-tiles of 64 output channels on the
@@ -1082,19 +1104,19 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
     // tile per workgroup there and fills only part of the chip: 1080p (136 tiles) trunk_b2 0.229 -> 0.179 ms per pair on the row kernel, 4K (510 tiles)
     // 0.387 -> 0.401; block 3 (64 channels, two workgroups per CU) stays on the persistent kernel at every size (1080p 0.225 vs 0.233)
     const bool row_small = b == 2 && B.c == 96 && ptiles <= 256;
-    const bool rowk = (b == 1 && B.c == 128) || (b == 0 && B.c == 192 && ((Wt + 31) / 32) * Ht <= 160) || row_small;
+    const bool rowk = block_on_row_kernel(E, c, b);
     bool s16 = E.t64 && !E.v40 && g_trunk_h2 && PA && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS &&
                ((b == 3 && B.c == 64) || (b == 2 && B.c == 96) || rowk);
     for (int i = 0; i < 8 && s16; i++) s16 = B.res[i].d_t64 != nullptr && (!row_small || B.res[i].d_row != nullptr);
     if (s16) {
         // stem-1 writes the first S16 tensor, eight persistent trunk launches ping-pong between the two, the head reads the last one
         const S16Geom G(Ht, Wt);
-        {
+        if (phases & PH_STEMS) {
             Timed t(E.prof, B.stem1.cls, B.stem1.flops_per_pixel * Ht * Wt, st);
             if ((rc = launch_conv(B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {reinterpret_cast<float*>(PA), B.c, 0}, nullptr, st, nullptr, G.pitch, G.plane()))) return rc;
         }
         unsigned char *pc = PA, *pn = PB;
-        for (int i = 0; i < 8; i++) {
+        if (phases & PH_TRUNK) for (int i = 0; i < 8; i++) {
             Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
             if (rowk) rc = launch_row(B.res[i], pc, pn, Ht, Wt, st);
             else if (E.rs && B.c == 64 && (Ht + 1) / 2 >= RS_MIN_PAIRS) rc = launch_rs(B.res[i], pc, pn, Ht, Wt, st, (i & 1) != 0);      // tiny tensors: conv_t64
@@ -1102,9 +1124,11 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
             if (rc) return rc;
             std::swap(pc, pn);
         }
-        Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);
-        return launch_conv(B.head, {reinterpret_cast<float*>(pc), B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st, fin, G.pitch, G.plane());
+        if (!(phases & PH_HEAD)) return 0;
+        Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);      // eight layers: the trunk output is back in PA
+        return launch_conv(B.head, {reinterpret_cast<float*>(PA), B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st, fin, G.pitch, G.plane());
     }
+    if (phases != PH_ALL) return fail(RIFE_HIP_EINVAL, "phased block execution needs the S16 trunk path");
     float* const stem_out = E.v40 ? c.T2 : c.T0;
     {
         Timed t(E.prof, B.stem1.cls, B.stem1.flops_per_pixel * (Hb / 4) * (Wb / 4), st);
@@ -1174,6 +1198,67 @@ static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
         hipLaunchKernelGGL(k_final, grid2d(c.w, c.h), dim3(256), 0, st, c.img0, c.img1, c.F, c.M, c.flow[3], d_out, c.w, c.h, c.wp, c.hp);
         HIPCHK(hipGetLastError());
     }
+    return 0;
+}
+
+// RIFE::process_v4 for G (2..4) pairs in LOCKSTEP (rife_hip_process_batch, SURVEY 8f-2 "batch >= 2 pairs per launch for the coarse blocks"):
+// every pair keeps its own workspace and stream, so the fine blocks of different pairs overlap as before; the eight trunk layers of a block that
+// runs on conv_row_kernel (the coarse blocks 1 / 0, block 2 on small grids; flownet.param:14-42, 66-94) are ONE launch per layer for all pairs
+// (gridDim.y = G) on the first pair's stream, between two event hand-offs.  The workgroups of all pairs stream the layer's weights from the L2
+// together, and the coarse grids - 68 / 255 workgroups per pair at 1080p - fill the chip in one round instead of G.
+// Same kernels, same arguments per tensor: the frames are bit-identical to G single calls.
+static int run_v4_group(const rife_hip& E, Ctx* const* cs, int G, const uint8_t* const* d_in0, const uint8_t* const* d_in1, const float* ts, uint8_t* const* d_out) {
+    int rc;
+    for (int g = 0; g < G; g++) {
+        Ctx& c = *cs[g];
+        if (!c.ev_group) HIPCHK(hipEventCreateWithFlags(&c.ev_group, hipEventDisableTiming));
+        Timed t(E.prof, "preproc", 0, c.stream);
+        launch_preproc(c.stream, d_in0[g], c.w, c.h, c.img0, c.wp, c.hp);
+        launch_preproc(c.stream, d_in1[g], c.w, c.h, c.img1, c.wp, c.hp);
+        HIPCHK(hipGetLastError());
+    }
+    const bool fuse_tail = g_trunk_h2 && g_head_h2 && g_fuse_tail && E.blk[3].head.d_wh != nullptr;
+    for (int b = 0; b < 4; b++) {
+        const rife_hip::Block& B = E.blk[b];
+        bool batched = G >= 2 && E.t64 && block_on_row_kernel(E, *cs[0], b) && cs[0]->P[b][0] && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS;
+        for (int i = 0; i < 8 && batched; i++) batched = (B.c == 96 ? B.res[i].d_row : B.res[i].d_t64) != nullptr;
+        for (int g = 0; g < G; g++) {
+            Ctx& c = *cs[g];
+            FinalArgs fin{c.img0, c.img1, c.F, c.M, d_out[g], c.w, c.h, c.wp, c.hp};
+            if (!batched) {
+                if ((rc = run_block_convs(E, c, b, ts[g], (b == 3 && fuse_tail) ? &fin : nullptr))) return rc;
+                if (b < 3 && (rc = run_flow_update(E, c, b))) return rc;
+            } else {
+                if ((rc = run_block_convs(E, c, b, ts[g], nullptr, nullptr, PH_STEMS))) return rc;
+                if (g > 0) HIPCHK(hipEventRecord(c.ev_group, c.stream));
+            }
+        }
+        if (!batched) continue;
+        hipStream_t lead = cs[0]->stream;
+        for (int g = 1; g < G; g++) HIPCHK(hipStreamWaitEvent(lead, cs[g]->ev_group, 0));
+        {
+            const int s = B.scale, Ht = cs[0]->hp / s / 4, Wt = cs[0]->wp / s / 4;
+            const unsigned char* pin[4]; unsigned char* pout[4];
+            for (int i = 0; i < 8; i++) {
+                for (int g = 0; g < G; g++) { pin[g] = cs[g]->P[b][i & 1]; pout[g] = cs[g]->P[b][(i & 1) ^ 1]; }
+                Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt * G, lead);
+                if ((rc = launch_row(B.res[i], nullptr, nullptr, Ht, Wt, lead, G, pin, pout))) return rc;
+            }
+        }
+        HIPCHK(hipEventRecord(cs[0]->ev_group, lead));
+        for (int g = 0; g < G; g++) {
+            Ctx& c = *cs[g];
+            if (g > 0) HIPCHK(hipStreamWaitEvent(c.stream, cs[0]->ev_group, 0));
+            if ((rc = run_block_convs(E, c, b, ts[g], nullptr, nullptr, PH_HEAD))) return rc;
+            if (b < 3 && (rc = run_flow_update(E, c, b))) return rc;
+        }
+    }
+    for (int g = 0; g < G; g++)
+        if (!fuse_tail) {
+            Ctx& c = *cs[g];
+            hipLaunchKernelGGL(k_final, grid2d(c.w, c.h), dim3(256), 0, c.stream, c.img0, c.img1, c.F, c.M, c.flow[3], d_out[g], c.w, c.h, c.wp, c.hp);
+            HIPCHK(hipGetLastError());
+        }
     return 0;
 }
 
@@ -2106,6 +2191,13 @@ int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1
 // them, so overlap of one pair's copies with another pair's kernels needs several host threads - the reference's proc threads
 // (src/main.cpp:849-866).  The batch call brings its own: 2 workers (the reference default), each a plain rife_hip_process() loop over its share of
 // the pairs (every call leases its own workspace + stream).  Same pixels as n rife_hip_process() calls.
+struct rife_hip_frame {
+    uint8_t* d = nullptr;      // tight u8 HWC RGB, the layout every run_* entry takes
+    int w = 0, h = 0, gpuid = 0;
+    size_t nbytes = 0;
+    std::shared_ptr<FramePool> pool;
+};
+
 int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0, const uint8_t* const* in1, const float* timestep,
                            uint8_t* const* out, int w, int h) {
     int rc;
@@ -2144,6 +2236,70 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     };
     std::vector<int> rcs(K, 0);
     std::vector<std::string> errs(K);
+    // Lockstep groups (plain rife-v4.6 on the S16 trunks): two workers, each takes groups of two consecutive pairs through run_v4_group - the coarse
+    // blocks of a group are batched launches - so four pairs are in flight and one worker's copies overlap the other's passes.  A trailing odd pair,
+    // timestep 0 / 1 copies and every other model family take the per-pair path below.
+    const bool groups = E->v4 && !E->v40 && !E->v1 && !E->tta && !E->tta_temporal && E->t64 && n >= 2 && !(getenv("RIFE_HIP_BATCH_GROUPS") && getenv("RIFE_HIP_BATCH_GROUPS")[0] == '0');
+    if (groups) {
+        std::vector<std::array<int, 2>> grp;                 // pair indices of a group, -1 = none
+        std::vector<int> singles;
+        {
+            int pend = -1;
+            for (int i = 0; i < n; i++) {
+                if (timestep[i] == 0.f || timestep[i] == 1.f) { singles.push_back(i); continue; }
+                if (pend < 0) pend = i; else { grp.push_back({pend, i}); pend = -1; }
+            }
+            if (pend >= 0) singles.push_back(pend);
+        }
+        const int KG = std::min<int>(2, (int)grp.size() + (singles.empty() ? 0 : 1));
+        std::vector<int> grc(std::max(KG, 1), 0);
+        std::vector<std::string> gerr(std::max(KG, 1));
+        const size_t nbytes = (size_t)w * h * 3;
+        auto one_pair = [&](int i) -> int {
+            if (timestep[i] == 0.f || timestep[i] == 1.f) return rife_hip_process(E, in0[i], in1[i], w, h, timestep[i], out[i]);
+            rife_hip_frame_t *f0 = nullptr, *f1 = nullptr;
+            int r = resident(in0[i], f0);
+            if (!r) r = resident(in1[i], f1);
+            if (!r) r = rife_hip_process_frames(E, f0, f1, timestep[i], out[i]);
+            retire(in0[i]); retire(in1[i]);
+            return r;
+        };
+        auto gworker = [&](int k) {
+            (void)hipSetDevice(E->gpuid);
+            std::unique_ptr<Ctx> c[2];
+            int r = 0;
+            for (size_t q = k; q < grp.size() && !r; q += KG) {
+                const int ia = grp[q][0], ib = grp[q][1];
+                rife_hip_frame_t* f[4] = {nullptr, nullptr, nullptr, nullptr};
+                const uint8_t* hp[4] = {in0[ia], in1[ia], in0[ib], in1[ib]};
+                int nres = 0;
+                for (; nres < 4 && !r; nres++) r = resident(hp[nres], f[nres]);
+                if (r) nres--;
+                for (int g = 0; g < 2 && !r; g++) if (!c[g]) r = lease_ctx(E, c[g], w, h);
+                if (!r) {
+                    Ctx* cs[2] = {c[0].get(), c[1].get()};
+                    const uint8_t* d0[2] = {f[0]->d, f[2]->d}; const uint8_t* d1[2] = {f[1]->d, f[3]->d};
+                    const float ts[2] = {timestep[ia], timestep[ib]};
+                    uint8_t* dout[2] = {c[0]->d_out, c[1]->d_out};
+                    r = run_v4_group(*E, cs, 2, d0, d1, ts, dout);
+                    if (!r && hipMemcpyAsync(out[ia], c[0]->d_out, nbytes, hipMemcpyDeviceToHost, c[0]->stream) != hipSuccess) r = fail(RIFE_HIP_EHIP, "D2H failed");
+                    if (!r && hipMemcpyAsync(out[ib], c[1]->d_out, nbytes, hipMemcpyDeviceToHost, c[1]->stream) != hipSuccess) r = fail(RIFE_HIP_EHIP, "D2H failed");
+                }
+                for (int g = 0; g < 2; g++) if (c[g] && hipStreamSynchronize(c[g]->stream) != hipSuccess && !r) r = fail(RIFE_HIP_EHIP, "stream sync failed");
+                for (int j = 0; j < nres; j++) retire(hp[j]);
+            }
+            for (int g = 0; g < 2; g++) if (c[g]) release_ctx(E, c[g]);
+            if (!r && k == KG - 1) for (int i : singles) if ((r = one_pair(i))) break;       // the leftovers ride on the last worker
+            if (r) { grc[k] = r; gerr[k] = g_err; }
+        };
+        std::vector<std::thread> gth;
+        for (int k = 1; k < KG; k++) gth.emplace_back(gworker, k);
+        if (KG > 0) gworker(0);
+        for (auto& t : gth) t.join();
+        for (auto& kv : shared) if (kv.second->f) rife_hip_frame_release(kv.second->f);      // only after an error
+        for (int k = 0; k < KG; k++) if (grc[k]) { g_err = gerr[k]; return grc[k]; }
+        return 0;
+    }
     auto worker = [&](int k) {
         (void)hipSetDevice(E->gpuid);
         for (int i = k; i < n; i += K) {
@@ -2169,12 +2325,6 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
 }
 
 // ---- stream mode: frames resident in device memory across calls (include/rife_hip.h) ----
-struct rife_hip_frame {
-    uint8_t* d = nullptr;      // tight u8 HWC RGB, the layout every run_* entry takes
-    int w = 0, h = 0, gpuid = 0;
-    size_t nbytes = 0;
-    std::shared_ptr<FramePool> pool;
-};
 
 static int rife_hip_frame_upload_impl(const rife_hip_t* E, const uint8_t* rgb, int w, int h, rife_hip_frame_t** frame) {
     if (frame) *frame = nullptr;

@@ -176,6 +176,28 @@ def test_process_batch_equals_single_calls(engines):
     assert g.process_batch([], [], []) == []
 
 
+@pytest.mark.parametrize("w,h,n", [(160, 96, 9), (640, 360, 7), (1920, 1080, 6)])
+def test_process_batch_lockstep_groups_equal_single_calls(engines, w, h, n):
+    """The lockstep-group path of rife_hip_process_batch (pairs of pairs; the coarse blocks' trunk layers are one launch for both, gridDim.y = 2;
+    SURVEY 8f-2) against n single calls: identical bytes, with shared frames (a sequence), an odd pair left over and timestep 0 / 1 copies in the mix,
+    and against the per-pair path of the same call (RIFE_HIP_BATCH_GROUPS=0)."""
+    import os
+    g, _ = engines
+    frames = [gen_frames.smooth_pair(w, h, 500 + i)[i & 1] for i in range(n + 1)]
+    ts = [(0.5, 0.25, 0.0, 0.7, 1.0, 0.125, 0.9, 0.3, 0.6)[i % 9] for i in range(n)]
+    want = [g.process(frames[i], frames[i + 1], ts[i]) for i in range(n)]
+    got = g.process_batch(frames[:n], frames[1:n + 1], ts)
+    for i in range(n):
+        assert np.array_equal(got[i], want[i]), (i, ts[i])
+    os.environ["RIFE_HIP_BATCH_GROUPS"] = "0"
+    try:
+        got0 = g.process_batch(frames[:n], frames[1:n + 1], ts)
+    finally:
+        del os.environ["RIFE_HIP_BATCH_GROUPS"]
+    for i in range(n):
+        assert np.array_equal(got0[i], want[i]), (i, ts[i])
+
+
 def test_8k_within_1_lsb(engines):
     """Maximum-size case: 7680x4320 (4x the pixels of the north-star frame; ~6.5 GB of workspace)."""
     g, o = engines
