@@ -2236,10 +2236,15 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     };
     std::vector<int> rcs(K, 0);
     std::vector<std::string> errs(K);
-    // Lockstep groups (plain rife-v4.6 on the S16 trunks): two workers, each takes groups of two consecutive pairs through run_v4_group - the coarse
-    // blocks of a group are batched launches - so four pairs are in flight and one worker's copies overlap the other's passes.  A trailing odd pair,
+    // Lockstep groups (plain rife-v4.6 on the S16 trunks): three workers, each takes groups of two consecutive pairs through run_v4_group - the coarse
+    // blocks of a group are batched launches - so up to six pairs are in flight and one worker's copies overlap the others' passes.  A trailing odd pair,
     // timestep 0 / 1 copies and every other model family take the per-pair path below.
-    const bool groups = E->v4 && !E->v40 && !E->v1 && !E->tta && !E->tta_temporal && E->t64 && n >= 2 && !(getenv("RIFE_HIP_BATCH_GROUPS") && getenv("RIFE_HIP_BATCH_GROUPS")[0] == '0');
+    // (only where the coarse grids leave CUs idle - block 0 on the row kernel, frames up to ~1080p: at 3840x2160 a coarse layer of ONE pair already
+    // fills the chip, measured 405 - 413 frames/s in groups against 400 - 425 per pair; RIFE_HIP_BATCH_GROUPS=1 / 0 forces / forbids the path)
+    const char* genv = getenv("RIFE_HIP_BATCH_GROUPS");
+    const int Ht0 = (h + 31) / 32, Wt0 = (w + 31) / 32;
+    const bool small_grid = ((Wt0 + 31) / 32) * Ht0 <= 160;
+    const bool groups = E->v4 && !E->v40 && !E->v1 && !E->tta && !E->tta_temporal && E->t64 && n >= 2 && (genv ? genv[0] != '0' : small_grid);
     if (groups) {
         std::vector<std::array<int, 2>> grp;                 // pair indices of a group, -1 = none
         std::vector<int> singles;
@@ -2251,7 +2256,7 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
             }
             if (pend >= 0) singles.push_back(pend);
         }
-        const int KG = std::min<int>(2, (int)grp.size() + (singles.empty() ? 0 : 1));
+        const int KG = std::min<int>(3, (int)grp.size() + (singles.empty() ? 0 : 1));      // three workers x two pairs in flight
         std::vector<int> grc(std::max(KG, 1), 0);
         std::vector<std::string> gerr(std::max(KG, 1));
         const size_t nbytes = (size_t)w * h * 3;
