@@ -14,7 +14,8 @@ import shutil
 import sys
 
 PASSES = {"mfma_lds": "SQ_VALU_MFMA_BUSY_CYCLES", "wait": "SQ_WAIT_ANY", "fetch": "FETCH_SIZE", "write": "WRITE_SIZE"}
-DOMINANT = "conv_t64_kernel<3, 2>"
+DOMINANT = "conv_rs_kernel"       # round 3: the row-streaming kernel serves the block-3 trunk (round 2: "conv_t64_kernel<3, 2>")
+TRUNKS = ("conv_rs_kernel", "conv_t64_kernel")
 
 
 def parse(path):
@@ -42,16 +43,16 @@ def main(src, dst, pairs=3):
     # ---- trunk kernels
     with open(os.path.join(dst, "pmc_trunk_kernels_4k.txt"), "w") as o:
         o.write("# bash tools/profile_round.sh: rocprofv3 --kernel-trace --pmc <pass> -- python tools/prof_run.py --workload 4k --pairs %d   (MI355X)\n" % pairs)
-        o.write("# per-dispatch means for the persistent trunk kernels (trunk_b3 = conv_t64_kernel<3, 2>, 64 channels; trunk_b2 = conv_t64_kernel<2, 3>, 96 channels), 4 separate PMC passes\n")
+        o.write("# per-dispatch means for the persistent trunk kernels (trunk_b3 = conv_rs_kernel<0>, 64 channels; trunk_b2 = conv_t64_kernel<2, 3>, 96 channels), 4 separate PMC passes\n")
         for short in PASSES:
             for k, c in tabs[short].items():
-                if "conv_t64_kernel" in k:
+                if any(t in k for t in TRUNKS):
                     o.write(k + "\n")
                     for n, v in sorted(c.items()):
                         o.write("    %-32s %18.1f\n" % (n, v))
         o.write("# derived\n")
         for k in f:
-            if "conv_t64_kernel" in k and k in w and k in m:
+            if any(t in k for t in TRUNKS) and k in w and k in m:
                 hb = f[k]["FETCH_SIZE"] * 2 * 1024 + w[k]["WRITE_SIZE"] * 1024
                 busy = m[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * m[k]["GRBM_GUI_ACTIVE"] / 8)      # GRBM_GUI_ACTIVE is summed over the 8 XCDs
                 o.write("%s: HBM bytes per launch %.1f MB (fetch %.1f + write %.1f), %.2f TB/s over the mean %.1f us; matrix pipe busy %.1f %%; LDS bank conflicts %.0f\n" % (

@@ -6,10 +6,10 @@
 # 3) the dominant kernel's ablation timings and per-step clock stamps (tools/t64_bench.py)
 # 4) bench.py JSON lines for every workload, the host-path sweep
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profile_$TAG
-DOM=${DOM:-conv_t64_kernel}
+DOM=${DOM:-conv_rs_kernel}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $ROOT/tools/prof_run.py --workload 4k --pairs 8 > $OUT/kt.log 2>&1
@@ -26,8 +26,8 @@ done
 # keep only the small summaries (gpurun_out is capped at 64 MiB)
 rm -rf $OUT/kt $OUT/kt1080 $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES $OUT/pmc_SQ_WAIT_ANY $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 cd $ROOT
-timeout 300 python tools/t64_bench.py > $OUT/t64_bench.txt 2>&1
-rm -f gpurun_out/t64_stamps.bin
+timeout 400 python tools/rs_bench.py > $OUT/rs_bench.txt 2>&1
+
 for wl in 4k 1080p v23-1080p 4k-tta; do
     timeout 600 python bench.py --workload $wl --steps 50 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
 done
