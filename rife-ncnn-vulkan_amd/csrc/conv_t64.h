@@ -96,8 +96,12 @@ __device__ __forceinline__ void t64_glds16(const unsigned char* g, unsigned char
     __builtin_amdgcn_global_load_lds((t64_glb_u8*)g, (t64_lds_u8*)l, 16, 0, 0);
 }
 
-template <int TAG, int NS = 2>
-__global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t64_wg_per_cu(NS), 2 * t64_wg_per_cu(NS)))) void conv_t64_kernel(T64Args a) {
+// LW (round 3): number of extra LOADER waves (0 or 2).  With LW = 2 the workgroup has ten waves: waves 8 and 9 issue every LDS-DMA piece of
+// the halo / weight ring and wait for them, the eight matrix waves issue none and never wait on the vector-memory counter - the stall
+// round 2 measured (a wave that waits for a slot in the CU's memory queue issues no MFMAs) is taken off the matrix waves, as in
+// conv_rs_kernel, without touching the arithmetic: results are bit-identical to LW = 0.
+template <int TAG, int NS = 2, int LW = 0>
+__global__ __launch_bounds__(T64_NTHR + 64 * LW) __attribute__((amdgpu_waves_per_eu(2 * t64_wg_per_cu(NS), 2 * t64_wg_per_cu(NS) + (LW ? 1 : 0)))) void conv_t64_kernel(T64Args a) {
     constexpr int T64_WCH = t64_wch(NS), T64_BSB = t64_bsb(NS), T64_LDS_BS = t64_lds_bs(NS), T64_LDS = t64_lds(NS), CH = 32 * NS;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char* const lds = ldsb;
@@ -106,6 +110,57 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
     const int h = lane >> 5, li = lane & 31;
     long long clk0 = 0, rt0 = 0;
     if (TAG & T64_CLK) { clk0 = (long long)__builtin_readcyclecounter(); rt0 = (long long)__builtin_amdgcn_s_memrealtime(); }
+    if (LW > 0 && r >= T64_TH) {
+        // ---- loader waves: the work-item stream and the ring schedule of the matrix waves below, DMA and waits only
+        const int l = r - T64_TH;
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int slot = (b & 7) * (nwg >> 3) + (b >> 3);
+        const int nitems = a.ntiles * a.nnt;
+        const int mine = nitems > slot ? (nitems - slot + nwg - 1) / nwg : 0;
+        const int imgstride = a.nchunks * T64_WCH + T64_BSB;
+        auto item = [&](int w_, unsigned& tb_, int& nt_) {
+            const int wv = a.reverse ? nitems - 1 - w_ : w_;
+            const int t_ = wv / a.nnt; nt_ = wv - t_ * a.nnt;
+            const int ty_ = t_ / a.tiles_x;
+            tb_ = (unsigned)(ty_ * T64_TH * a.pitch + (t_ - ty_ * a.tiles_x) * 32) * 32u;
+        };
+        auto dma_in = [&](unsigned tb_, int c, int par) {                // the 22 pieces of a halo chunk, every LW-th one
+            const unsigned char* src_ = a.in + (tb_ + (unsigned)(2 * c) * a.plane);
+            for (int i = l; i < 22; i += LW) {
+                const int sidx = i * 64 + lane;
+                const int pl = sidx >= 2 * T64_NPX ? 1 : 0, s1 = sidx - pl * 2 * T64_NPX;
+                const int P = min(s1 >> 1, T64_NPX - 1), pos = s1 & 1;
+                const int kh = pos ^ ((P >> 3) & 1);
+                const int py = P / T64_IW, px = P - py * T64_IW;
+                const unsigned so = (unsigned)pl * a.plane + (unsigned)(py * a.pitch + px) * 32u + (unsigned)(kh * 16);
+                if (sidx < 4 * T64_NPX) t64_glds16(src_ + so, lds + T64_LDS_IN + par * T64_INB + i * 1024);
+            }
+        };
+        auto dma_w = [&](int nt_, int c, int par) {
+            const unsigned char* src_ = a.img + (nt_ * imgstride + c * T64_WCH) + lane * 16;
+            for (int i = l; i < T64_WCH / 1024; i += LW) t64_glds16(src_ + i * 1024, lds + T64_LDS_W + par * T64_WCH + i * 1024);
+        };
+        auto dma_bs = [&](int nt_, int buf) {
+            if (l == 0 && lane < T64_BSB / 16) t64_glds16(a.img + (nt_ * imgstride + a.nchunks * T64_WCH) + lane * 16, lds + T64_LDS_BS + buf * T64_BSB);
+        };
+        auto sync = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+        unsigned tb = 0; int nt = 0;
+        if (mine > 0) { item(slot, tb, nt); dma_bs(nt, 0); dma_w(nt, 0, 0); dma_in(tb, 0, 0); }
+        sync();
+        for (int k = 0; k < mine; k++) {
+            const bool more = k + 1 < mine;
+            unsigned tbn = 0; int ntn = 0;
+            if (more) item(slot + (k + 1) * nwg, tbn, ntn);
+            for (int c = 0; c < a.nchunks; c++) {
+                if (c + 1 < a.nchunks) { dma_in(tb, c + 1, (c & 1) ^ 1); dma_w(nt, c + 1, (c & 1) ^ 1); }
+                else if (more) { dma_in(tbn, 0, 0); dma_w(ntn, 0, 0); }
+                if (c == 1 && more) dma_bs(ntn, (k + 1) & 1);
+                sync();
+            }
+            tb = tbn; nt = ntn;
+        }
+        return;
+    }
 
     // ---- per-lane constants
     // halo DMA: piece i = r + 8 j of the chunk buffer covers LDS slots 64 i .. 64 i + 63 (16 bytes each)
@@ -166,7 +221,7 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
         a.stamps[(((size_t)blockIdx.x * 8 + r) * 32 + stepno) * 4 + (K)] = (long long)__builtin_readcyclecounter();
     // halo chunk C of the tile at TB -> in[PAR]; weight chunk C -> w[PAR]
 #define T64_DMA_IN(TB, C, PAR)                                                                               \
-    if (!(TAG & T64_NODMA)) {                                                                                \
+    if (!(TAG & T64_NODMA) && LW == 0) {                                                                                \
         const unsigned char* src_ = a.in + ((TB) + (unsigned)(2 * (C)) * a.plane);       /* wave-uniform base + 32-bit lane offset */ \
         unsigned char* dst_ = lds + T64_LDS_IN + (PAR) * T64_INB + r * 1024;                                 \
         t64_glds16(src_ + soff[0], dst_);                                                                    \
@@ -174,7 +229,7 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
         if (r < 6 && s2ok) t64_glds16(src_ + soff[2], dst_ + 16 * 1024);                                     \
     }
 #define T64_DMA_W(NT, C, PAR)                                                                                \
-    if (!(TAG & T64_NODMA)) {                                                                                \
+    if (!(TAG & T64_NODMA) && LW == 0) {                                                                                \
         const unsigned char* src_ = a.img + ((NT) * imgstride + (C) * T64_WCH + r * 1024) + lane * 16;       \
         unsigned char* dst_ = lds + T64_LDS_W + (PAR) * T64_WCH + r * 1024;                                  \
         t64_glds16(src_, dst_);                                                                              \
@@ -205,7 +260,7 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
 #define T64_SYNC()                                                                                           \
     {                                                                                                        \
         T64_STAMP(0)                                                                                         \
-        if (!(TAG & T64_NOVMWAIT)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
+        if (!(TAG & T64_NOVMWAIT) && LW == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* LW > 0: only epilogue stores are in flight here */ \
         T64_STAMP(1)                                                                                         \
         __builtin_amdgcn_s_barrier();                                                                        \
         T64_STAMP(2)                                                                                         \
@@ -234,7 +289,7 @@ __global__ __launch_bounds__(T64_NTHR) __attribute__((amdgpu_waves_per_eu(2 * t6
 
     // ---- prologue: bias / slopes, weight chunk 0, halo chunk 0 of the first work item
 #define T64_DMA_BS(NT, BUF)                                                                                  \
-    if (r == 7 && lane < T64_BSB / 16 && !(TAG & T64_NODMA))                                                 \
+    if (r == 7 && lane < T64_BSB / 16 && !(TAG & T64_NODMA) && LW == 0)                                      \
         t64_glds16(a.img + ((NT) * imgstride + a.nchunks * T64_WCH) + lane * 16, lds + T64_LDS_BS + (BUF) * T64_BSB);
     if (TAG & T64_NODMA) { for (int i = tid; i < T64_LDS / 16; i += T64_NTHR) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     if (mine > 0) { T64_DMA_BS(nt, 0) T64_DMA_W(nt, 0, 0) T64_DMA_IN(tb, 0, 0) }

@@ -640,6 +640,8 @@ struct S16Geom {
 // reverse: walk the tiles last to first.  Consecutive trunk layers alternate, so that a layer starts on what its predecessor wrote
 // last - still in the L2 / Infinity Cache (134 MB in + 134 MB out per 4K layer against 256 MB of cache: in one direction only the
 // first rows of a layer's input were written more than a cache-full of traffic ago by the time they are read).
+// RIFE_HIP_T64_LW=0: the 96-channel trunk without loader waves (A/B; conv_t64.h, template parameter LW)
+static const bool g_t64_loader_waves = []() { const char* e = getenv("RIFE_HIP_T64_LW"); return !(e && e[0] == '0'); }();
 static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool reverse = false) {
     if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_t64 image");
     const int NS = t64_ns(L.cout);
@@ -652,6 +654,7 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
         if (it == ncu.end()) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_t64_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, t64_lds(2)));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_t64_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, t64_lds(3)));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_t64_kernel<2, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, t64_lds(3)));
             int n = 0;
             HIPCHK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
             it = ncu.emplace(dev, std::max(8, n / 8 * 8)).first;
@@ -664,6 +667,7 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
     a.nchunks = L.cout / 16; a.nnt = L.cout / (32 * NS);
     const int nwg = std::min(t64_wg_per_cu(NS) * cus, (a.ntiles * a.nnt + 7) / 8 * 8);      // all workgroups resident at once
     if (L.cout == 64) hipLaunchKernelGGL((conv_t64_kernel<3, 2>), dim3(nwg), dim3(T64_NTHR), t64_lds(2), st, a);       // TAG: the profile class (trunk_b3 .. trunk_b0)
+    else if (L.cout == 96 && g_t64_loader_waves) hipLaunchKernelGGL((conv_t64_kernel<2, 3, 2>), dim3(nwg), dim3(T64_NTHR + 128), t64_lds(3), st, a);      // two loader waves
     else if (L.cout == 96) hipLaunchKernelGGL((conv_t64_kernel<2, 3>), dim3(nwg), dim3(T64_NTHR), t64_lds(3), st, a);
     else return fail(RIFE_HIP_EINVAL, "conv_t64 serves 64 and 96 channels");
     hipError_t e = hipGetLastError();
