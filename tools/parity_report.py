@@ -1,4 +1,4 @@
-"""Parity report per BASELINE config (SURVEY.md §8d "Parity reporting"): HIP engine vs CPU oracle on the F2 (smooth synthetic) and
+"""Parity report per BASELINE config (SURVEY.md §8d "Parity reporting"): HIP engine vs CPU oracle on the F1 (the reference's real frame pair tiled to size), F2 (smooth synthetic, native resolution) and
 F3 (noise) frames: max |diff| in LSB, share of channels with diff 0 / 1 / >= 2, PSNR.  Run on the GPU box; the output is
 committed as profiles/<round>/parity_report.txt."""
 import importlib, os, sys, time
@@ -28,12 +28,20 @@ for name, fam, w, h, ts, kw in CONFIGS:
     d = gen_models.ensure(None, fam)
     g = amd.RIFE(0, **fl); g.load(d)
     o = pyoracle.OracleRIFE(num_threads=min(len(os.sched_getaffinity(0)), 64), **fl); o.set_gpu_crop(1); o.load(d)
-    for kind in ("F2 smooth", "F3 noise"):
+    for kind in ("F1 real frames tiled", "F2 smooth", "F3 noise"):
         if kind == "F3 noise" and (w > 1920 or "tta_mode" in kw):
             continue                                   # keep the CPU side of the report to a few minutes
+        if kind == "F2 smooth" and "tta_mode" in kw:
+            continue
         diffs = []
         for i, t in enumerate(ts):
-            a, b = (gen_frames.smooth_pair(w, h, 1000 + i) if kind == "F2 smooth" else gen_frames.noise_pair(w, h, 7 + i))
+            if kind.startswith("F1"):
+                a, b = gen_frames.tiled_real_pair(w // 640)
+                if i & 1: a, b = b, a
+            elif kind == "F2 smooth":
+                a, b = gen_frames.smooth_pair(w, h, 1000 + i) if w * h < 4000000 else gen_frames.smooth_pair_native(w, h, 1000 + i)
+            else:
+                a, b = gen_frames.noise_pair(w, h, 7 + i)
             got, want = g.process(a, b, t), o.process(a, b, t)
             diffs.append(np.abs(got.astype(np.int32) - want.astype(np.int32)).ravel())
         dd = np.concatenate(diffs)
