@@ -640,8 +640,9 @@ struct S16Geom {
 // reverse: walk the tiles last to first.  Consecutive trunk layers alternate, so that a layer starts on what its predecessor wrote
 // last - still in the L2 / Infinity Cache (134 MB in + 134 MB out per 4K layer against 256 MB of cache: in one direction only the
 // first rows of a layer's input were written more than a cache-full of traffic ago by the time they are read).
-// RIFE_HIP_T64_LW=0: the 96-channel trunk without loader waves (A/B; conv_t64.h, template parameter LW)
-static const bool g_t64_loader_waves = []() { const char* e = getenv("RIFE_HIP_T64_LW"); return !(e && e[0] == '0'); }();
+// RIFE_HIP_T64_LW=1: the 96-channel trunk with two loader waves (conv_t64.h, template parameter LW).  Off by default: measured equal or 2 % slower
+// (4K, same call: trunk_b2 0.401 vs 0.392 - 0.396 ms per pair) - unlike in conv_rs_kernel, whose consumers also lose the weight stream and the stores
+static const bool g_t64_loader_waves = []() { const char* e = getenv("RIFE_HIP_T64_LW"); return e && e[0] == '1'; }();
 static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool reverse = false) {
     if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_t64 image");
     const int NS = t64_ns(L.cout);
