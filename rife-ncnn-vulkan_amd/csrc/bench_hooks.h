@@ -534,6 +534,35 @@ int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms
     return rc;
 }
 
+// probe of the block-scaled fp8 matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4, both operands e4m3): raw per-lane operand dwords in, the
+// wave's 16 accumulator registers per lane out; the scale dwords go through VGPRs (tools/mx_probe.py pins the operand layout against numpy)
+__global__ void k_probe_mx(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t sa, uint32_t sb, float* __restrict__ d) {
+    const int lane = threadIdx.x;
+    i32x8 av, bv;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { av[j] = (int)a[lane * 8 + j]; bv[j] = (int)b[lane * 8 + j]; }
+    int va = (int)sa, vb = (int)sb;
+    asm volatile("" : "+v"(va), "+v"(vb));
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; r++) c[r] = 0.f;
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 0, 0, 0, va, 0, vb);
+#pragma unroll
+    for (int r = 0; r < 16; r++) d[lane * 16 + r] = c[r];
+}
+int rife_hip_probe_mx(int gpuid, const uint32_t* a, const uint32_t* b, uint32_t sa, uint32_t sb, float* d) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    uint32_t *da = nullptr, *db = nullptr; float* dd = nullptr;
+    HIPCHK(hipMalloc(&da, 64 * 8 * 4)); HIPCHK(hipMalloc(&db, 64 * 8 * 4)); HIPCHK(hipMalloc(&dd, 64 * 16 * 4));
+    HIPCHK(hipMemcpy(da, a, 64 * 8 * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, 64 * 8 * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_mx, dim3(1), dim3(64), 0, 0, da, db, sa, sb, dd);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(d, dd, 64 * 16 * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dd);
+    return 0;
+}
+
 // fills the workgroup's whole LDS allocation with a pattern and leaves: launched between the probe's launches, it decides what the next
 // kernel finds in LDS locations it does not write itself
 __global__ void k_lds_scrub(uint32_t pattern, int ndw, uint32_t* sink) {

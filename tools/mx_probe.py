@@ -1,0 +1,66 @@
+"""GPU box: pin the operand convention of __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4 (both operands OCP e4m3) against numpy.
+A (32 x 64) and B (64 x 32) of small integers (exact in e4m3), D = A @ B with the standard 32 x 32 C/D map
+(col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  Hypotheses for the per-lane packing of A / B are tried until one reproduces D.
+    python tools/mx_probe.py"""
+import ctypes, os, sys, itertools
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from tools import benchlib
+L = benchlib.lib()
+L.rife_hip_probe_mx.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+
+def e4m3(v):
+    """encode small values exactly representable in OCP e4m3fn (bias 7, 3 mantissa bits)"""
+    out = np.zeros(v.shape, np.uint8)
+    for idx, x in np.ndenumerate(v):
+        if x == 0: continue
+        s = 0x80 if x < 0 else 0
+        m = abs(float(x)); e = int(np.floor(np.log2(m))); frac = m / 2.0 ** e - 1.0
+        out[idx] = s | ((e + 7) << 3) | int(round(frac * 8))
+    return out
+
+rng = np.random.default_rng(5)
+A = rng.integers(-4, 5, (32, 64)).astype(np.float32)
+B = rng.integers(-4, 5, (64, 32)).astype(np.float32)
+want = A @ B
+def run(pa, pb, sa=0x7f7f7f7f, sb=0x7f7f7f7f):
+    d = np.zeros((64, 16), np.float32)
+    rc = L.rife_hip_probe_mx(0, pa.ctypes.data, pb.ctypes.data, sa, sb, d.ctypes.data)
+    assert rc == 0
+    D = np.zeros((32, 32), np.float32)
+    for lane in range(64):
+        for r in range(16):
+            D[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), lane & 31] = d[lane, r]
+    return D
+A8, B8 = e4m3(A), e4m3(B)
+# hypotheses: K index of byte j (0..31) of lane (i = lane & 31, g = lane >> 5)
+HYP = {
+    "k = 32 g + j (each half-wave holds 32 consecutive K)": lambda g, j: 32 * g + j,
+    "k = 2 j + g (interleaved)": lambda g, j: 2 * j + g,
+    "k = 16 g + (j % 16) + 32 (j // 16)": lambda g, j: 16 * g + (j % 16) + 32 * (j // 16),
+    "k = 8 g + (j % 8) + 16 (j // 8)": lambda g, j: 8 * g + (j % 8) + 16 * (j // 8),
+    "k = 4 g + (j % 4) + 8 (j // 4)": lambda g, j: 4 * g + (j % 4) + 8 * (j // 4),
+}
+found = None
+for (na, fa), (nb, fb) in itertools.product(HYP.items(), HYP.items()):
+    pa = np.zeros((64, 32), np.uint8); pb = np.zeros((64, 32), np.uint8)
+    for lane in range(64):
+        i, g = lane & 31, lane >> 5
+        for j in range(32):
+            pa[lane, j] = A8[i, fa(g, j)]; pb[lane, j] = B8[fb(g, j), i]
+    D = run(pa.view(np.uint32).reshape(64, 8).copy(), pb.view(np.uint32).reshape(64, 8).copy())
+    ok = np.array_equal(D, want)
+    if ok or na == nb:
+        print("A: %-55s B: %-55s -> %s (max |D - want| %g)" % (na, nb, "MATCH" if ok else "no", float(np.abs(D - want).max())), flush=True)
+    if ok and found is None: found = (na, nb, pa, pb)
+if found:
+    na, nb, pa, pb = found
+    pa32 = pa.view(np.uint32).reshape(64, 8).copy(); pb32 = pb.view(np.uint32).reshape(64, 8).copy()
+    # scales: E8M0 byte 127 = 2^0; which byte does opsel 0 take, and is the scale per lane (row, K block)?
+    for sa, sb, note in ((0x7f7f7f7f, 0x7f7f7f7f, "all bytes 127"), (0x7f7f7f80, 0x7f7f7f7f, "A byte 0 = 128"), (0x7f7f807f, 0x7f7f7f7f, "A byte 1 = 128"),
+                         (0x7f7f7f7f, 0x7f7f7f7e, "B byte 0 = 126"), (0x00000080, 0x0000007e, "bytes 1-3 zero, A 128, B 126")):
+        D = run(pa32, pb32, sa, sb)
+        ratio = D[want != 0] / want[want != 0]
+        print("scales %-32s -> D / want in [%g, %g]" % (note, float(ratio.min()), float(ratio.max())), flush=True)
+else:
+    print("no hypothesis matched")
