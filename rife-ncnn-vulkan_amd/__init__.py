@@ -248,12 +248,13 @@ class RIFE:
 
 
     def v4_tap(self, in0image, in1image, timestep, what, b, inject):
-        """what 0 / 1: 12-channel input of IFBlock b (unfused kernel / through the fused stem kernel); 2: blob out0 before the postproc."""
+        """what 0 / 1: 12-channel input of IFBlock b (unfused kernel / through the fused stem kernel); 2: blob out0 before the postproc;
+        4 / 3: F (4 channels) and M as block b's stem finds them, after k_flow_update / as written by the stem that applies the last update itself."""
         a = np.ascontiguousarray(in0image, dtype=np.uint8); bb = np.ascontiguousarray(in1image, dtype=np.uint8)
         h, w, _ = a.shape
         wp, hp = (w + 31) // 32 * 32, (h + 31) // 32 * 32
         s = {1: 4, 2: 2, 3: 1}.get(b, 1)
-        out = np.empty((3, hp, wp) if what == 2 else (12, hp // s, wp // s), np.float32)
+        out = np.empty((3, hp, wp) if what == 2 else (5, hp, wp) if what in (3, 4) else (12, hp // s, wp // s), np.float32)
         inj = [np.ascontiguousarray(f, dtype=np.float32) for f in inject]
         arr = (ctypes.c_void_p * max(1, len(inj)))(*[f.ctypes.data for f in inj])
         _check(lib().rife_hip_v4_tap(self._h, _p(a), _p(bb), w, h, float(timestep), int(what), int(b), arr, len(inj), _p(out)), "v4_tap")

@@ -138,18 +138,76 @@ __global__ void k_assemble0(const uint32_t* __restrict__ img0, const uint32_t* _
     dst[0] = o0; dst[1] = o1;
 }
 
+// ncnn linear_coeffs for an upscale by S (power of two): fx = (dx + 0.5) / S - 0.5 is exact in fp32 here
+// (the reference computes it in double and rounds to float; all intermediates are dyadic and short).
+__device__ __forceinline__ void up_coeff(int d, int S, int in, int& s0, float& a0, float& a1) {
+    float f = ((float)d + 0.5f) * (1.0f / (float)S) - 0.5f;
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= in - 1) { s = in - 2; f = 1.f; }
+    s0 = s; a0 = 1.f - f; a1 = f;
+}
+
+// One full-resolution pixel of the flow update after a block (flownet.param:47-58, 99-105, 152-158): u = Interp(S)(flow_b) at (x, y);
+// F = F * 1 + u[0:4] * S (Eltwise with coefficients), M = M + u[4].  flow_b is kept as [hp / S][wp / S][8] fp32 {x, y, z, w, mask, unused, 0, 0}.
+// Shared by k_flow_update<S> and by the fused stems that apply the update of the block before them while they gather (stem_fused.h).
+template <int S>
+__device__ __forceinline__ void flow_upsampled(const float* __restrict__ flow, int wp, int hp, int x, int y, float4& u, float& um) {
+    const int Wb = wp / S, Hb = hp / S;
+    int sx, sy; float a0, a1, b0, b1;
+    up_coeff(x, S, Wb, sx, a0, a1);
+    up_coeff(y, S, Hb, sy, b0, b1);
+    const float* p00 = flow + ((size_t)sy * Wb + sx) * 8;
+    const float* p10 = p00 + (size_t)Wb * 8;
+    const float4 q00 = *reinterpret_cast<const float4*>(p00), q01 = *reinterpret_cast<const float4*>(p00 + 8);
+    const float4 q10 = *reinterpret_cast<const float4*>(p10), q11 = *reinterpret_cast<const float4*>(p10 + 8);
+    const float m00 = p00[4], m01 = p00[12], m10 = p10[4], m11 = p10[12];
+#define RIFE_UP(c00, c01, c10, c11) (((c00) * a0 + (c01) * a1) * b0 + ((c10) * a0 + (c11) * a1) * b1)
+    u.x = RIFE_UP(q00.x, q01.x, q10.x, q11.x);
+    u.y = RIFE_UP(q00.y, q01.y, q10.y, q11.y);
+    u.z = RIFE_UP(q00.z, q01.z, q10.z, q11.z);
+    u.w = RIFE_UP(q00.w, q01.w, q10.w, q11.w);
+    um = RIFE_UP(m00, m01, m10, m11);
+#undef RIFE_UP
+}
+template <int S>
+__device__ __forceinline__ void flow_accumulate(const float4 u, const float um, float4& f, float& m) {
+    const float s = (float)S;
+    f = make_float4(f.x * 1.0f + u.x * s, f.y * 1.0f + u.y * s, f.z * 1.0f + u.z * s, f.w * 1.0f + u.w * s);
+    m = m + um;
+}
+
+// A flow update that the consumer of F, M applies itself: F, M are read from the old tensors, updated with Interp(US)(flow) and written to
+// Fw, Mw (different buffers: neighbouring tiles re-read the old values of their shared halo pixels).  flow == nullptr: F, M are current.
+struct FlowPending {
+    const float* flow = nullptr;
+    float4* Fw = nullptr;
+    float* Mw = nullptr;
+};
+
 // Blocks 1..3 input (flownet.param:52-62, 107-115, 160-165):
 //   x = Concat(Interp(1/S)(Concat(warp(in0,F.xy), warp(in1,F.zw), in2, M)), Interp(1/S)(F)/S)  -> NHWC16 (12 + 4 zero)
 // one pixel (bx, by) of the block input at 1/S resolution: 12 channels {warp(in0,F.xy) rgb, warp(in1,F.zw) rgb, t, M, F/S xyzw}
-template <int S>
+// UPD: the flow update of the previous block (scale 2 S) is applied on the way: every full-resolution pixel read here is updated and written
+// to pend.Fw / pend.Mw (same arithmetic as k_flow_update<2 S>: the 12 channels are those of the unfused sequence bit for bit).
+template <int S, bool UPD = false>
 __device__ __forceinline__ void assemble_pixel(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float timestep,
-                                               const float4* __restrict__ F, const float* __restrict__ M, int wp, int hp, int x, int y, float o[12]) {
+                                               const float4* __restrict__ F, const float* __restrict__ M, int wp, int hp, int x, int y, float o[12],
+                                               const FlowPending& pend = FlowPending{}) {
     if (S == 1) {
         const size_t i = (size_t)y * wp + x;
-        const float4 f = F[i];
+        float4 f = F[i];
+        float mk = M[i];
+        if (UPD) {
+            float4 u; float um;
+            flow_upsampled<2 * S>(pend.flow, wp, hp, x, y, u, um);
+            flow_accumulate<2 * S>(u, um, f, mk);
+            pend.Fw[i] = f; pend.Mw[i] = mk;
+        }
         const float3 w0 = warp_rgbx(img0, x, y, f.x, f.y, wp, hp);
         const float3 w1 = warp_rgbx(img1, x, y, f.z, f.w, wp, hp);
-        o[0] = w0.x; o[1] = w0.y; o[2] = w0.z; o[3] = w1.x; o[4] = w1.y; o[5] = w1.z; o[6] = timestep; o[7] = M[i];
+        o[0] = w0.x; o[1] = w0.y; o[2] = w0.z; o[3] = w1.x; o[4] = w1.y; o[5] = w1.z; o[6] = timestep; o[7] = mk;
         o[8] = f.x; o[9] = f.y; o[10] = f.z; o[11] = f.w;
     } else {
         const int sx = S * x + S / 2 - 1, sy = S * y + S / 2 - 1;
@@ -158,11 +216,18 @@ __device__ __forceinline__ void assemble_pixel(const uint32_t* __restrict__ img0
         for (int k = 0; k < 4; k++) {
             const int px = sx + (k & 1), py = sy + (k >> 1);
             const size_t i = (size_t)py * wp + px;
-            const float4 f = F[i];
+            float4 f = F[i];
+            float mk = M[i];
+            if (UPD) {
+                float4 u; float um;
+                flow_upsampled<2 * S>(pend.flow, wp, hp, px, py, u, um);
+                flow_accumulate<2 * S>(u, um, f, mk);
+                pend.Fw[i] = f; pend.Mw[i] = mk;
+            }
             const float3 w0 = warp_rgbx(img0, px, py, f.x, f.y, wp, hp);
             const float3 w1 = warp_rgbx(img1, px, py, f.z, f.w, wp, hp);
             v[k][0] = w0.x; v[k][1] = w0.y; v[k][2] = w0.z; v[k][3] = w1.x; v[k][4] = w1.y; v[k][5] = w1.z;
-            v[k][6] = timestep; v[k][7] = M[i];
+            v[k][6] = timestep; v[k][7] = mk;
             v[k][8] = f.x; v[k][9] = f.y; v[k][10] = f.z; v[k][11] = f.w;
         }
 #pragma unroll
@@ -188,50 +253,26 @@ __global__ void k_assemble(const uint32_t* __restrict__ img0, const uint32_t* __
     dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// ncnn linear_coeffs for an upscale by S (power of two): fx = (dx + 0.5) / S - 0.5 is exact in fp32 here
-// (the reference computes it in double and rounds to float; all intermediates are dyadic and short).
-__device__ __forceinline__ void up_coeff(int d, int S, int in, int& s0, float& a0, float& a1) {
-    float f = ((float)d + 0.5f) * (1.0f / (float)S) - 0.5f;
-    int s = (int)floorf(f);
-    f -= (float)s;
-    if (s < 0) { s = 0; f = 0.f; }
-    if (s >= in - 1) { s = in - 2; f = 1.f; }
-    s0 = s; a0 = 1.f - f; a1 = f;
-}
-
 // flow_b is kept as [Hb][Wb][8] fp32 {x, y, z, w, mask, unused, 0, 0}.
 // After block b < 3 (flownet.param:47-58, 99-105, 152-158):
 //   u = Interp(S)(flow_b);  b == 0: F = u[0:4] * S, M = u[4];   b > 0: F = F*1 + u[0:4]*S (Eltwise), M = M + u[4]
 template <int S, bool FIRST>
 __global__ void k_flow_update(const float* __restrict__ flow, float4* __restrict__ F, float* __restrict__ M, int wp, int hp) {
-    const int Wb = wp / S, Hb = hp / S;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= wp) return;
-    int sx, sy; float a0, a1, b0, b1;
-    up_coeff(x, S, Wb, sx, a0, a1);
-    up_coeff(y, S, Hb, sy, b0, b1);
-    const float* p00 = flow + ((size_t)sy * Wb + sx) * 8;
-    const float* p10 = p00 + (size_t)Wb * 8;
-    const float4 q00 = *reinterpret_cast<const float4*>(p00), q01 = *reinterpret_cast<const float4*>(p00 + 8);
-    const float4 q10 = *reinterpret_cast<const float4*>(p10), q11 = *reinterpret_cast<const float4*>(p10 + 8);
-    const float m00 = p00[4], m01 = p00[12], m10 = p10[4], m11 = p10[12];
-#define RIFE_UP(c00, c01, c10, c11) (((c00) * a0 + (c01) * a1) * b0 + ((c10) * a0 + (c11) * a1) * b1)
-    float4 u;
-    u.x = RIFE_UP(q00.x, q01.x, q10.x, q11.x);
-    u.y = RIFE_UP(q00.y, q01.y, q10.y, q11.y);
-    u.z = RIFE_UP(q00.z, q01.z, q10.z, q11.z);
-    u.w = RIFE_UP(q00.w, q01.w, q10.w, q11.w);
-    const float um = RIFE_UP(m00, m01, m10, m11);
-#undef RIFE_UP
+    float4 u; float um;
+    flow_upsampled<S>(flow, wp, hp, x, y, u, um);
     const size_t i = (size_t)y * wp + x;
     const float s = (float)S;
     if (FIRST) {
         F[i] = make_float4(u.x * s, u.y * s, u.z * s, u.w * s);
         M[i] = um;
     } else {
-        const float4 f = F[i];
-        F[i] = make_float4(f.x * 1.0f + u.x * s, f.y * 1.0f + u.y * s, f.z * 1.0f + u.z * s, f.w * 1.0f + u.w * s);
-        M[i] = M[i] + um;
+        float4 f = F[i];
+        float m = M[i];
+        flow_accumulate<S>(u, um, f, m);
+        F[i] = f;
+        M[i] = m;
     }
 }
 

@@ -807,6 +807,7 @@ struct Ctx {
     unsigned char* P[4][2] = {};                                     // per block: trunk ping / pong as S16 tensors (conv_t64.h), zero borders
     float* flow[4] = {nullptr, nullptr, nullptr, nullptr};           // [hp/s][wp/s][8]
     float4* F = nullptr; float* M = nullptr;                         // full-resolution flow (4ch) and mask logit
+    float4* F2 = nullptr; float* M2 = nullptr;                       // the other pair of buffers for a flow update fused into the next stem (stem_fused.h UPD); F, M are swapped with them
     float4* outf = nullptr;                                          // TTA only: out0 as float, padded
     // hipGraph replay of the plain v4 schedule for launch-bound frame sizes: fixed staging buffers (d_in0 / d_in1 / d_out), the
     // timestep in device memory, one warm-up pass (lazy allocations, kernel attributes), then capture once and replay
@@ -897,6 +898,8 @@ struct rife_hip {
     bool t64 = true;
     // block-3 trunk on the row-streaming kernel (conv_rs.h) instead of conv_t64 (RIFE_HIP_RS=0 at create time: A/B, bit-equality test)
     bool rs = true;
+    // the flow updates after blocks 1 and 2 inside the fused stems of blocks 2 and 3 (stem_fused.h UPD; RIFE_HIP_FUSE_FLOW=0: three k_flow_update launches as before)
+    bool fuse_flow = true;
     int flow_div(int b) const { return v40 ? 2 * blk[b].scale : blk[b].scale; }
     // rife-v2.x schedule (IFNet + ContextNet + FusionNet)
     struct V2Block { ConvLayer stem0, stem1, conv[6], head; int c = 0, scale = 1; } fblk[4];
@@ -951,7 +954,7 @@ static int ensure_ctx_dims_impl(Ctx& c, int w, int h, int wp, int hp, const Ctx*
     c.g_warm = false; c.d_ts = nullptr;
     for (void* p : c.allocs) (void)hipFree(p);
     c.allocs.clear();
-    c.outf = nullptr;
+    c.outf = nullptr; c.F2 = nullptr; c.M2 = nullptr;
     c.w = w; c.h = h; c.wp = wp; c.hp = hp;
     const size_t P = (size_t)wp * hp;
     int rc;
@@ -994,6 +997,10 @@ static int ensure_ctx_dims_impl(Ctx& c, int w, int h, int wp, int hp, const Ctx*
     }
     if ((rc = dalloc(c, c.F, P))) return rc;
     if ((rc = dalloc(c, c.M, P))) return rc;
+    if (!want_outf && !scratch) {                                      // the plain pass (not the TTA workspaces, whose updates go through the consensus kernels)
+        if ((rc = dalloc(c, c.F2, P))) return rc;
+        if ((rc = dalloc(c, c.M2, P))) return rc;
+    }
     if (!scratch && (rc = dalloc(c, c.d_ts, 4))) return rc;
     if (want_outf && (rc = dalloc(c, c.outf, P))) return rc;
     return 0;
@@ -1005,7 +1012,7 @@ static void reset_ctx(Ctx& c) {
     if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
     for (void* p : c.allocs) (void)hipFree(p);
     c.allocs.clear();
-    c.w = c.h = c.wp = c.hp = 0; c.v2 = false; c.outf = nullptr; c.d_ts = nullptr; c.g_warm = false; for (auto& pb : c.P) pb[0] = pb[1] = nullptr;
+    c.w = c.h = c.wp = c.hp = 0; c.v2 = false; c.outf = nullptr; c.F2 = nullptr; c.M2 = nullptr; c.d_ts = nullptr; c.g_warm = false; for (auto& pb : c.P) pb[0] = pb[1] = nullptr;
 }
 static int ensure_ctx_dims(Ctx& c, int w, int h, int wp, int hp, const Ctx* scratch = nullptr, bool own_images = true, bool want_outf = false) {
     const int rc = ensure_ctx_dims_impl(c, w, h, wp, hp, scratch, own_images, want_outf);
@@ -1059,7 +1066,15 @@ static bool block_on_row_kernel(const rife_hip& E, const Ctx& c, int b) {
 
 enum { PH_STEMS = 1, PH_TRUNK = 2, PH_HEAD = 4, PH_ALL = 7 };
 // phases != PH_ALL (rife_hip_process_batch): the S16 path only; PH_TRUNK is then the caller's batched launch
-static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, const FinalArgs* fin = nullptr, const float* tsp = nullptr, int phases = PH_ALL) {
+// Can the flow update after block b - 1 be left to block b's fused stem (stem_fused.h UPD)?  Blocks 2 and 3 of rife-v4.6 only: their stems
+// visit every full-resolution pixel.
+static bool flow_update_fused_into(const rife_hip& E, const Ctx& c, int b) {
+    return E.fuse_flow && !E.v40 && (b == 2 || b == 3) && c.F2 && E.blk[b].stem0.d_wh && g_trunk_h2 && g_fuse_stem;
+}
+
+// upd_flow != null: the flow of block b - 1, whose update of F, M this block's stem applies itself (flow_update_fused_into); F, M swap with F2, M2
+static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, const FinalArgs* fin = nullptr, const float* tsp = nullptr, int phases = PH_ALL,
+                           const float* upd_flow = nullptr) {
     const rife_hip::Block& B = E.blk[b];
     hipStream_t st = c.stream;
     const int s = B.scale, Hb = c.hp / s, Wb = c.wp / s;
@@ -1082,19 +1097,29 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
             if (!fdone[dev]) {
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
                 fdone[dev] = true;
             }
         }
-        if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+        if (upd_flow) {
+            if (s > 2 || !c.F2) return fail(RIFE_HIP_EINVAL, "no fused flow update for this block");
+            fa.pend.flow = upd_flow; fa.pend.Fw = c.F2; fa.pend.Mw = c.M2;
+            if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2, 0, true>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+            else hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256, true>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);
+            std::swap(c.F, c.F2); std::swap(c.M, c.M2);
+        } else if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
         else if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
         else hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);      // 64-byte swizzled records, three workgroups per CU
         HIPCHK(hipGetLastError());
     } else {
+        if (upd_flow) return fail(RIFE_HIP_EINVAL, "fused flow update without the fused stem");
         if (b > 0 && (rc = run_assemble(E, c, b, timestep, tsp))) return rc;
         Timed t(E.prof, B.stem0.cls, B.stem0.flops_per_pixel * (Hb / 2) * (Wb / 2), st);
         if ((rc = launch_conv(B.stem0, {c.X, xin_ld, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, nullptr, st))) return rc;
     }
 after_stem0:
+    FinalArgs fin_now;                                                   // the fused tail reads the F, M that are current AFTER this block's stem
+    if (fin) { fin_now = *fin; fin_now.F = c.F; fin_now.M = c.M; fin = &fin_now; }
     const int Ht = Hb / 4, Wt = Wb / 4;
     // S16 trunk tensors: blocks 3 / 2 on the persistent LDS-DMA kernel (conv_t64.h; block 2 only when its grid fills a good part of the
     // chip), the coarse blocks 1 / 0 on the one-pass row kernel (conv_row.h).  (Blocks 1 / 0 as N-tiles of 64 output channels on the
@@ -1190,9 +1215,12 @@ static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     }
     const bool fuse_tail = !E.v40 && g_trunk_h2 && g_head_h2 && g_fuse_tail && E.blk[3].head.d_wh != nullptr;
     FinalArgs fin{c.img0, c.img1, c.F, c.M, d_out, c.w, c.h, c.wp, c.hp};
+    const float* pending = nullptr;                                      // flow whose update of F, M the next block's stem applies
     for (int b = 0; b < 4; b++) {
-        if ((rc = run_block_convs(E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr, tsp))) return rc;
-        if ((b < 3 || E.v40) && (rc = run_flow_update(E, c, b))) return rc;
+        if ((rc = run_block_convs(E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr, tsp, PH_ALL, pending))) return rc;
+        pending = nullptr;
+        if (b < 3 && flow_update_fused_into(E, c, b + 1)) pending = c.flow[b];
+        else if ((b < 3 || E.v40) && (rc = run_flow_update(E, c, b))) return rc;
     }
     if (E.v40) {
         Timed t(E.prof, "final", 0, st);
@@ -1223,6 +1251,11 @@ static int run_v4_group(const rife_hip& E, Ctx* const* cs, int G, const uint8_t*
         HIPCHK(hipGetLastError());
     }
     const bool fuse_tail = g_trunk_h2 && g_head_h2 && g_fuse_tail && E.blk[3].head.d_wh != nullptr;
+    const float* pend[4] = {nullptr, nullptr, nullptr, nullptr};         // per pair: flow whose update the next block's stem applies (run_v4)
+    auto after_block = [&](Ctx& c, int g, int b) -> int {
+        if (b < 3 && flow_update_fused_into(E, c, b + 1)) { pend[g] = c.flow[b]; return 0; }
+        return b < 3 ? run_flow_update(E, c, b) : 0;
+    };
     for (int b = 0; b < 4; b++) {
         const rife_hip::Block& B = E.blk[b];
         bool batched = G >= 2 && E.t64 && block_on_row_kernel(E, *cs[0], b) && cs[0]->P[b][0] && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS;
@@ -1231,10 +1264,12 @@ static int run_v4_group(const rife_hip& E, Ctx* const* cs, int G, const uint8_t*
             Ctx& c = *cs[g];
             FinalArgs fin{c.img0, c.img1, c.F, c.M, d_out[g], c.w, c.h, c.wp, c.hp};
             if (!batched) {
-                if ((rc = run_block_convs(E, c, b, ts[g], (b == 3 && fuse_tail) ? &fin : nullptr))) return rc;
-                if (b < 3 && (rc = run_flow_update(E, c, b))) return rc;
+                if ((rc = run_block_convs(E, c, b, ts[g], (b == 3 && fuse_tail) ? &fin : nullptr, nullptr, PH_ALL, pend[g]))) return rc;
+                pend[g] = nullptr;
+                if ((rc = after_block(c, g, b))) return rc;
             } else {
-                if ((rc = run_block_convs(E, c, b, ts[g], nullptr, nullptr, PH_STEMS))) return rc;
+                if ((rc = run_block_convs(E, c, b, ts[g], nullptr, nullptr, PH_STEMS, pend[g]))) return rc;
+                pend[g] = nullptr;
                 if (g > 0) HIPCHK(hipEventRecord(c.ev_group, c.stream));
             }
         }
@@ -1255,7 +1290,7 @@ static int run_v4_group(const rife_hip& E, Ctx* const* cs, int G, const uint8_t*
             Ctx& c = *cs[g];
             if (g > 0) HIPCHK(hipStreamWaitEvent(c.stream, cs[0]->ev_group, 0));
             if ((rc = run_block_convs(E, c, b, ts[g], nullptr, nullptr, PH_HEAD))) return rc;
-            if (b < 3 && (rc = run_flow_update(E, c, b))) return rc;
+            if ((rc = after_block(c, g, b))) return rc;
         }
     }
     for (int g = 0; g < G; g++)
@@ -2010,6 +2045,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     E->frame_pool->gpuid = gpuid;
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_RS"); E->rs = !(e && e[0] == '0'); }
+    { const char* e = getenv("RIFE_HIP_FUSE_FLOW"); E->fuse_flow = !(e && e[0] == '0'); }
     return E;
 }
 
@@ -2554,7 +2590,10 @@ int rife_hip_v4_extract_flow(const rife_hip_t* E, const uint8_t* in0, const uint
 // ---- parity taps of the gather code (round 3): the 12-channel block input and the tail of the graph, on injected flows --------------------
 // Shared prologue: frames -> padded RGBX, then for every block k < n_inject the injected blob flow{k} goes through the hot path's own
 // k_flow_update into F, M (flownet.param:47-58, 99-105, 152-158).
-static int tap_prologue(const rife_hip_t* E, Ctx& c, const uint8_t* in0, const uint8_t* in1, int w, int h, const float* const* inject, int n_inject, float*& tmp) {
+// `pending` != null: as in run_v4, the update of the LAST injected flow is left to the fused stem of the next block where the product does so
+// (flow_update_fused_into); *pending is then that flow.
+static int tap_prologue(const rife_hip_t* E, Ctx& c, const uint8_t* in0, const uint8_t* in1, int w, int h, const float* const* inject, int n_inject, float*& tmp,
+                        const float** pending = nullptr) {
     int rc;
     if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
     c.own_stream = true;
@@ -2569,6 +2608,7 @@ static int tap_prologue(const rife_hip_t* E, Ctx& c, const uint8_t* in0, const u
         const int s = E->blk[k].scale, Hb = c.hp / s, Wb = c.wp / s;
         HIPCHK(hipMemcpyAsync(tmp, inject[k], (size_t)Hb * Wb * 6 * 4, hipMemcpyHostToDevice, c.stream));
         hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(Wb, Hb), dim3(256), 0, c.stream, tmp, c.flow[k], 6, Hb, Wb, 8);
+        if (pending && k == n_inject - 1 && k < 3 && flow_update_fused_into(*E, c, k + 1)) { *pending = c.flow[k]; continue; }
         if (k < 3 && (rc = run_flow_update(*E, c, k))) return rc;
     }
     HIPCHK(hipGetLastError());
@@ -2581,19 +2621,34 @@ static int tap_prologue(const rife_hip_t* E, Ctx& c, const uint8_t* in0, const u
 //           LDS only: the kernel is run with one-hot weights (output channel 12 p + k = input channel k under tap (1 + p / 2, 1 + p % 2), bias 0,
 //           slope 1), so that its stride-2 output holds the block input's four pixel parities; the split-f16 matrix path returns hi + lo of
 //           every value, i.e. the value to 2^-22 relative;
-// what = 2: blob out0 (flownet.param:217) before the postproc, from the unfused float tail k_final_float (b ignored; n_inject = 4).
+// what = 2: blob out0 (flownet.param:217) before the postproc, from the unfused float tail k_final_float (b ignored; n_inject = 4);
+// what = 4 / 3: F, M as block b's stem reads them: after k_flow_update / written by the stem that applies the update of flow{b-1} itself.
 // out: planar CHW fp32, 12 x hp/S x wp/S (what 0, 1) or 3 x hp x wp (what 2).  n_inject must be b (what 0, 1) or 4 (what 2).
 static int rife_hip_v4_tap_impl(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, int what, int b,
                                 const float* const* inject, int n_inject, float* out) {
     int rc;
     if ((rc = process_common(E, w, h, timestep))) return rc;
     if (!E->v4 || E->v40) return fail(RIFE_HIP_EINVAL, "the gather taps exist for the rife-v4.6 graph only");
-    if (what < 0 || what > 2) return fail(RIFE_HIP_EINVAL, "bad tap");
+    if (what < 0 || what > 4) return fail(RIFE_HIP_EINVAL, "bad tap");
     if (what == 2 ? n_inject != 4 : (b < 1 || b > 3 || n_inject != b)) return fail(RIFE_HIP_EINVAL, "bad block / injection count");
     if ((rc = check_device(E->gpuid))) return rc;
     Ctx c; float* tmp = nullptr;
-    if ((rc = tap_prologue(E, c, in0, in1, w, h, inject, n_inject, tmp))) return rc;
+    const float* pending = nullptr;
+    if ((rc = tap_prologue(E, c, in0, in1, w, h, inject, n_inject, tmp, (what == 1 || what == 3) ? &pending : nullptr))) return rc;
     hipStream_t st = c.stream;
+    // what = 3 / 4: F (4 channels) and M as block b's stem finds them, [5][hp][wp]: 4 = after k_flow_update, 3 = as written by the stem that applies
+    // the last update itself (only where the product fuses it: EINVAL otherwise)
+    auto copy_fm = [&](const float4* F, const float* M) -> int {
+        hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(c.wp, c.hp), dim3(256), 0, st, reinterpret_cast<const float*>(F), tmp, 4, c.hp, c.wp, 4);
+        HIPCHK(hipGetLastError());
+        const size_t P = (size_t)c.wp * c.hp;
+        HIPCHK(hipMemcpyAsync(out, tmp, P * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(out + 4 * P, M, P * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    };
+    if (what == 4) return copy_fm(c.F, c.M);
+    if (what == 3 && !pending) return fail(RIFE_HIP_EINVAL, "the flow update before this block is not fused into its stem");
     if (what == 2) {
         float4* outf = nullptr;
         if ((rc = dalloc(c, outf, (size_t)c.wp * c.hp))) return rc;
@@ -2636,7 +2691,13 @@ static int rife_hip_v4_tap_impl(const rife_hip_t* E, const uint8_t* in0, const u
         const int nb = fa.tiles_x * ((Ho + 3) / 4);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
-        if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+        if (pending) {                                                   // every launch reads the old F, M and writes the same new ones
+            fa.pend.flow = pending; fa.pend.Fw = c.F2; fa.pend.Mw = c.M2;
+            if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2, 0, true>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+            else hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256, true>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);
+            if (what == 3) { HIPCHK(hipGetLastError()); return copy_fm(c.F2, c.M2); }
+        } else if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
         else if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
         else hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);
         HIPCHK(hipGetLastError());
@@ -2669,12 +2730,15 @@ static int rife_hip_v4_process_injected_impl(const rife_hip_t* E, const uint8_t*
     if (n_inject < 0 || n_inject > 3) return fail(RIFE_HIP_EINVAL, "bad injection count");
     if ((rc = check_device(E->gpuid))) return rc;
     Ctx c; float* tmp = nullptr;
-    if ((rc = tap_prologue(E, c, in0, in1, w, h, inject, n_inject, tmp))) return rc;
+    const float* pending = nullptr;
+    if ((rc = tap_prologue(E, c, in0, in1, w, h, inject, n_inject, tmp, &pending))) return rc;
     const bool fuse_tail = g_trunk_h2 && g_head_h2 && g_fuse_tail && E->blk[3].head.d_wh != nullptr;
     FinalArgs fin{c.img0, c.img1, c.F, c.M, c.d_out, c.w, c.h, c.wp, c.hp};
     for (int b = n_inject; b < 4; b++) {
-        if ((rc = run_block_convs(*E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr))) return rc;
-        if (b < 3 && (rc = run_flow_update(*E, c, b))) return rc;
+        if ((rc = run_block_convs(*E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr, nullptr, PH_ALL, pending))) return rc;
+        pending = nullptr;
+        if (b < 3 && flow_update_fused_into(*E, c, b + 1)) pending = c.flow[b];
+        else if (b < 3 && (rc = run_flow_update(*E, c, b))) return rc;
     }
     if (!fuse_tail) hipLaunchKernelGGL(k_final, grid2d(c.w, c.h), dim3(256), 0, c.stream, c.img0, c.img1, c.F, c.M, c.flow[3], c.d_out, c.w, c.h, c.wp, c.hp);
     HIPCHK(hipGetLastError());

@@ -23,6 +23,7 @@ struct StemFusedArgs {
     int wp, hp;            // padded full resolution
     int Ho, Wo, out_ld, Cout, tiles_x;
     float* dbg = nullptr;  // bench builds (ABL & 1024): the gathered block-input pixel of every thread, [workgroup][512][12]
+    FlowPending pend;      // UPD kernels: the flow update of the previous block, applied while gathering (elementwise.h); F, M are then the OLD tensors
 };
 
 // LDS pixel record: 32 B hi + 32 B lo (+ 16 B pad: 80-byte records are conflict-free for the 16-byte staging writes and 2-way for
@@ -34,8 +35,12 @@ constexpr int stemf_lds_bytes() { return (9 * 65 + 1) * stemf_pixb<ABL>() + 9 * 
 // ABL (bench only): 4096 = round-2 staging of the second halo pixel under a lane-divergent branch; 1 = skip MFMA + epilogue, 2 = second halo pixel in a second round, 16 = skip stores, 32 = skip MFMAs, 64 = direct-store epilogue, 128 = 64-byte LDS records
 // ABL 256: 64-byte records with the 16-byte quarters XOR-swizzled by pixel index (quarter q of pixel P at position q ^ ((P >> 2) & 3): 2-way on the
 // stride-2 operand reads like the padded records, conflict-free staging writes) -> 46.6 KB for NS = 1: three workgroups (24 waves) per CU
-template <int S, int NS, int ABL = 0>
+// UPD: k_flow_update<2 S> of the block before (flownet.param:99-105, 152-158) happens here: the kernel visits every full-resolution pixel (S <= 2)
+// anyway, so F, M make one round trip less through HBM per block and the launch disappears; halo pixels shared by tiles are written twice with
+// the same value, into the other F, M buffer.
+template <int S, int NS, int ABL = 0, bool UPD = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((ABL & 256) ? 6 : 4, (ABL & 256) ? 6 : 4))) void stem0_fused_kernel(StemFusedArgs a) {
+    static_assert(!UPD || S <= 2, "the scale-4 stem samples a quarter of the full-resolution pixels");
     constexpr int IH = 9, IW = 65, PIXB = stemf_pixb<ABL>(), NT = NS * 32;
     constexpr int NPIX = IH * IW;
     constexpr int W_16 = 9 * 2 * NT;
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((ABL & 256)
         const int py_ = p_ / IW, px_ = p_ - py_ * IW;                                                             \
         const int by_ = iy0 + py_, bx_ = ix0 + px_;                                                               \
         const bool in_ = by_ >= 0 && by_ < Hb && bx_ >= 0 && bx_ < Wb;                                            \
-        assemble_pixel<S>(a.img0, a.img1, timestep, a.F, a.M, a.wp, a.hp, min(max(bx_, 0), Wb - 1), min(max(by_, 0), Hb - 1), O); \
+        assemble_pixel<S, UPD>(a.img0, a.img1, timestep, a.F, a.M, a.wp, a.hp, min(max(bx_, 0), Wb - 1), min(max(by_, 0), Hb - 1), O, a.pend); \
         _Pragma("unroll") for (int c = 0; c < 12; c++) O[c] = in_ ? O[c] : 0.f;                                   \
     }
 #define STEM_STAGE(P, O)                                                                                          \

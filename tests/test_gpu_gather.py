@@ -81,6 +81,23 @@ def test_block_input_bit_exact_and_through_the_fused_stem(engines, w, h, seed, b
     assert err.max() <= 0, "fused stem kernel of block %d: worst excess %g at %s" % (b, float(err.max()), np.unravel_index(np.argmax(err), err.shape))
 
 
+@pytest.mark.parametrize("w,h,seed", SIZES)
+@pytest.mark.parametrize("b", [2, 3])
+def test_flow_update_inside_the_stem_writes_the_same_F_M(engines, w, h, seed, b):
+    """Blocks 2 and 3: the product's stem kernel applies the flow update of the block before it while it gathers (stem_fused.h UPD,
+    flownet.param:99-105, 152-158) and writes F, M for the later stages.  what = 1 above already ran that kernel (its block input is the
+    oracle's); here the tensors it WRITES against the flow-update kernel's, bit for bit - every full-resolution pixel, borders included."""
+    g, o, names = engines
+    a, c = gen_frames.noise_pair(w, h, seed) if seed % 2 else gen_frames.smooth_pair(w, h, seed)
+    inj = injected_flows(w, h, 300 + seed, b)
+    want = g.v4_tap(a, c, 0.5, 4, b, inj)
+    got = g.v4_tap(a, c, 0.5, 3, b, inj)
+    assert np.array_equal(got, want), "%d of %d floats differ" % (int((got != want).sum()), want.size)
+    if b == 3:      # scale 1: channels 7..11 of the oracle's block input ARE M and F
+        blob = o.v4_extract(a, c, 0.5, names[2], flows=inj)
+        assert np.array_equal(got[4], blob[7]) and np.array_equal(got[:4], blob[8:12])
+
+
 def test_block3_input_at_4k(engines):
     """The product's block-3 stem (three workgroups per CU, swizzled 64-byte records) at the north-star size, F1 frames tiled 6 x 6."""
     g, o, names = engines
@@ -108,3 +125,18 @@ def test_tail_on_injected_flows(engines, w, h, seed):
     got8 = g.v4_process_injected(a, c, 0.45, inj[:3]).astype(np.int32)
     dd = np.abs(got8 - want8)
     assert dd.max() <= 1 and (dd > 0).mean() < 1e-3, "%d of %d bytes differ, max %d" % (int((dd > 0).sum()), dd.size, int(dd.max()))
+
+
+@pytest.mark.parametrize("w,h", [(256, 192), (640, 360), (1920, 1080)])
+def test_pass_with_fused_flow_updates_is_bit_identical_to_three_update_launches(modeldirs, w, h, monkeypatch):
+    """The plain pass with the updates after blocks 1 and 2 inside the stems of blocks 2 and 3 (default) against the same pass with
+    RIFE_HIP_FUSE_FLOW=0 (k_flow_update after every block): same arithmetic on the same values, so the frames must be the same bytes."""
+    a, c = gen_frames.smooth_pair(w, h, 11) if w < 1000 else gen_frames.tiled_real_pair(3)
+    monkeypatch.setenv("RIFE_HIP_FUSE_FLOW", "0")
+    g0 = amd.RIFE(0, rife_v4=True); g0.load(modeldirs["rife-v4.6"])
+    monkeypatch.delenv("RIFE_HIP_FUSE_FLOW")
+    g1 = amd.RIFE(0, rife_v4=True); g1.load(modeldirs["rife-v4.6"])
+    for t in (0.5, 0.2):
+        x0, x1 = g0.process(a, c, t), g1.process(a, c, t)
+        assert np.array_equal(x0, x1), "%d bytes differ" % int((x0 != x1).sum())
+    assert np.array_equal(g1.process(a, c, 0.5), g1.process(a, c, 0.5))      # F / F2 swap back: the second call starts from the same buffers

@@ -197,20 +197,20 @@ def test_malformed_param_files_are_refused_not_fatal(modeldirs, tmp_path):
 
 
 def test_pmc_tables_reads_the_committed_summaries(tmp_path):
-    """tools/pmc_tables.py on the per-kernel PMC summaries kept in profiles/r2: the derived files are complete and the dominant
+    """tools/pmc_tables.py on the per-kernel PMC summaries kept in profiles/r3: the derived files are complete and the dominant
     kernel's traffic is what bench.py reports as roofline.traffic."""
     import json, shutil
     from tools import pmc_tables
     src = tmp_path / "src"; src.mkdir()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for short, first in pmc_tables.PASSES.items():
-        shutil.copy(os.path.join(root, "profiles", "r2", "pmc_all_kernels_4k_%s.txt" % short), src / ("pmc_%s_all.txt" % first))
+        shutil.copy(os.path.join(root, "profiles", "r3", "pmc_all_kernels_4k_%s.txt" % short), src / ("pmc_%s_all.txt" % first))
     dst = tmp_path / "dst"
     pmc_tables.main(str(src), str(dst))
     j = json.load(open(dst / "pmc_4k.json"))
-    committed = json.load(open(os.path.join(root, "profiles", "r2", "pmc_4k.json")))
+    committed = json.load(open(os.path.join(root, "profiles", "r3", "pmc_4k.json")))
     assert j["hbm_bytes_per_launch"] == committed["hbm_bytes_per_launch"] > 2.6e8       # >= the 267.5 MB the layer stores
     table = open(dst / "bandwidth_kernels_4k.txt").read()
-    assert "conv_t64_kernel<3, 2>" in table and "k_flow_update" in table
+    assert "conv_rs_kernel" in table and "k_flow_update" in table
     derived = [l for l in open(dst / "pmc_trunk_kernels_4k.txt") if "matrix pipe busy" in l]
     assert len(derived) == 2

@@ -1,10 +1,9 @@
 #!/bin/bash
-# build container: copy what tools/profile_round.sh <tag> and tools/r2_final.sh left under gpurun_out/ into profiles/<tag>/
-TAG=${1:-r2}; SRC=gpurun_out/profile_$TAG; DST=profiles/$TAG
+# build container: copy what tools/profile_round.sh <tag> left under gpurun_out/profile_<tag>/ into profiles/<tag>/
+TAG=${1:-r3}; SRC=gpurun_out/profile_$TAG; DST=profiles/$TAG
 mkdir -p $DST
-cp $SRC/kernel_stats_4k.csv $SRC/kernel_stats_1080p.csv $SRC/t64_bench.txt $SRC/host_path.txt $DST/
+for f in kernel_stats_4k.csv kernel_stats_1080p.csv rs_bench.txt t64_bench.txt host_path.txt pytest_gpu.txt; do [ -f $SRC/$f ] && cp $SRC/$f $DST/; done
 cp $SRC/tables/* $DST/
 sed -i "s#\"source\": \"[^\"]*tables/#\"source\": \"$DST/#" $DST/pmc_4k.json
-for wl in 4k 1080p v23-1080p 4k-tta; do cp gpurun_out/final/bench_$wl.json $DST/bench_${wl//-/_}.json; done
-cp gpurun_out/final/pytest_gpu.txt $DST/pytest_gpu.txt
+for wl in 4k 1080p v23-1080p 4k-tta; do [ -f $SRC/bench_$wl.json ] && cp $SRC/bench_$wl.json $DST/bench_${wl//-/_}.json; done
 ls $DST

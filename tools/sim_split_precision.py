@@ -39,6 +39,18 @@ def trunk_conv(x, w, b, stride=1, padding=0):
     if s == "hi":
         return REAL_CONV(hi, w, b, stride=stride, padding=padding)
     lo = x - hi
+    if s == "rs_fp8":
+        # conv_rs_kernel's fp8 form (block 3 only, 64 channels): the tensor between the layers is {hi f16, e4m3(lo * 2^9)}, so the skip
+        # connection sees hi + lo_q too; the lo product runs on e4m3(w * 2^kw), kw = the largest power of two that keeps max |w| <= 448
+        if w.shape[0] != 64:
+            return REAL_CONV(x, w, b, stride=stride, padding=padding)
+        kw = int(np.floor(np.log2(448.0 / max(float(w.abs().max()), 1e-30))))
+        lo_q = q8(lo, torch.float8_e4m3fn, 2.0 ** 9)
+        w_q = w if os.environ.get("RS_W_EXACT") else q8(w, torch.float8_e4m3fn, 2.0 ** kw)
+        y = REAL_CONV(hi, w, b, stride=stride, padding=padding) + REAL_CONV(lo_q, w_q, None, stride=stride, padding=padding)
+        if not os.environ.get("RS_SKIP_EXACT"):
+            x.copy_(hi + lo_q)
+        return y
     if s == "gpu_fp8":
         # what conv_h2c does: f16 weights carry 2^k (k <= 15 so that the identity tap 2^k stays finite), lo * 2^9 and w * 2^(k-9) go
         # through e4m3, one shared accumulator; the folded skip tap sees hi + lo_q, so the residual stream is rounded too
@@ -80,14 +92,15 @@ def main():
     w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (640, 360)
     d = gen_models.ensure(None, "rife-v4.6")
     net = torch_graph.TorchNet(os.path.join(d, "flownet.param"), os.path.join(d, "flownet.bin"))
-    pairs = {"F2 smooth": gen_frames.smooth_pair(w, h, 1000), "F3 noise": gen_frames.noise_pair(w, h, 7)}
+    only = os.environ.get("ONLY")
+    pairs = {"F3 noise": gen_frames.noise_pair(w, h, 7)} if only == "F3" else {"F2 smooth": gen_frames.smooth_pair(w, h, 1000), "F3 noise": gen_frames.noise_pair(w, h, 7)}
     try:
         pairs["F1 real"] = gen_frames.real_pair(w, h)
     except Exception:
         pass
     schemes = os.environ.get("SCHEMES", "hi,hi+lo_f16,hi+lo_e4m3_w8,gpu_fp8").split(",")
     for name, (a, b) in pairs.items():
-        for t in (0.5, 0.25):
+        for t in ((0.5,) if only else (0.5, 0.25)):
             SCHEME["name"] = "exact"
             f_ref, u_ref = run(net, a, b, t)
             for s in schemes:
