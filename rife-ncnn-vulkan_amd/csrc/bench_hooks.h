@@ -535,7 +535,7 @@ int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms
 }
 
 // probe of the block-scaled fp8 matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4, both operands e4m3): raw per-lane operand dwords in, the
-// wave's 16 accumulator registers per lane out; the scale dwords go through VGPRs (tools/mx_probe.py pins the operand layout against numpy)
+// wave's 16 accumulator registers per lane out; the scale dwords go through VGPRs (tools/probes/mx_probe.py pins the operand layout against numpy)
 __global__ void k_probe_mx(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t sa, uint32_t sb, float* __restrict__ d) {
     const int lane = threadIdx.x;
     i32x8 av, bv;
@@ -573,7 +573,7 @@ __global__ void k_lds_scrub(uint32_t pattern, int ndw, uint32_t* sink) {
     if (pattern == 0x12345678u && l[(threadIdx.x * 7) % ndw] != pattern) sink[0] = 1;      // keeps the stores alive
 }
 
-// tools/stem_bisect.py: path of a code object whose stem0_fused_kernel<4, 2, 0> / <2, 2, 0> rife_hip_probe_stem_det launches instead of the built-in ones
+// tools/probes/stem_bisect.py: path of a code object whose stem0_fused_kernel<4, 2, 0> / <2, 2, 0> rife_hip_probe_stem_det launches instead of the built-in ones
 static std::string g_stem_hsaco;
 static long long g_probe_extra[3] = {0, 0, 0};      // launch 0 of the external kernel vs the built-in one: differing floats, NaNs
 int rife_hip_probe_set_stem_hsaco(const char* path) { g_stem_hsaco = path ? path : ""; return 0; }
@@ -624,7 +624,7 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
         return 0;
     };
     if (!g_stem_hsaco.empty() && (S == 4 || S == 2) && (ABL == 0 || ABL == 4096)) {
-        // the kernel from an externally assembled code object (tools/stem_bisect.py: the compiler's assembly with wait states inserted)
+        // the kernel from an externally assembled code object (tools/probes/stem_bisect.py: the compiler's assembly with wait states inserted)
         hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
         HIPCHK(hipModuleLoad(&mod, g_stem_hsaco.c_str()));
         const std::string fname = std::string("_ZN4rife18stem0_fused_kernelILi") + (S == 4 ? "4" : "2") + "ELi2ELi" + (ABL ? "4096" : "0") + "EEEvNS_13StemFusedArgsE";
@@ -674,9 +674,6 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
         case 2: rc = run(stem0_fused_kernel<2, 2, 0>, stemf_lds_bytes<2>()); break;
         case 1 + 16 * 256: rc = run(stem0_fused_kernel<1, 1, 256>, (stemf_lds_bytes<1, 256>())); break;
         case 1: rc = run(stem0_fused_kernel<1, 1, 0>, stemf_lds_bytes<1>()); break;
-        case 4 + 16 * 2: rc = run(stem0_fused_kernel<4, 2, 2>, stemf_lds_bytes<2>()); break;
-        case 4 + 16 * 64: rc = run(stem0_fused_kernel<4, 2, 64>, stemf_lds_bytes<2>()); break;
-        case 4 + 16 * 66: rc = run(stem0_fused_kernel<4, 2, 66>, stemf_lds_bytes<2>()); break;
         case 4 + 16 * 1024: rc = run(stem0_fused_kernel<4, 2, 1024>, stemf_lds_bytes<2>()); break;
         case 4 + 16 * 4096: rc = run(stem0_fused_kernel<4, 2, 4096>, stemf_lds_bytes<2>()); break;
         case 2 + 16 * 4096: rc = run(stem0_fused_kernel<2, 2, 4096>, stemf_lds_bytes<2>()); break;
@@ -746,12 +743,8 @@ int rife_hip_bench_stemf(int gpuid, int wp, int hp, int variant, int iters, floa
     switch (variant) {
         case 0: rc = run(stem0_fused_kernel<1, 1, 0>); break;
         case 1: rc = run(stem0_fused_kernel<1, 1, 1>); break;
-        case 2: rc = run(stem0_fused_kernel<1, 1, 2>); break;
-        case 3: rc = run(stem0_fused_kernel<1, 1, 3>); break;
         case 16: rc = run(stem0_fused_kernel<1, 1, 16>); break;
         case 32: rc = run(stem0_fused_kernel<1, 1, 32>); break;
-        case 64: rc = run(stem0_fused_kernel<1, 1, 64>); break;
-        case 128: rc = run(stem0_fused_kernel<1, 1, 128>); break;
         default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
     }
     (void)hipFree(i0); (void)hipFree(i1); (void)hipFree(F); (void)hipFree(M); (void)hipFree(out); (void)hipFree(bias); (void)hipFree(wh);

@@ -28,6 +28,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Bench-only ablation switches: template bits that strip or alter a phase of a kernel for timing experiments (tools/*_bench.py, through
+// librife_hip_bench.so = these sources + bench_hooks.h with -DRIFE_HIP_BENCH_BUILD).  In the product build the test is the constant false
+// whatever the template argument, so no product kernel carries an ablation path.
+#ifdef RIFE_HIP_BENCH_BUILD
+#define RIFE_ABL(bits) ((bits) != 0)
+#else
+#define RIFE_ABL(bits) (false)
+#endif
+
 namespace rife {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -362,9 +371,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         float* oth = lds + ((ch & 1) ^ 1) * BUF;
         RIFE8_TAPS(cur, 0, 4)
         if (ch + 1 < a.nchunks) RIFE8_WRITE(oth)            // chunk ch+1: loaded during the previous chunk
-        if (!(TAG & 512) && ch + 2 < a.nchunks) RIFE8_ISSUE(ch + 2)
+        if (!RIFE_ABL(TAG & 512) && ch + 2 < a.nchunks) RIFE8_ISSUE(ch + 2)
         RIFE8_TAPS(cur, 4, 9)
-        if (!(TAG & 1024)) __syncthreads();                 // chunk ch+1 visible; everyone is done with `cur`
+        if (!RIFE_ABL(TAG & 1024)) __syncthreads();                 // chunk ch+1 visible; everyone is done with `cur`
     }
 #undef RIFE8_ISSUE
 #undef RIFE8_WRITE
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k];
-            if (TAG & 256) { if (v[0] == 123.456f) a.out[0] = v[1]; }   // ablation: keep the value alive, store (almost) never
+            if RIFE_ABL(TAG & 256) { if (v[0] == 123.456f) a.out[0] = v[1]; }   // ablation: keep the value alive, store (almost) never
             else if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
         }
     }
@@ -613,13 +622,13 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    // bench-only (TAG & 32768): wave 0 of every workgroup records the shader clock at its phase boundaries into a.partial
+    // bench-only RIFE_ABL(TAG & 32768): wave 0 of every workgroup records the shader clock at its phase boundaries into a.partial
     // ([workgroup][16] 64-bit slots: 0 start, 8 index math done, 9 first loads issued, 10 first chunk in LDS, 1 prologue barrier passed,
     // 2..5 one per chunk, 6 epilogue barrier passed, 7 tile in LDS, 13 stores issued, 14 stores done, 15 HW_ID | XCC_ID << 32)
 #define H2B_STAMP(SLOT)                                                                                      \
-    if ((TAG & 32768) && tid == 0) reinterpret_cast<long long*>(a.partial)[(size_t)blockIdx.x * 16 + (SLOT)] = (long long)__builtin_readcyclecounter();
+    if (RIFE_ABL(TAG & 32768) && tid == 0) reinterpret_cast<long long*>(a.partial)[(size_t)blockIdx.x * 16 + (SLOT)] = (long long)__builtin_readcyclecounter();
     H2B_STAMP(0)
-    if ((TAG & 32768) && tid == 0)
+    if (RIFE_ABL(TAG & 32768) && tid == 0)
         reinterpret_cast<long long*>(a.partial)[(size_t)blockIdx.x * 16 + 15] =
             (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     const int half = lane >> 5, li = lane & 31;
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
     H2B_WRITE_W()
     H2B_STAMP(10)
     if (nch > 1) { H2B_ISSUE_W(1) }
-    if (!(TAG & 512) && nch > 2) { H2B_ISSUE_IN(2, rinA) }
+    if (!RIFE_ABL(TAG & 512) && nch > 2) { H2B_ISSUE_IN(2, rinA) }
     __syncthreads();
     H2B_STAMP(1)
     // one chunk: RIN is the register set that holds chunk CH + 1 on entry and receives chunk CH + 3
@@ -728,14 +737,14 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
         unsigned char* cur = ldsb + ((CH) & 1) * INB;                                                       \
         unsigned char* oth = ldsb + (((CH) & 1) ^ 1) * INB;                                                 \
         H2B_TAPS(cur, 0, NTAPS / 2)                                                                         \
-        if (!(TAG & 2048) && (CH) + 1 < nch) { H2B_WRITE_IN(oth, RIN) }                                     \
-        if (!(TAG & 512) && (CH) + 3 < nch) { H2B_ISSUE_IN((CH) + 3, RIN) }                                 \
+        if (!RIFE_ABL(TAG & 2048) && (CH) + 1 < nch) { H2B_WRITE_IN(oth, RIN) }                                     \
+        if (!RIFE_ABL(TAG & 512) && (CH) + 3 < nch) { H2B_ISSUE_IN((CH) + 3, RIN) }                                 \
         H2B_TAPS(cur, NTAPS / 2, NTAPS)                                                                     \
         if ((CH) + 1 < nch) {                                                                               \
-            if (!(TAG & 1024)) __syncthreads();                 /* everyone is done with the weight slab of chunk CH */ \
-            if (!(TAG & 2048)) { H2B_WRITE_W() }                                                            \
-            if (!(TAG & 512) && (CH) + 2 < nch) { H2B_ISSUE_W((CH) + 2) }                                   \
-            if (!(TAG & 1024)) __syncthreads();                                                             \
+            if (!RIFE_ABL(TAG & 1024)) __syncthreads();                 /* everyone is done with the weight slab of chunk CH */ \
+            if (!RIFE_ABL(TAG & 2048)) { H2B_WRITE_W() }                                                            \
+            if (!RIFE_ABL(TAG & 512) && (CH) + 2 < nch) { H2B_ISSUE_W((CH) + 2) }                                   \
+            if (!RIFE_ABL(TAG & 1024)) __syncthreads();                                                             \
         }                                                                                                   \
         if ((CH) < 11) { H2B_STAMP(2 + (CH)) }                                                              \
     }
@@ -756,7 +765,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
     const int oy = oy0 + wv, ox = ox0 + li;
     const bool pok = oy < a.Ho && ox < a.Wo;
     constexpr int ROWF = NT + 4;                               // floats per pixel row of the transpose tile (odd number of 16-B slots)
-    const bool via_lds = a.nsplit == 1 && !(TAG & 256) && a.out_ld == NT && a.Cout == NT && a.nz == 1;
+    const bool via_lds = a.nsplit == 1 && !RIFE_ABL(TAG & 256) && a.out_ld == NT && a.Cout == NT && a.nz == 1;
     if (via_lds) __syncthreads();                              // every wave is done reading the staging buffers
     H2B_STAMP(6)
     float* const tl = reinterpret_cast<float*>(ldsb) + wv * 32 * ROWF;
@@ -780,7 +789,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k];
             if (via_lds) *reinterpret_cast<f32x4*>(tl + li * ROWF + n * 32 + 8 * q + 4 * half) = v;
-            else if (TAG & 256) { if (v[0] == 123.456f) a.out[0] = v[1]; }   // ablation: keep alive, (almost) never store
+            else if RIFE_ABL(TAG & 256) { if (v[0] == 123.456f) a.out[0] = v[1]; }   // ablation: keep alive, (almost) never store
             else if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
         }
     }
@@ -798,7 +807,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
         }
     }
     H2B_STAMP(13)
-    if (TAG & 32768) { __builtin_amdgcn_s_waitcnt(0); H2B_STAMP(14) }
+    if RIFE_ABL(TAG & 32768) { __builtin_amdgcn_s_waitcnt(0); H2B_STAMP(14) }
 #undef H2B_STAMP
 }
 

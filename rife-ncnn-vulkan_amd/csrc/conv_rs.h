@@ -4,30 +4,33 @@
 // and matrix phases added up (22 + 27 + 43 us = the 82 - 88 us of a 4K launch) instead of overlapping, because every wave both fed the matrix
 // pipe and issued the tile's LDS-DMA pieces and stores, and a wave that waits for a slot in the CU's memory queue issues no MFMAs.
 //
-// One workgroup per CU, 8 waves, no two of which do the same job:
+// One workgroup per CU, 8 waves, three jobs:
 //   * waves 0-3, "consumers" (one per SIMD): wave k owns output block n = k & 1 (32 channels) of output row (k >> 1) of the current row
 //     pair.  Its 36 weight fragments ([K chunk 4][tap 9] x 16 bytes per lane = 144 VGPRs) are loaded ONCE per launch and stay in registers:
 //     no weight ever passes through LDS (conv_t64 re-streamed the 72 KB of weights per 8 x 32 tile: 1.2 GB of L2 -> LDS traffic per 4K
-//     launch, 4 x the activations).  A consumer only issues ds_read_b128 (pixel fragments) and MFMAs, plus the epilogue of the PREVIOUS
-//     row (bias, LeakyReLU, split into {hi, lo}; VALU work the scheduler spreads between this row's MFMAs) whose result goes to an LDS
-//     staging buffer.  It never touches vector memory after the prologue.
-//   * waves 4-5, "loaders": LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, no registers) of the halo ROWS two steps ahead into a
+//     launch, 4 x the activations).  A consumer issues ds_read_b128 (pixel fragments, three MFMA pairs ahead of their use - across the step
+//     boundary too) and MFMAs in two accumulation chains (hi products, lo products), and writes the raw fp32 sums of its row to an LDS
+//     staging buffer.  It never touches vector memory after the prologue and does no epilogue arithmetic.
+//   * waves 4-5, "loaders": LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, no registers) of the halo ROWS three steps ahead into a
 //     ring of 12 row slots.  A workgroup walks DOWN (or up) a 32-column strip, so every input row is loaded once per strip instead of once
 //     per 8-row tile: 34 / 32 of the tensor instead of 10 x 34 / (8 x 32) = 1.33 x.
-//   * waves 6-7, "storers": copy the staged output rows of two steps ago to global memory (1 KiB contiguous per instruction).
+//   * waves 6-7, "storers": bias, LeakyReLU and the {hi, lo} split of the row pair staged two steps ago, then 1 KiB contiguous per store.
 //   Loads and stores are issued by different waves because vmcnt only retires in order within one kind of access: the loaders' counted
-//   waits (vmcnt(9) / vmcnt(18): the rows of the step after next may still be in flight) would be meaningless with stores in the same queue.
+//   waits (vmcnt(9) / vmcnt(18): the rows of the steps after next may still be in flight) would be meaningless with stores in the same queue.
 // A step = one row pair of one strip = 76 MFMAs per consumer (2,432 cycles of its SIMD's matrix pipe) and ends with ONE s_barrier:
-//   iteration it:  consumers  MFMAs of step it, epilogue of step it - 1 -> staging[(it - 1) & 1]
-//                  loaders    rows of step it + 2 -> ring; wait for the rows of step it + 1
-//                  storers    staging[it & 1] (= step it - 2) -> global
+//   iteration it:  consumers  MFMAs of step it -> staging[it % 3]; first fragments of step it + 1
+//                  loaders    rows of step it + 3 -> ring; wait for the rows of step it + 2
+//                  storers    staging[(it - 2) % 3] -> epilogue -> global
 // Work split: the tiles_x x ceil(H / 2) (strip, row pair) units in strip-major order are cut into gridDim.x equal contiguous ranges (4K: 8,160
 // units over 256 workgroups = 31 or 32 steps each); a range that crosses into the next strip restarts the ring there (4 fresh rows).
 // Tensors are the S16 tensors of conv_t64.h ({hi, lo} f16 planes per 16-channel chunk, one pixel of zero border), the weight image is
-// conv_t64's (pack_t64_image), products / accumulation order / epilogue are those of conv_t64_kernel: results are bit-identical to it
-// (tests/test_gpu_t64.py, tools/rs_bench.py).
+// conv_t64's (pack_t64_image), the products are conv_t64_kernel's.  The sums differ from conv_t64's in the last bits (two chains added at the
+// end instead of one): tests/test_gpu_t64.py and tools/rs_bench.py hold the two kernels together (<= 1 LSB on the u8 frame, < 1e-3 of the
+// bytes differ, block-3 flows to 1e-4) and check that conv_rs itself is run-to-run identical.
 // LDS: ring 12 x 8,704 B (row slot = [chunk 4][hi | lo][34 px][32 B], halves swapped where bit 3 of the column is set: conflict-free
-// ds_read_b128, applied to the DMA source addresses) + staging 2 x 2 rows x 8 KiB + bias / slopes = 137,728 B.
+// ds_read_b128, applied to the DMA source addresses) + staging 3 x 2 rows x 8 KiB of fp32 sums + bias / slopes = 154,112 B.
+// Measured (MI355X, 4K, same-call A/B, profiles/r3/rs_bench.txt): 73.5 - 76 us per launch in the pass against 81.6 - 82.9 for conv_t64; matrix work
+// alone 45.8 us (2.22 GHz), memory alone 49.9 us, both 60.1 us at the 1.88 GHz the chip settles at under this load: the phases overlap.
 #pragma once
 #include <type_traits>
 #include "conv_t64.h"
@@ -58,7 +61,7 @@ struct RsArgs {
     int npairs;                  // row pairs per strip = ceil(H / 2)
     int nunits;                  // tiles_x * npairs
     int descend;                 // 1: every workgroup walks its range last unit first, rows bottom-up (consecutive layers alternate)
-    long long* stamps = nullptr; // bench builds (TAG & RS_CLK): [workgroup][4] = shader cycles of the workgroup's life, start, end (100 MHz counter)
+    long long* stamps = nullptr; // bench builds RIFE_ABL(TAG & RS_CLK): [workgroup][4] = shader cycles of the workgroup's life, start, end (100 MHz counter)
 };
 // bench-only ablation bits of TAG (timing experiments; results are garbage).  The product instantiates TAG = 0.
 enum { RS_NOSTORE = 0x100, RS_NODMA = 0x200, RS_NOMATH = 0x400, RS_CLK = 0x40000, RS_PRIO = 0x2000, RS_NTLOAD = 0x4000, RS_NTSTORE = 0x8000 };
@@ -79,7 +82,7 @@ struct RsCursor {
 template <int TAG>
 __device__ __forceinline__ void rs_dma16(const unsigned char* base, unsigned voff, unsigned dst) {
     unsigned keep;
-    if (TAG & RS_NTLOAD)
+    if RIFE_ABL(TAG & RS_NTLOAD)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
     else
@@ -168,7 +171,7 @@ __device__ __forceinline__ void rs_consumer(const RsArgs& a, unsigned char* cons
             fl[st] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG) + RS_SEG);
         };
         f32x16 accH, accL;
-        if (!(TAG & RS_NOMATH)) {
+        if (!RIFE_ABL(TAG & RS_NOMATH)) {
             for_each_slot<0, RS_NPAIR>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 constexpr RsPairDesc d = rs_pair(N, m);
@@ -208,7 +211,7 @@ __device__ __forceinline__ void rs_consumer(const RsArgs& a, unsigned char* cons
     };
     RS_SYNC_LGKM();                                                      // ring rows of steps 0 and 1 landed (loaders), bias in LDS
     step_addresses(true);
-    if (!(TAG & RS_NOMATH)) for_each_slot<0, RS_PF>([&](auto mc) {       // first fragments of step 0 (parity 0)
+    if (!RIFE_ABL(TAG & RS_NOMATH)) for_each_slot<0, RS_PF>([&](auto mc) {       // first fragments of step 0 (parity 0)
         constexpr int m = decltype(mc)::value;
         constexpr RsPairDesc d = rs_pair(N, m);
         fh[m % NF] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG));
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave role (wave-uniform by construction)
     long long clk0 = 0, rt0 = 0;
-    if (TAG & RS_CLK) { clk0 = (long long)__builtin_readcyclecounter(); rt0 = (long long)__builtin_amdgcn_s_memrealtime(); }
+    if RIFE_ABL(TAG & RS_CLK) { clk0 = (long long)__builtin_readcyclecounter(); rt0 = (long long)__builtin_amdgcn_s_memrealtime(); }
 
     const int nwg = gridDim.x, b = blockIdx.x;
     const int u0 = (int)((long long)a.nunits * b / nwg), u1 = (int)((long long)a.nunits * (b + 1) / nwg);
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     if (wv < 4) {
         // ------------------------------------------------------------------------------------------------ consumers
-        if (TAG & RS_PRIO) __builtin_amdgcn_s_setprio(2);             // A/B only: raised priority of the matrix waves measured 3 - 5 % SLOWER (their loader / storer starve, the barrier waits)
+        if RIFE_ABL(TAG & RS_PRIO) __builtin_amdgcn_s_setprio(2);             // A/B only: raised priority of the matrix waves measured 3 - 5 % SLOWER (their loader / storer starve, the barrier waits)
         if (wv == 0 && lane < 32) reinterpret_cast<f32x4*>(ldsb + RS_LDS_BS)[lane] = reinterpret_cast<const f32x4*>(a.img + 4 * t64_wch(2))[lane];
         if (wv & 1) rs_consumer<1, TAG>(a, ldsb, wv >> 1, lane, S, ufirst);
         else rs_consumer<0, TAG>(a, ldsb, wv >> 1, lane, S, ufirst);
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int i = j; i < nnew; i += 2) {
                 const int prow = a.descend ? y + nnew - 1 - i : y + 4 - nnew + i;       // padded row index (pixel row prow - 1)
                 int sl = sq + i; if (sl >= RS_NR) sl -= RS_NR;
-                if (!(TAG & RS_NODMA)) {
+                if (!RIFE_ABL(TAG & RS_NODMA)) {
                     const unsigned rowoff = (unsigned)(prow * a.pitch + x0) * 32u;
                     const unsigned dst = (unsigned)(RS_LDS_RING + sl * RS_ROWB);
 #pragma unroll
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
             sq += nnew; if (sq >= RS_NR) sq -= RS_NR;
             return mine;
         };
-        if (TAG & RS_NODMA) { for (int i = lane + 64 * j; i < RS_LDS_STG / 16; i += 128) reinterpret_cast<f32x4*>(ldsb)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if RIFE_ABL(TAG & RS_NODMA) { for (int i = lane + 64 * j; i < RS_LDS_STG / 16; i += 128) reinterpret_cast<f32x4*>(ldsb)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // prologue: rows of steps 0 .. RS_AHEAD - 1; steps 0 and 1 must have landed before the first barrier
         load_step(true);
         int ahead = 0;                                                   // my pieces of the newest step issued
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (; loaded < RS_AHEAD && loaded < S; loaded++) { const bool f = cur.advance(a.npairs, a.descend); ahead = load_step(f); }
         if (loaded < RS_AHEAD) ahead = 0;                                // fewer than RS_AHEAD steps in the range: wait for everything
 #define RS_WAIT_AHEAD()                                                                                      \
-        if (TAG & RS_NODMA) RS_SYNC_LGKM();                                                                  \
+        if RIFE_ABL(TAG & RS_NODMA) RS_SYNC_LGKM();                                                                  \
         else if (ahead == 0) RS_SYNC_VM(0);                                                                  \
         else if (ahead == 9) RS_SYNC_VM(9);                                                                  \
         else RS_SYNC_VM(18);
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int it = 0; it <= S + 1; it++) {
             if (it >= 2) {                                               // step it - 2, staged at the end of iteration it - 2
                 const int y = 2 * cur.p + j, x0 = 32 * cur.strip;
-                if (y < a.H && !(TAG & RS_NOSTORE)) {
+                if (y < a.H && !RIFE_ABL(TAG & RS_NOSTORE)) {
                     const unsigned okmask = x0 + px < a.W ? 0xffffffffu : 0u;
                     const unsigned char* src = ldsb + RS_LDS_STG + ((it - 2) % RS_NSTG) * (2 * RS_STG_ROW) + j * RS_STG_ROW + px * 64;
                     unsigned char* dst = a.out + ((unsigned)((y + 1) * a.pitch + x0 + 1) * 32u + (unsigned)(lane * 16));
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             hv[e] = hh;
                             lv[e] = (_Float16)(v - (float)hh);
                         }
-                        if (TAG & RS_NTSTORE) {
+                        if RIFE_ABL(TAG & RS_NTSTORE) {
                             __builtin_nontemporal_store(hv, reinterpret_cast<f16x8*>(dst + (size_t)(2 * cc) * a.plane));
                             __builtin_nontemporal_store(lv, reinterpret_cast<f16x8*>(dst + (size_t)(2 * cc + 1) * a.plane));
                         } else {
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
             else if (it == S) RS_SYNC_LGKM();                            // the consumers' final barrier: the last step's staging writes have landed
         }
     }
-    if ((TAG & RS_CLK) && tid == 0) {
+    if (RIFE_ABL(TAG & RS_CLK) && tid == 0) {
         a.stamps[4 * blockIdx.x] = (long long)__builtin_readcyclecounter() - clk0;
         a.stamps[4 * blockIdx.x + 1] = rt0;
         a.stamps[4 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_memrealtime();

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(T64_NTHR + 64 * LW) __attribute__((amdgpu_waves_per
     const int r = __builtin_amdgcn_readfirstlane(tid >> 6);              // wave = output row of the tile (wave-uniform by construction)
     const int h = lane >> 5, li = lane & 31;
     long long clk0 = 0, rt0 = 0;
-    if (TAG & T64_CLK) { clk0 = (long long)__builtin_readcyclecounter(); rt0 = (long long)__builtin_amdgcn_s_memrealtime(); }
+    if RIFE_ABL(TAG & T64_CLK) { clk0 = (long long)__builtin_readcyclecounter(); rt0 = (long long)__builtin_amdgcn_s_memrealtime(); }
     if (LW > 0 && r >= T64_TH) {
         // ---- loader waves: the work-item stream and the ring schedule of the matrix waves below, DMA and waits only
         const int l = r - T64_TH;
@@ -217,11 +217,11 @@ __global__ __launch_bounds__(T64_NTHR + 64 * LW) __attribute__((amdgpu_waves_per
 
     int stepno = 0;
 #define T64_STAMP(K)                                                                                         \
-    if ((TAG & T64_STAMPS) && lane == 0 && stepno < 32)                                                      \
+    if (RIFE_ABL(TAG & T64_STAMPS) && lane == 0 && stepno < 32)                                                      \
         a.stamps[(((size_t)blockIdx.x * 8 + r) * 32 + stepno) * 4 + (K)] = (long long)__builtin_readcyclecounter();
     // halo chunk C of the tile at TB -> in[PAR]; weight chunk C -> w[PAR]
 #define T64_DMA_IN(TB, C, PAR)                                                                               \
-    if (!(TAG & T64_NODMA) && LW == 0) {                                                                                \
+    if (!RIFE_ABL(TAG & T64_NODMA) && LW == 0) {                                                                                \
         const unsigned char* src_ = a.in + ((TB) + (unsigned)(2 * (C)) * a.plane);       /* wave-uniform base + 32-bit lane offset */ \
         unsigned char* dst_ = lds + T64_LDS_IN + (PAR) * T64_INB + r * 1024;                                 \
         t64_glds16(src_ + soff[0], dst_);                                                                    \
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(T64_NTHR + 64 * LW) __attribute__((amdgpu_waves_per
         if (r < 6 && s2ok) t64_glds16(src_ + soff[2], dst_ + 16 * 1024);                                     \
     }
 #define T64_DMA_W(NT, C, PAR)                                                                                \
-    if (!(TAG & T64_NODMA) && LW == 0) {                                                                                \
+    if (!RIFE_ABL(TAG & T64_NODMA) && LW == 0) {                                                                                \
         const unsigned char* src_ = a.img + ((NT) * imgstride + (C) * T64_WCH + r * 1024) + lane * 16;       \
         unsigned char* dst_ = lds + T64_LDS_W + (PAR) * T64_WCH + r * 1024;                                  \
         t64_glds16(src_, dst_);                                                                              \
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(T64_NTHR + 64 * LW) __attribute__((amdgpu_waves_per
     // IDN: the 32-channel output block (of this work item) that K chunk C is the skip connection of, or -1
 #define T64_TAPS(C, PAR, IDN)                                                                                \
     T64_STAMP(3)                                                                                             \
-    if (!(TAG & T64_NOMATH)) {                                                                               \
+    if (!RIFE_ABL(TAG & T64_NOMATH)) {                                                                               \
         _Pragma("unroll") for (int t = 0; t < 9; t++) {                                                      \
             const f16x8 ah = *reinterpret_cast<const f16x8*>(ap[t] + (PAR) * T64_INB);                       \
             const f16x8 al = *reinterpret_cast<const f16x8*>(ap[t] + (PAR) * T64_INB + T64_PLANE);           \
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(T64_NTHR + 64 * LW) __attribute__((amdgpu_waves_per
 #define T64_SYNC()                                                                                           \
     {                                                                                                        \
         T64_STAMP(0)                                                                                         \
-        if (!(TAG & T64_NOVMWAIT) && LW == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* LW > 0: only epilogue stores are in flight here */ \
+        if (!RIFE_ABL(TAG & T64_NOVMWAIT) && LW == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* LW > 0: only epilogue stores are in flight here */ \
         T64_STAMP(1)                                                                                         \
         __builtin_amdgcn_s_barrier();                                                                        \
         T64_STAMP(2)                                                                                         \
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(T64_NTHR + 64 * LW) __attribute__((amdgpu_waves_per
     {                                                                                                        \
         const float* const bs = bs0 + (BUF) * (T64_BSB / 4);                                                 \
         const int oy_ = (OY0) + r, ox_ = (OX0) + li;                                                         \
-        const bool ok_ = oy_ < a.H && ox_ < a.W && (!(TAG & T64_NOSTORE) || acc[0][0] == 123.456f);          /* ablation: (almost) never true, keeps the matrix work alive */ \
+        const bool ok_ = oy_ < a.H && ox_ < a.W && (!RIFE_ABL(TAG & T64_NOSTORE) || acc[0][0] == 123.456f);          /* ablation: (almost) never true, keeps the matrix work alive */ \
         unsigned char* const o_ = a.out + ((unsigned)(2 * h + 4 * NS * (NT)) * a.plane + (unsigned)((oy_ + 1) * a.pitch + ox_ + 1) * 32u); \
         _Pragma("unroll") for (int n = 0; n < NS; n++) {                                                     \
             float v_[16];                                                                                    \
@@ -289,9 +289,9 @@ __global__ __launch_bounds__(T64_NTHR + 64 * LW) __attribute__((amdgpu_waves_per
 
     // ---- prologue: bias / slopes, weight chunk 0, halo chunk 0 of the first work item
 #define T64_DMA_BS(NT, BUF)                                                                                  \
-    if (r == 7 && lane < T64_BSB / 16 && !(TAG & T64_NODMA) && LW == 0)                                      \
+    if (r == 7 && lane < T64_BSB / 16 && !RIFE_ABL(TAG & T64_NODMA) && LW == 0)                                      \
         t64_glds16(a.img + ((NT) * imgstride + a.nchunks * T64_WCH) + lane * 16, lds + T64_LDS_BS + (BUF) * T64_BSB);
-    if (TAG & T64_NODMA) { for (int i = tid; i < T64_LDS / 16; i += T64_NTHR) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if RIFE_ABL(TAG & T64_NODMA) { for (int i = tid; i < T64_LDS / 16; i += T64_NTHR) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     if (mine > 0) { T64_DMA_BS(nt, 0) T64_DMA_W(nt, 0, 0) T64_DMA_IN(tb, 0, 0) }
     T64_SYNC()
 
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(T64_NTHR + 64 * LW) __attribute__((amdgpu_waves_per
         oy0 = oy0n; ox0 = ox0n; tb = tbn; nt = ntn;
     }
     if (mine > 0) T64_EPILOGUE(poy0, pox0, pnt, (mine - 1) & 1)
-    if ((TAG & T64_CLK) && tid == 0) {
+    if (RIFE_ABL(TAG & T64_CLK) && tid == 0) {
         a.stamps[4 * blockIdx.x] = (long long)__builtin_readcyclecounter() - clk0;
         a.stamps[4 * blockIdx.x + 1] = rt0;
         a.stamps[4 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_memrealtime();

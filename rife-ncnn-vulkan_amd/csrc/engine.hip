@@ -17,6 +17,7 @@
 #include <array>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -636,6 +637,20 @@ struct S16Geom {
     size_t bytes(int C) const { return (size_t)plane() * (C / 8); }
 };
 
+// compute units of the current device (cached): grid sizes of the persistent kernels and the kernel-selection thresholds below
+static int device_cus() {
+    int dev = 0; (void)hipGetDevice(&dev);
+    static std::mutex mu; static std::map<int, int> ncu;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = ncu.find(dev);
+    if (it == ncu.end()) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        it = ncu.emplace(dev, n).first;
+    }
+    return it->second;
+}
+
 // one C -> C (C = 64, 96) residual trunk convolution, S16 in / S16 out, persistent workgroups (two / one per CU)
 // reverse: walk the tiles last to first.  Consecutive trunk layers alternate, so that a layer starts on what its predecessor wrote
 // last - still in the L2 / Infinity Cache (134 MB in + 134 MB out per 4K layer against 256 MB of cache: in one direction only the
@@ -699,7 +714,7 @@ static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char*
     RsArgs a;
     a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane();
     a.npairs = (H + 1) / 2; a.nunits = G.tiles_x * a.npairs; a.descend = descend ? 1 : 0;
-    const int nwg = std::min(cus, a.nunits);                             // one workgroup per CU (137 KB of LDS), all resident
+    const int nwg = std::min(cus, a.nunits);                             // one workgroup per CU (154 KB of LDS), all resident
     hipLaunchKernelGGL((conv_rs_kernel<0>), dim3(nwg), dim3(RS_NTHR), RS_LDS, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_rs launch: ") + hipGetErrorString(e));
@@ -898,8 +913,11 @@ struct rife_hip {
     bool t64 = true;
     // block-3 trunk on the row-streaming kernel (conv_rs.h) instead of conv_t64 (RIFE_HIP_RS=0 at create time: A/B, bit-equality test)
     bool rs = true;
-    // the flow updates after blocks 1 and 2 inside the fused stems of blocks 2 and 3 (stem_fused.h UPD; RIFE_HIP_FUSE_FLOW=0: three k_flow_update launches as before)
-    bool fuse_flow = true;
+    // RIFE_HIP_FUSE_FLOW=1 (A/B, parity taps): the flow updates after blocks 1 and 2 inside the fused stems of blocks 2 and 3 (stem_fused.h UPD)
+    // instead of two k_flow_update launches.  Bit-identical, and measured SLOWER at 4K (432 vs 442 frames/s, same call): the update kernels
+    // run at 6 - 7 TB/s, the stems are bound by gather latency and VALU issue and every load added to them costs more than the pass it removes
+    // (stem0_b3 0.210 -> 0.285, stem0_b2 0.161 -> 0.272, flow_update 0.191 -> 0.034 ms per pair).  Off in the product.
+    bool fuse_flow = false;
     int flow_div(int b) const { return v40 ? 2 * blk[b].scale : blk[b].scale; }
     // rife-v2.x schedule (IFNet + ContextNet + FusionNet)
     struct V2Block { ConvLayer stem0, stem1, conv[6], head; int c = 0, scale = 1; } fblk[4];
@@ -944,6 +962,8 @@ namespace rife {
 // models/rife-v4.6/flownet.param; tests/test_models.py proves the equivalence whenever /root/reference exists)
 static const uint64_t V46_HASH_OUT0 = RIFE_V46_HASH_OUT0;
 
+static std::atomic<bool> g_fuse_flow_buffers{false};                 // some engine of the process asked for RIFE_HIP_FUSE_FLOW=1: workspaces carry F2, M2
+
 // (Re)allocate a workspace for frames of w x h (padded wp x hp).  `scratch` != null: borrow the big per-layer
 // scratch tensors (block input, stem output, trunk ping/pong) from another context of the same pixel count —
 // the TTA passes run one after another on one stream, only flows / F / M / images must persist per pass.
@@ -955,6 +975,7 @@ static int ensure_ctx_dims_impl(Ctx& c, int w, int h, int wp, int hp, const Ctx*
     for (void* p : c.allocs) (void)hipFree(p);
     c.allocs.clear();
     c.outf = nullptr; c.F2 = nullptr; c.M2 = nullptr;
+    for (auto& pb : c.P) pb[0] = pb[1] = nullptr;                       // S16 trunk tensors: allocated by the first block that runs on them (ensure_s16)
     c.w = w; c.h = h; c.wp = wp; c.hp = hp;
     const size_t P = (size_t)wp * hp;
     int rc;
@@ -973,18 +994,6 @@ static int ensure_ctx_dims_impl(Ctx& c, int w, int h, int wp, int hp, const Ctx*
         if ((rc = dalloc(c, c.T1, P / 16 * 64))) return rc;
         if ((rc = dalloc(c, c.T2, P / 16 * 64))) return rc;
     }
-    {   // S16 trunk tensors of the four blocks (192 / 128 / 96 / 64 channels at 1/32 .. 1/4 resolution); never borrowed: the zero border belongs to THIS geometry
-        static const int CB[4] = {192, 128, 96, 64}, SB[4] = {32, 16, 8, 4};
-        for (int b = 0; b < 4; b++) {
-            const S16Geom G(hp / SB[b], wp / SB[b]);
-            const size_t nb = G.bytes(CB[b]);
-            for (int k = 0; k < 2; k++) {
-                if ((rc = dalloc(c, c.P[b][k], nb))) return rc;
-                if (c.stream) HIPCHK(hipMemsetAsync(c.P[b][k], 0, nb, c.stream));
-                else HIPCHK(hipMemset(c.P[b][k], 0, nb));
-            }
-        }
-    }
     static const int sc[4] = {8, 4, 2, 1};
     for (int b = 0; b < 4; b++) {
         const size_t n = P / (sc[b] * sc[b]) * 8;
@@ -997,7 +1006,7 @@ static int ensure_ctx_dims_impl(Ctx& c, int w, int h, int wp, int hp, const Ctx*
     }
     if ((rc = dalloc(c, c.F, P))) return rc;
     if ((rc = dalloc(c, c.M, P))) return rc;
-    if (!want_outf && !scratch) {                                      // the plain pass (not the TTA workspaces, whose updates go through the consensus kernels)
+    if (!want_outf && !scratch && g_fuse_flow_buffers) {               // the plain pass of an engine created with RIFE_HIP_FUSE_FLOW=1 (not the TTA workspaces, whose updates go through the consensus kernels)
         if ((rc = dalloc(c, c.F2, P))) return rc;
         if ((rc = dalloc(c, c.M2, P))) return rc;
     }
@@ -1059,9 +1068,35 @@ static int run_assemble(const rife_hip& E, Ctx& c, int b, float timestep, const 
 static bool block_on_row_kernel(const rife_hip& E, const Ctx& c, int b) {
     const rife_hip::Block& B = E.blk[b];
     const int s = B.scale, Ht = c.hp / s / 4, Wt = c.wp / s / 4;
-    const int ptiles = ((Ht + 7) / 8) * ((Wt + 31) / 32);
-    const bool row_small = b == 2 && B.c == 96 && ptiles <= 256;
-    return (b == 1 && B.c == 128) || (b == 0 && B.c == 192 && ((Wt + 31) / 32) * Ht <= 160) || row_small;
+    const int ptiles = ((Ht + 7) / 8) * ((Wt + 31) / 32), cus = device_cus();
+    const bool row_small = b == 2 && B.c == 96 && ptiles <= cus;                               // fewer 8 x 32 tiles than the chip has CUs
+    return (b == 1 && B.c == 128) || (b == 0 && B.c == 192 && ((Wt + 31) / 32) * Ht <= cus * 5 / 8) || row_small;      // MI355X: 160 of 256
+}
+
+// Does block b run on S16 trunk tensors (conv_rs / conv_t64 / conv_row) at this frame size?  Blocks 3 / 2 on the persistent kernels, the coarse
+// blocks on the row kernel where block_on_row_kernel says so; never for rife-v4 (4.0), RIFE_HIP_T64=0, or a tensor of 4 GB and more (the
+// kernels address S16 tensors with 32-bit byte offsets).
+static bool block_on_s16(const rife_hip& E, const Ctx& c, int b) {
+    const rife_hip::Block& B = E.blk[b];
+    const int s = B.scale, Ht = c.hp / s / 4, Wt = c.wp / s / 4;
+    const bool rowk = block_on_row_kernel(E, c, b);
+    bool s16 = E.t64 && !E.v40 && g_trunk_h2 && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS &&
+               ((b == 3 && B.c == 64) || (b == 2 && B.c == 96) || rowk);
+    for (int i = 0; i < 8 && s16; i++) s16 = B.res[i].d_t64 != nullptr && (!(rowk && B.c == 96) || B.res[i].d_row != nullptr);
+    return s16 && (unsigned long long)S16Geom(Ht, Wt).bytes(B.c) < (1ull << 32);
+}
+// the block's two S16 tensors (trunk ping / pong), allocated on first use with their zero borders: a workspace only carries the tensors of
+// the blocks that really run on the S16 kernels (TTA: 16 workspaces)
+static int ensure_s16(Ctx& c, int b, int Ht, int Wt, int C) {
+    if (c.P[b][0] && c.P[b][1]) return 0;
+    const size_t nb = S16Geom(Ht, Wt).bytes(C);
+    int rc;
+    for (int k = 0; k < 2; k++) {
+        if ((rc = dalloc(c, c.P[b][k], nb))) { c.P[b][0] = c.P[b][1] = nullptr; return rc; }
+        if (c.stream) HIPCHK(hipMemsetAsync(c.P[b][k], 0, nb, c.stream));
+        else HIPCHK(hipMemset(c.P[b][k], 0, nb));
+    }
+    return 0;
 }
 
 enum { PH_STEMS = 1, PH_TRUNK = 2, PH_HEAD = 4, PH_ALL = 7 };
@@ -1125,20 +1160,16 @@ after_stem0:
     // chip), the coarse blocks 1 / 0 on the one-pass row kernel (conv_row.h).  (Blocks 1 / 0 as N-tiles of 64 output channels on the
     // persistent kernel were measured too: 4K trunk_b1 0.300 vs 0.285 ms per pair, trunk_b0 0.228 vs 0.206 - a chain of 8 - 12 dependent
     // steps whose fixed cost exceeds a step's matrix work at these sizes.)
-    unsigned char* const PA = c.P[b][0];
-    unsigned char* const PB = c.P[b][1];
-    const int ptiles = ((Ht + 7) / 8) * ((Wt + 31) / 32);
     // block 0 on the row kernel only while its grid is small: at 4K all 272 workgroups stream the same 663 KB of weights through the L2 at
     // once (0.239 vs 0.208 ms per pair for the per-tile kernel), at 1080p (68 workgroups) it wins (0.133 vs 0.152); block 1 wins at both
     // block 2 on small grids (<= 256 tiles of 8 x 32: fewer tiles than CUs): the persistent kernel (one workgroup per CU for 96 channels) has at most one
     // tile per workgroup there and fills only part of the chip: 1080p (136 tiles) trunk_b2 0.229 -> 0.179 ms per pair on the row kernel, 4K (510 tiles)
     // 0.387 -> 0.401; block 3 (64 channels, two workgroups per CU) stays on the persistent kernel at every size (1080p 0.225 vs 0.233)
-    const bool row_small = b == 2 && B.c == 96 && ptiles <= 256;
     const bool rowk = block_on_row_kernel(E, c, b);
-    bool s16 = E.t64 && !E.v40 && g_trunk_h2 && PA && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS &&
-               ((b == 3 && B.c == 64) || (b == 2 && B.c == 96) || rowk);
-    for (int i = 0; i < 8 && s16; i++) s16 = B.res[i].d_t64 != nullptr && (!row_small || B.res[i].d_row != nullptr);
-    if (s16) {
+    if (block_on_s16(E, c, b)) {
+        if ((rc = ensure_s16(c, b, Ht, Wt, B.c))) return rc;
+        unsigned char* const PA = c.P[b][0];
+        unsigned char* const PB = c.P[b][1];
         // stem-1 writes the first S16 tensor, eight persistent trunk launches ping-pong between the two, the head reads the last one
         const S16Geom G(Ht, Wt);
         if (phases & PH_STEMS) {
@@ -1258,8 +1289,7 @@ static int run_v4_group(const rife_hip& E, Ctx* const* cs, int G, const uint8_t*
     };
     for (int b = 0; b < 4; b++) {
         const rife_hip::Block& B = E.blk[b];
-        bool batched = G >= 2 && E.t64 && block_on_row_kernel(E, *cs[0], b) && cs[0]->P[b][0] && B.stem1.d_whp && B.head.d_wh && B.head.epi == EPI_DECONV_PS;
-        for (int i = 0; i < 8 && batched; i++) batched = (B.c == 96 ? B.res[i].d_row : B.res[i].d_t64) != nullptr;
+        const bool batched = G >= 2 && block_on_row_kernel(E, *cs[0], b) && block_on_s16(E, *cs[0], b);
         for (int g = 0; g < G; g++) {
             Ctx& c = *cs[g];
             FinalArgs fin{c.img0, c.img1, c.F, c.M, d_out[g], c.w, c.h, c.wp, c.hp};
@@ -2045,7 +2075,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     E->frame_pool->gpuid = gpuid;
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_RS"); E->rs = !(e && e[0] == '0'); }
-    { const char* e = getenv("RIFE_HIP_FUSE_FLOW"); E->fuse_flow = !(e && e[0] == '0'); }
+    { const char* e = getenv("RIFE_HIP_FUSE_FLOW"); E->fuse_flow = e && e[0] == '1'; if (E->fuse_flow) g_fuse_flow_buffers = true; }
     return E;
 }
 
@@ -2284,7 +2314,7 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     // fills the chip, measured 405 - 413 frames/s in groups against 400 - 425 per pair; RIFE_HIP_BATCH_GROUPS=1 / 0 forces / forbids the path)
     const char* genv = getenv("RIFE_HIP_BATCH_GROUPS");
     const int Ht0 = (h + 31) / 32, Wt0 = (w + 31) / 32;
-    const bool small_grid = ((Wt0 + 31) / 32) * Ht0 <= 160;
+    const bool small_grid = ((Wt0 + 31) / 32) * Ht0 <= device_cus() * 5 / 8;      // MI355X: 160 workgroups, block 0 on the row kernel (block_on_row_kernel)
     const bool groups = E->v4 && !E->v40 && !E->v1 && !E->tta && !E->tta_temporal && E->t64 && n >= 2 && (genv ? genv[0] != '0' : small_grid);
     if (groups) {
         std::vector<std::array<int, 2>> grp;                 // pair indices of a group, -1 = none

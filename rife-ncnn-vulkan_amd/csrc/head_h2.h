@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define HEAD_ABL 0
 #endif
     if (EPI == EPI_FINAL || EPI == EPI_DECONV_PS) {
-        if (EPI == EPI_FINAL && (HEAD_ABL & 1)) {     // ablation: no tail at all (keep the accumulators alive)
+        if (EPI == EPI_FINAL && RIFE_ABL(HEAD_ABL & 1)) {     // ablation: no tail at all (keep the accumulators alive)
             float sacc = 0.f;
 #pragma unroll
             for (int par = 0; par < 4; par++)
@@ -221,13 +221,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     uint32_t pk = 0;
                     if (valid) {
                         const size_t i = (size_t)fy * fa.wp + fx;
-                        float4 f = (HEAD_ABL & 2) ? make_float4(0.1f, 0.2f, 0.3f, 0.4f) : fa.F[i];
+                        float4 f = RIFE_ABL(HEAD_ABL & 2) ? make_float4(0.1f, 0.2f, 0.3f, 0.4f) : fa.F[i];
                         f.x = f.x + dx; f.y = f.y + dy; f.z = f.z + dz; f.w = f.w + dw;
-                        const float mm = ((HEAD_ABL & 2) ? 0.5f : fa.M[i]) + dm;
-                        const float m = (HEAD_ABL & 8) ? mm * 0.01f : 1.f / (1.f + expf(-mm));
+                        const float mm = (RIFE_ABL(HEAD_ABL & 2) ? 0.5f : fa.M[i]) + dm;
+                        const float m = RIFE_ABL(HEAD_ABL & 8) ? mm * 0.01f : 1.f / (1.f + expf(-mm));
                         const float rm = 1.0f - m;
-                        const float3 w1 = (HEAD_ABL & 4) ? make_float3(f.z, f.w, f.z) : warp_rgbx(fa.img1, fx, fy, f.z, f.w, fa.wp, fa.hp);
-                        const float3 w0 = (HEAD_ABL & 4) ? make_float3(f.x, f.y, f.x) : warp_rgbx(fa.img0, fx, fy, f.x, f.y, fa.wp, fa.hp);
+                        const float3 w1 = RIFE_ABL(HEAD_ABL & 4) ? make_float3(f.z, f.w, f.z) : warp_rgbx(fa.img1, fx, fy, f.z, f.w, fa.wp, fa.hp);
+                        const float3 w0 = RIFE_ABL(HEAD_ABL & 4) ? make_float3(f.x, f.y, f.x) : warp_rgbx(fa.img0, fx, fy, f.x, f.y, fa.wp, fa.hp);
                         const float r = w0.x * m + w1.x * rm, g = w0.y * m + w1.y * rm, b = w0.z * m + w1.z * rm;
                         pk = (uint32_t)min(max((int)(r * 255.f + 0.5f), 0), 255) | ((uint32_t)min(max((int)(g * 255.f + 0.5f), 0), 255) << 8) |
                              ((uint32_t)min(max((int)(b * 255.f + 0.5f), 0), 255) << 16);

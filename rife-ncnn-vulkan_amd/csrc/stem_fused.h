@@ -27,13 +27,15 @@ struct StemFusedArgs {
 };
 
 // LDS pixel record: 32 B hi + 32 B lo (+ 16 B pad: 80-byte records are conflict-free for the 16-byte staging writes and 2-way for
-// the stride-2 operand reads; 64-byte records are 4-way / 8-way).  ABL bit 128 selects the unpadded record for A/B runs.
-template <int ABL> constexpr int stemf_pixb() { return (ABL & (128 | 256)) ? 64 : 80; }
+// the stride-2 operand reads; plain 64-byte records are 4-way / 8-way and measured 8 % slower).
+template <int ABL> constexpr int stemf_pixb() { return (ABL & 256) ? 64 : 80; }
 template <int NS, int ABL = 0>
 constexpr int stemf_lds_bytes() { return (9 * 65 + 1) * stemf_pixb<ABL>() + 9 * 2 * NS * 32 * 16; }      // + one dummy pixel record
 
-// ABL (bench only): 4096 = round-2 staging of the second halo pixel under a lane-divergent branch; 1 = skip MFMA + epilogue, 2 = second halo pixel in a second round, 16 = skip stores, 32 = skip MFMAs, 64 = direct-store epilogue, 128 = 64-byte LDS records
-// ABL 256: 64-byte records with the 16-byte quarters XOR-swizzled by pixel index (quarter q of pixel P at position q ^ ((P >> 2) & 3): 2-way on the
+// ABL, bench builds only (RIFE_ABL): 1 = skip MFMA + epilogue, 16 = skip stores, 32 = skip MFMAs, 1024 = dump the gathered pixels, 4096 = round-2
+// staging of the second halo pixel under a lane-divergent branch.  (Settled A/Bs removed: second halo pixel in a second dependent round,
+// direct-store epilogue, unswizzled 64-byte records - all slower.)
+// ABL 256 (a layout, not an ablation: block 3 of the product): 64-byte records with the 16-byte quarters XOR-swizzled by pixel index (quarter q of pixel P at position q ^ ((P >> 2) & 3): 2-way on the
 // stride-2 operand reads like the padded records, conflict-free staging writes) -> 46.6 KB for NS = 1: three workgroups (24 waves) per CU
 // UPD: k_flow_update<2 S> of the block before (flownet.param:99-105, 152-158) happens here: the kernel visits every full-resolution pixel (S <= 2)
 // anyway, so F, M make one round trip less through HBM per block and the launch disappears; halo pixels shared by tiles are written twice with
@@ -95,39 +97,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((ABL & 256)
     }
     // Round 3: no lane-divergent control flow around the staging.  The 73 second pixels (waves 0-1) used to be staged under
     // `if (tid + 512 < NPIX)`; built with the SLP vectorizer the compiler tail-merged that store block with the other paths' and the kernel
-    // was not run-to-run stable (whole groups of 16 halo pixels came out with stale LDS contents: tools/stem_bisect.py, stem_poison.py,
+    // was not run-to-run stable (whole groups of 16 halo pixels came out with stale LDS contents: tools/probes/stem_bisect.py, stem_poison.py,
     // DESIGN.md (d)-8).  Now the wave role is a scalar (readfirstlane) and the lanes without a second pixel write a dummy record instead
     // of branching.
     const bool two_px = __builtin_amdgcn_readfirstlane(wv8) < 2;
-    if ((ABL & 4096) && wv8 < 2) {                                       // bench builds: the round-2 form (tools/stem_det_both.py reproduces the instability with it)
+    if (RIFE_ABL(ABL & 4096) && wv8 < 2) {                                       // bench builds: the round-2 form (tools/probes/stem_det_both.py reproduces the instability with it)
         float o0[12], o1[12];
         STEM_GATHER(tid, o0)
         STEM_GATHER(tid + 512, o1)
         STEM_STAGE(tid, o0)
         if (tid + 512 < NPIX) STEM_STAGE(tid + 512, o1)
-    } else if (two_px && !(ABL & 2)) {
+    } else if (two_px) {
         float o0[12], o1[12];
         STEM_GATHER(tid, o0)
         STEM_GATHER(tid + 512, o1)
-        if (ABL & 1024) { _Pragma("unroll") for (int c = 0; c < 12; c++) a.dbg[((size_t)blockIdx.x * 512 + tid) * 12 + c] = o0[c]; }
+        if (RIFE_ABL(ABL & 1024)) { _Pragma("unroll") for (int c = 0; c < 12; c++) a.dbg[((size_t)blockIdx.x * 512 + tid) * 12 + c] = o0[c]; }
         STEM_STAGE(tid, o0)
         const int p1 = tid + 512 < NPIX ? tid + 512 : NPIX;              // record NPIX is the dummy
         STEM_STAGE(p1, o1)
     } else {
         float o0[12];
         STEM_GATHER(tid, o0)
-        if (ABL & 1024) { _Pragma("unroll") for (int c = 0; c < 12; c++) a.dbg[((size_t)blockIdx.x * 512 + tid) * 12 + c] = o0[c]; }
+        if (RIFE_ABL(ABL & 1024)) { _Pragma("unroll") for (int c = 0; c < 12; c++) a.dbg[((size_t)blockIdx.x * 512 + tid) * 12 + c] = o0[c]; }
         STEM_STAGE(tid, o0)
-        if ((ABL & 2) && tid + 512 < NPIX) {     // A/B: the second pixel as a second, dependent round
-            STEM_GATHER(tid + 512, o0)
-            STEM_STAGE(tid + 512, o0)
-        }
     }
 #undef STEM_GATHER
 #undef STEM_STAGE
     __syncthreads();
 
-    if (ABL & 1) return;
+    if (RIFE_ABL(ABL & 1)) return;
     if (nsel >= NS) return;                                // NS = 1: waves 4-7 only helped with the gather
     f32x16 acc;
 #pragma unroll
@@ -148,26 +146,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((ABL & 256)
             al = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB + 32);
         }
         const f16x8 bw = *reinterpret_cast<const f16x8*>(bb + (t * 2 * NT) * 16);
-        if (ABL & 32) { acc[0] += (float)ah[0] + (float)al[1] + (float)bw[2]; continue; }     // ablation: LDS reads without the matrix pipe
+        if (RIFE_ABL(ABL & 32)) { acc[0] += (float)ah[0] + (float)al[1] + (float)bw[2]; continue; }     // ablation: LDS reads without the matrix pipe
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, ah, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, al, acc, 0, 0, 0);
     }
 
-    if (ABL & 64) {   // A/B: direct epilogue, one 16-byte store per register quad (32 B per pixel per instruction)
-        const int oy = oy0 + wv, ox = ox0 + li;
-        const bool pok = oy < a.Ho && ox < a.Wo;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c0 = nsel * 32 + 8 * q + 4 * half;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.slope + c0);
-            f32x4 v;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { v[k] = acc[4 * q + k] + b4[k]; v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k]; }
-            if (pok && c0 < a.Cout) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + c0) = v;
-        }
-        return;
-    }
     // epilogue: bias + leaky, then transpose the wave's 32 x 32 tile through LDS (the halo tile is dead by now) so that
     // 8 consecutive lanes store one pixel's 128 contiguous bytes (a full line per pixel, 1 KB per instruction if out_ld = 32)
     __syncthreads();                                       // waves 4-7 (NS = 1) have exited; exited waves do not count
@@ -191,7 +174,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((ABL & 256)
     for (int j = 0; j < 4; j++) {
         const int px = j * 8 + pl;
         const f32x4 v = *reinterpret_cast<const f32x4*>(tl + px * ROWF + chunk * 4);
-        if (ABL & 16) { if (v[0] == 123.456f) a.out[0] = v[1]; }                               // ablation: no stores
+        if (RIFE_ABL(ABL & 16)) { if (v[0] == 123.456f) a.out[0] = v[1]; }                               // ablation: no stores
         else if (oy < a.Ho && ox0 + px < a.Wo && c0 < a.Cout) *reinterpret_cast<f32x4*>(orow + (size_t)px * a.out_ld) = v;
     }
 }

@@ -39,6 +39,18 @@ def engines(modeldirs):
     return g, o, names
 
 
+@pytest.fixture(scope="module")
+def fused_engine(modeldirs):
+    old = os.environ.get("RIFE_HIP_FUSE_FLOW")
+    os.environ["RIFE_HIP_FUSE_FLOW"] = "1"                              # read at create time
+    try:
+        g = amd.RIFE(0, rife_v4=True); g.load(modeldirs["rife-v4.6"])
+    finally:
+        if old is None: del os.environ["RIFE_HIP_FUSE_FLOW"]
+        else: os.environ["RIFE_HIP_FUSE_FLOW"] = old
+    return g
+
+
 def injected_flows(w, h, seed, n):
     """blobs flow0..flow{n-1} (6 x hp/s x wp/s, s = 8, 4, 2, 1): smooth fields + noise; after the x s of the flow update the coarse one moves
     samples by up to ~300 px, the finer ones add tens of pixels; channel 4 = mask logit increments of a few units."""
@@ -83,16 +95,21 @@ def test_block_input_bit_exact_and_through_the_fused_stem(engines, w, h, seed, b
 
 @pytest.mark.parametrize("w,h,seed", SIZES)
 @pytest.mark.parametrize("b", [2, 3])
-def test_flow_update_inside_the_stem_writes_the_same_F_M(engines, w, h, seed, b):
-    """Blocks 2 and 3: the product's stem kernel applies the flow update of the block before it while it gathers (stem_fused.h UPD,
-    flownet.param:99-105, 152-158) and writes F, M for the later stages.  what = 1 above already ran that kernel (its block input is the
-    oracle's); here the tensors it WRITES against the flow-update kernel's, bit for bit - every full-resolution pixel, borders included."""
-    g, o, names = engines
+def test_flow_update_inside_the_stem_writes_the_same_F_M(engines, fused_engine, w, h, seed, b):
+    """Blocks 2 and 3, opt-in schedule RIFE_HIP_FUSE_FLOW=1 (slower than the update kernels on MI355X, kept for A/B): the stem kernel applies
+    the flow update of the block before it while it gathers (stem_fused.h UPD, flownet.param:99-105, 152-158) and writes F, M for the later
+    stages.  The block input it computes from them against the oracle's blob, and the tensors it WRITES against the flow-update kernel's, bit
+    for bit - every full-resolution pixel, borders included."""
+    _, o, names = engines
+    g = fused_engine
     a, c = gen_frames.noise_pair(w, h, seed) if seed % 2 else gen_frames.smooth_pair(w, h, seed)
     inj = injected_flows(w, h, 300 + seed, b)
     want = g.v4_tap(a, c, 0.5, 4, b, inj)
     got = g.v4_tap(a, c, 0.5, 3, b, inj)
     assert np.array_equal(got, want), "%d of %d floats differ" % (int((got != want).sum()), want.size)
+    blob_in = o.v4_extract(a, c, 0.5, names[b - 1], flows=inj)
+    err = np.abs(g.v4_tap(a, c, 0.5, 1, b, inj) - blob_in) - (3e-7 * np.abs(blob_in) + 1.2e-7)      # through the UPD kernel's matrix path: hi + lo of every value
+    assert err.max() <= 0, float(err.max())
     if b == 3:      # scale 1: channels 7..11 of the oracle's block input ARE M and F
         blob = o.v4_extract(a, c, 0.5, names[2], flows=inj)
         assert np.array_equal(got[4], blob[7]) and np.array_equal(got[:4], blob[8:12])
@@ -129,12 +146,12 @@ def test_tail_on_injected_flows(engines, w, h, seed):
 
 @pytest.mark.parametrize("w,h", [(256, 192), (640, 360), (1920, 1080)])
 def test_pass_with_fused_flow_updates_is_bit_identical_to_three_update_launches(modeldirs, w, h, monkeypatch):
-    """The plain pass with the updates after blocks 1 and 2 inside the stems of blocks 2 and 3 (default) against the same pass with
-    RIFE_HIP_FUSE_FLOW=0 (k_flow_update after every block): same arithmetic on the same values, so the frames must be the same bytes."""
+    """The plain pass with the updates after blocks 1 and 2 inside the stems of blocks 2 and 3 (RIFE_HIP_FUSE_FLOW=1) against the product's
+    schedule (k_flow_update after every block): same arithmetic on the same values, so the frames must be the same bytes."""
     a, c = gen_frames.smooth_pair(w, h, 11) if w < 1000 else gen_frames.tiled_real_pair(3)
-    monkeypatch.setenv("RIFE_HIP_FUSE_FLOW", "0")
+    monkeypatch.delenv("RIFE_HIP_FUSE_FLOW", raising=False)
     g0 = amd.RIFE(0, rife_v4=True); g0.load(modeldirs["rife-v4.6"])
-    monkeypatch.delenv("RIFE_HIP_FUSE_FLOW")
+    monkeypatch.setenv("RIFE_HIP_FUSE_FLOW", "1")
     g1 = amd.RIFE(0, rife_v4=True); g1.load(modeldirs["rife-v4.6"])
     for t in (0.5, 0.2):
         x0, x1 = g0.process(a, c, t), g1.process(a, c, t)

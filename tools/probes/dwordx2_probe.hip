@@ -1,5 +1,5 @@
 // GPU box probe: do 8-byte global loads at 4-byte (not 8-byte) aligned addresses always return the right two dwords?
-//   hipcc --offload-arch=gfx950 -O3 tools/dwordx2_probe.hip -o /tmp/dwordx2_probe && /tmp/dwordx2_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/dwordx2_probe.hip -o /tmp/dwordx2_probe && /tmp/dwordx2_probe
 // Buffer B[i] = hash(i); every lane loads uint2 at a pseudo-random dword index near its pixel (like the paired warp taps of
 // warp_rgbx) next to 16-byte loads of a second buffer, many rounds; counts the dwords that differ from hash(idx), hash(idx + 1).
 #include <hip/hip_runtime.h>

@@ -1,7 +1,7 @@
 """GPU box: pin the operand convention of __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4 (both operands OCP e4m3) against numpy.
 A (32 x 64) and B (64 x 32) of small integers (exact in e4m3), D = A @ B with the standard 32 x 32 C/D map
 (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  Hypotheses for the per-lane packing of A / B are tried until one reproduces D.
-    python tools/mx_probe.py"""
+    python tools/probes/mx_probe.py"""
 import ctypes, os, sys, itertools
 import numpy as np
 sys.path.insert(0, os.getcwd())

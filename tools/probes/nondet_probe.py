@@ -1,5 +1,5 @@
 """GPU box: is the plain rife-v4.6 pass deterministic inside one process at a large size, and if not, which stage differs first?
-    python tools/nondet_probe.py [w h reps]
+    python tools/probes/nondet_probe.py [w h reps]
 Runs the same pair `reps` times: frames byte-compared, then the flow blobs flow0 .. flow3 (rife_hip_v4_extract_flow) compared run to run."""
 import importlib, os, sys
 import numpy as np

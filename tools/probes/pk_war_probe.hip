@@ -1,5 +1,5 @@
 // GPU box probe: is a VALU write to a VGPR safe right behind a packed-fp32 instruction that READS that VGPR (write-after-read)?
-//   hipcc --offload-arch=gfx950 -O3 tools/pk_war_probe.hip -o /tmp/pk_war_probe && /tmp/pk_war_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/pk_war_probe.hip -o /tmp/pk_war_probe && /tmp/pk_war_probe
 // The SLP-vectorized build of the fused stem kernels contained   v_pk_mul_f32 v[34:35], v[18:19], 0.5   directly followed by   v_mov_b32 v18, v23
 // and was not run-to-run stable in quarter-wave groups of lanes.  This probe runs exactly that pair, many times, on a
 // full chip (4 waves per SIMD, with and without memory traffic next to it) and counts lanes whose product used the NEW value of v18.

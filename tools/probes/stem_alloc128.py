@@ -1,9 +1,9 @@
 """GPU box: the LIBRARY-flags (no SLP) assembly of stem0_fused_kernel<2, 2>, whose 115 VGPRs are allocated as 120, with its register allocation
 raised to 128 in the kernel descriptor (four waves x 128 = the whole 512-entry register file of a SIMD, like the SLP build): stable or not?
-    python tools/stem_alloc128.py      -> gpurun_out/stem_alloc128.txt"""
+    python tools/probes/stem_alloc128.py      -> gpurun_out/stem_alloc128.txt"""
 import ctypes, os, re, subprocess, sys
 sys.path.insert(0, os.getcwd())
-from tools import stem_unpack as U
+from tools.probes import stem_unpack as U
 from tools import benchlib
 log = open("gpurun_out/stem_alloc128.txt", "w")
 def say(*a):

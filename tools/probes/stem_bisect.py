@@ -6,7 +6,7 @@ assembles VARIANTS of that assembly - wait states (s_nop 7) inserted after chose
 determinism probe launches instead of its built-in kernels (rife_hip_probe_set_stem_hsaco).  Stage 1 tries instruction classes, stage 2 delta-
 debugs the smallest class that cures the instability down to a 1-minimal set of sites and prints them with their neighbourhood.
 
-    python tools/stem_bisect.py [budget seconds]      -> gpurun_out/stem_bisect.txt
+    python tools/probes/stem_bisect.py [budget seconds]      -> gpurun_out/stem_bisect.txt
 """
 import ctypes, os, re, subprocess, sys, time
 sys.path.insert(0, os.getcwd())

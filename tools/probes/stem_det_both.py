@@ -1,6 +1,6 @@
 """GPU box: run-to-run stability of the fused stem kernels of blocks 1 / 2 under BOTH sets of compiler flags, old and new staging code.
 
-    python tools/stem_det_both.py [launches]      -> gpurun_out/stem_det_both.txt
+    python tools/probes/stem_det_both.py [launches]      -> gpurun_out/stem_det_both.txt
 Four builds of stem0_fused_kernel<4, 2> and <2, 2> (csrc/stem_fused.h), `launches` (default 200) identical launches each at 3840x2176 and
 1920x1088, floats that differ from launch 0 summed over the launches, and launch 0 against the library's kernel:
   library flags (-fno-slp-vectorize), round-3 staging     = the product

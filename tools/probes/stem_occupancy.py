@@ -3,10 +3,10 @@
   E2 packed,   128 VGPRs, 100 KB of LDS -> one workgroup per CU, same registers
   E3 packed,   136 VGPRs                -> one workgroup per CU (three waves per SIMD allowed, a 512-thread workgroup needs two)
   E4 unpacked IN PLACE (no scratch registers), 128 VGPRs, 65 KB -> two workgroups per CU, scalar fp32 instead of v_pk_*
-    python tools/stem_occupancy.py      -> gpurun_out/stem_occupancy.txt"""
+    python tools/probes/stem_occupancy.py      -> gpurun_out/stem_occupancy.txt"""
 import ctypes, os, re, sys
 sys.path.insert(0, os.getcwd())
-from tools import stem_unpack as U
+from tools.probes import stem_unpack as U
 from tools import benchlib
 log = open("gpurun_out/stem_occupancy.txt", "w")
 def say(*a):

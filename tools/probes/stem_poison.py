@@ -1,13 +1,13 @@
-"""GPU box: does the SLP-vectorized fused stem kernel read registers it never wrote?  (follow-up of tools/stem_bisect.py)
+"""GPU box: does the SLP-vectorized fused stem kernel read registers it never wrote?  (follow-up of tools/probes/stem_bisect.py)
 
-tools/stem_bisect.py showed that no wait state anywhere cures the run-to-run instability of the SLP build, that its differences are large (1 - 3 % of
+tools/probes/stem_bisect.py showed that no wait state anywhere cures the run-to-run instability of the SLP build, that its differences are large (1 - 3 % of
 the value, whole groups of 16 halo pixels) and that launches 1, 2, ... of a burst agree with each other while launch 0 differs: the result depends
 on what the previous kernel left behind in the CU (registers or LDS), not on timing.  This script assembles variants of the compiler's assembly
 whose first instructions fill VGPRs v1 .. v127 (v0 = work-item id) with a poison value - a quiet NaN, or a large number - and compares launch 0
 with the library's own (non-SLP) kernel on the same inputs: if poison reaches the output, the kernel consumes an uninitialised register; a
 bisection over the register set names it, and the first read of that register in the assembly is printed.
 
-    python tools/stem_poison.py [budget seconds]      -> gpurun_out/stem_poison.txt
+    python tools/probes/stem_poison.py [budget seconds]      -> gpurun_out/stem_poison.txt
 """
 import ctypes, os, re, subprocess, sys, time
 sys.path.insert(0, os.getcwd())

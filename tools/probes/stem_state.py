@@ -1,7 +1,7 @@
-"""GPU box: which STATE does the SLP build of the fused stem kernels depend on?  (after tools/stem_bisect.py and stem_poison.py: not wait states,
+"""GPU box: which STATE does the SLP build of the fused stem kernels depend on?  (after tools/probes/stem_bisect.py and stem_poison.py: not wait states,
 not memory waits, not register residue)  1. are the input buffers intact after the launches (an out-of-bounds store)?  2. does the result follow
 what a scrub kernel leaves in the CUs' LDS between the launches (a read of LDS the kernel did not write)?
-    python tools/stem_state.py      -> gpurun_out/stem_state.txt"""
+    python tools/probes/stem_state.py      -> gpurun_out/stem_state.txt"""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, os.getcwd())
 from tools import benchlib

@@ -1,4 +1,4 @@
-// translation unit of tools/stem_bisect.py: the two fused stem kernels that were not run-to-run stable when built with the SLP vectorizer
+// translation unit of tools/probes/stem_bisect.py: the two fused stem kernels that were not run-to-run stable when built with the SLP vectorizer
 #include "../../rife-ncnn-vulkan_amd/csrc/stem_fused.h"
 template __global__ void rife::stem0_fused_kernel<4, 2, 0>(rife::StemFusedArgs);
 template __global__ void rife::stem0_fused_kernel<2, 2, 0>(rife::StemFusedArgs);

@@ -3,7 +3,7 @@
 Takes the compiler's SLP assembly of the fused stem kernels (tools/probes/stem_tu.hip, round-2 flags) and rewrites every v_pk_mul_f32 /
 v_pk_add_f32 into two scalar v_mul_f32 / v_add_f32 (through two scratch registers v128 / v129, so that overlapping operands cannot
 interfere) - same registers, same schedule, same everything else - and runs the determinism probe on both.
-    python tools/stem_unpack.py      -> gpurun_out/stem_unpack.txt"""
+    python tools/probes/stem_unpack.py      -> gpurun_out/stem_unpack.txt"""
 import ctypes, os, re, subprocess, sys
 sys.path.insert(0, os.getcwd())
 OUT = "gpurun_out/stem_unpack"

@@ -1,9 +1,9 @@
-"""GPU box: WHICH packed-fp32 instructions of the SLP build of stem0_fused_kernel<2, 2> misbehave?  (tools/stem_unpack.py: unpacking all of them
+"""GPU box: WHICH packed-fp32 instructions of the SLP build of stem0_fused_kernel<2, 2> misbehave?  (tools/probes/stem_unpack.py: unpacking all of them
 cures the instability.)  Classes by opcode / operand modifiers first, then delta debugging inside the smallest curing class.
-    python tools/stem_unpack2.py [budget seconds]      -> gpurun_out/stem_unpack2.txt"""
+    python tools/probes/stem_unpack2.py [budget seconds]      -> gpurun_out/stem_unpack2.txt"""
 import ctypes, os, re, sys, time
 sys.path.insert(0, os.getcwd())
-from tools import stem_unpack as U
+from tools.probes import stem_unpack as U
 from tools import benchlib
 T0 = time.time(); BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 420.0
 log = open("gpurun_out/stem_unpack2.txt", "w")

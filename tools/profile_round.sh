@@ -5,6 +5,7 @@
 # 2) separate PMC passes of the same workload: matrix pipe / LDS / wave states, FETCH_SIZE, WRITE_SIZE (never combined with other traces)
 # 3) the dominant kernel's ablation timings and per-step clock stamps (tools/t64_bench.py)
 # 4) bench.py JSON lines for every workload, the host-path sweep
+# (tools/collect_profiles.sh <tag> copies the summaries into profiles/<tag>/; tools/round_close.sh runs the GPU suite + smoke())
 set -u
 TAG=${1:-r3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -16,6 +17,11 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- p
 cp $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_4k.csv 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt1080 -- python $ROOT/tools/prof_run.py --workload 1080p --pairs 8 > $OUT/kt1080.log 2>&1
 cp $(find $OUT/kt1080 -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_1080p.csv 2>/dev/null
+for wl in v23-1080p 4k-tta; do      # BASELINE configs 2 and 5
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$wl -- python $ROOT/tools/prof_run.py --workload $wl --pairs 4 > $OUT/kt_$wl.log 2>&1
+    cp $(find $OUT/kt_$wl -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_${wl//-/_}.csv 2>/dev/null
+    rm -rf $OUT/kt_$wl
+done
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
     name=$(echo $pass | cut -d' ' -f1)
     timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$name -- python $ROOT/tools/prof_run.py --workload 4k --pairs 3 > $OUT/pmc_$name.log 2>&1
