@@ -76,7 +76,10 @@ __device__ __forceinline__ float warp_lerp(float v0, float v1, float v2, float v
 
 // The two taps of a row are neighbours - or the same pixel where the sample leaves the frame - so each row is ONE 8-byte load at column
 // xb = min(x0, w - 2) and a select (w >= 2: padded widths are multiples of 32): half the gather instructions of four dword loads, same values.
-__device__ __forceinline__ float3 warp_rgbx(const uint32_t* __restrict__ img, int x, int y, float fx, float fy, int w, int h) {
+// In two halves, so that a kernel can put other work between the loads and their use (stem_rs.h): warp_issue() computes the taps and starts
+// the two loads, warp_finish() does the arithmetic.  warp_rgbx() is the two back to back.
+struct WarpLoads { uint2 r0, r1; float alpha, beta; bool l0, l1; };
+__device__ __forceinline__ WarpLoads warp_issue(const uint32_t* __restrict__ img, int x, int y, float fx, float fy, int w, int h) {
     const float sample_x = (float)x + fx;
     const float sample_y = (float)y + fy;
     int x0 = (int)floorf(sample_x);
@@ -86,15 +89,21 @@ __device__ __forceinline__ float3 warp_rgbx(const uint32_t* __restrict__ img, in
     y0 = min(max(y0, 0), h - 1);
     x1 = min(max(x1, 0), w - 1);
     y1 = min(max(y1, 0), h - 1);
-    const float alpha = sample_x - (float)x0;
-    const float beta = sample_y - (float)y0;
+    WarpLoads t;
+    t.alpha = sample_x - (float)x0;
+    t.beta = sample_y - (float)y0;
     const int xb = min(x0, w - 2);
-    uint2 r0, r1;
-    __builtin_memcpy(&r0, __builtin_assume_aligned(img + (y0 * w + xb), 4), 8);
-    __builtin_memcpy(&r1, __builtin_assume_aligned(img + (y1 * w + xb), 4), 8);
-    const bool l0 = x0 == xb, l1 = x1 == xb;
-    const float3 a = unpack_rgb(l0 ? r0.x : r0.y), b = unpack_rgb(l1 ? r0.x : r0.y), c = unpack_rgb(l0 ? r1.x : r1.y), d = unpack_rgb(l1 ? r1.x : r1.y);
-    return make_float3(warp_lerp(a.x, b.x, c.x, d.x, alpha, beta), warp_lerp(a.y, b.y, c.y, d.y, alpha, beta), warp_lerp(a.z, b.z, c.z, d.z, alpha, beta));
+    __builtin_memcpy(&t.r0, __builtin_assume_aligned(img + (y0 * w + xb), 4), 8);
+    __builtin_memcpy(&t.r1, __builtin_assume_aligned(img + (y1 * w + xb), 4), 8);
+    t.l0 = x0 == xb; t.l1 = x1 == xb;
+    return t;
+}
+__device__ __forceinline__ float3 warp_finish(const WarpLoads& t) {
+    const float3 a = unpack_rgb(t.l0 ? t.r0.x : t.r0.y), b = unpack_rgb(t.l1 ? t.r0.x : t.r0.y), c = unpack_rgb(t.l0 ? t.r1.x : t.r1.y), d = unpack_rgb(t.l1 ? t.r1.x : t.r1.y);
+    return make_float3(warp_lerp(a.x, b.x, c.x, d.x, t.alpha, t.beta), warp_lerp(a.y, b.y, c.y, d.y, t.alpha, t.beta), warp_lerp(a.z, b.z, c.z, d.z, t.alpha, t.beta));
+}
+__device__ __forceinline__ float3 warp_rgbx(const uint32_t* __restrict__ img, int x, int y, float fx, float fy, int w, int h) {
+    return warp_finish(warp_issue(img, x, y, fx, fy, w, h));
 }
 
 // generic rife.Warp on planar CHW fp32 (per-kernel parity test entry point; v2.3 context features)

@@ -28,6 +28,7 @@
 #include "elementwise.h"
 #include "elementwise_v2.h"
 #include "stem_fused.h"
+#include "stem_rs.h"
 #include "head_h2.h"
 #include "conv_t64.h"
 #include "conv_row.h"
@@ -913,6 +914,9 @@ struct rife_hip {
     bool t64 = true;
     // block-3 trunk on the row-streaming kernel (conv_rs.h) instead of conv_t64 (RIFE_HIP_RS=0 at create time: A/B, bit-equality test)
     bool rs = true;
+    // block 3: block-input assembly + both stem convolutions in one row-streaming kernel (stem_rs.h) instead of stem0_fused_kernel + conv_h2s2_kernel
+    // (RIFE_HIP_STEM_RS=0 at create time: A/B, the comparison test)
+    bool stem_rs = true;
     // RIFE_HIP_FUSE_FLOW=1 (A/B, parity taps): the flow updates after blocks 1 and 2 inside the fused stems of blocks 2 and 3 (stem_fused.h UPD)
     // instead of two k_flow_update launches.  Bit-identical, and measured SLOWER at 4K (432 vs 442 frames/s, same call): the update kernels
     // run at 6 - 7 TB/s, the stems are bound by gather latency and VALU issue and every load added to them costs more than the pass it removes
@@ -1063,6 +1067,37 @@ static int run_assemble(const rife_hip& E, Ctx& c, int b, float timestep, const 
     return 0;
 }
 
+// block 3 of rife-v4.6: frames + F, M -> the first S16 trunk tensor (stem_rs.h); two workgroups per CU, all resident
+static int launch_stem_rs(const rife_hip& E, Ctx& c, const rife_hip::Block& B, unsigned char* out, int Hq, int Wq, float timestep, const float* tsp) {
+    {
+        int dev = 0; (void)hipGetDevice(&dev);
+        static std::mutex mu; static std::map<int, bool> done;
+        std::lock_guard<std::mutex> g(mu);
+        if (!done[dev]) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_rs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, SRS_LDS));
+            done[dev] = true;
+        }
+    }
+    const S16Geom G(Hq, Wq);
+    StemRsArgs a;
+    a.img0 = c.img0; a.img1 = c.img1; a.F = c.F; a.M = c.M;
+    a.w0 = B.stem0.d_wh; a.bias0 = B.stem0.d_bias; a.slope0 = B.stem0.d_slope;
+    a.w1 = B.stem1.d_whp; a.bias1 = B.stem1.d_bias; a.slope1 = B.stem1.d_slope;
+    a.out = out; a.timestep = timestep; a.tsp = tsp; a.wp = c.wp; a.hp = c.hp; a.Hq = Hq; a.Wq = Wq; a.pitch = G.pitch; a.plane = G.plane();
+    a.nunits = ((Wq + SRS_SW - 1) / SRS_SW) * Hq;
+    const int nwg = std::min(2 * device_cus(), a.nunits);
+    hipLaunchKernelGGL((stem_rs_kernel<0>), dim3(nwg), dim3(SRS_NTHR), SRS_LDS, c.stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("stem_rs launch: ") + hipGetErrorString(e));
+    return 0;
+}
+// can block b's two stems run as one stem_rs launch?  (64-channel block 3 at scale 1 on the S16 trunk, 12 -> 32 -> 64 channels, uniform shapes)
+static bool block_on_stem_rs(const rife_hip& E, const Ctx& c, int b) {
+    const rife_hip::Block& B = E.blk[b];
+    return E.stem_rs && b == 3 && B.scale == 1 && B.c == 64 && B.stem0.d_wh && B.stem0.cout == 32 && B.stem1.d_whp && B.stem1.cout == 64 &&
+           g_trunk_h2 && g_fuse_stem && (c.hp % 4) == 0 && (c.wp % 4) == 0;
+}
+
 // One IFBlock: stems, 8 residual convs, head -> flow[b]   (flownet.param:11-46, 63-98, 116-151, 166-201)
 // which trunk kernel serves block b at this frame size: 0 = conv_t64 / conv_rs (fine blocks), 1 = conv_row (coarse blocks, small grids)
 static bool block_on_row_kernel(const rife_hip& E, const Ctx& c, int b) {
@@ -1115,7 +1150,9 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
     const int s = B.scale, Hb = c.hp / s, Wb = c.wp / s;
     const int xin_ld = b == 0 ? 8 : 16;
     int rc;
-    if (!(phases & PH_STEMS)) goto after_stem0;
+    // block 3: one row-streaming kernel for the assembly and both stems (stem_rs.h), launched where stem 1 used to be
+    const bool srs = !upd_flow && block_on_stem_rs(E, c, b) && block_on_s16(E, c, b);
+    if (!(phases & PH_STEMS) || srs) goto after_stem0;
     if (b == 0 && (rc = run_assemble(E, c, 0, timestep, tsp))) return rc;
     if (b > 0 && B.stem0.d_wh && g_trunk_h2 && g_fuse_stem) {
         // assemble + stem-0 in one kernel (stem_fused.h): the block input never goes to HBM
@@ -1172,7 +1209,10 @@ after_stem0:
         unsigned char* const PB = c.P[b][1];
         // stem-1 writes the first S16 tensor, eight persistent trunk launches ping-pong between the two, the head reads the last one
         const S16Geom G(Ht, Wt);
-        if (phases & PH_STEMS) {
+        if ((phases & PH_STEMS) && srs) {
+            Timed t(E.prof, "stems_b3", B.stem0.flops_per_pixel * (Hb / 2) * (Wb / 2) + B.stem1.flops_per_pixel * Ht * Wt, st);
+            if ((rc = launch_stem_rs(E, c, B, PA, Ht, Wt, timestep, tsp))) return rc;
+        } else if (phases & PH_STEMS) {
             Timed t(E.prof, B.stem1.cls, B.stem1.flops_per_pixel * Ht * Wt, st);
             if ((rc = launch_conv(B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {reinterpret_cast<float*>(PA), B.c, 0}, nullptr, st, nullptr, G.pitch, G.plane()))) return rc;
         }
@@ -2075,6 +2115,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     E->frame_pool->gpuid = gpuid;
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_RS"); E->rs = !(e && e[0] == '0'); }
+    { const char* e = getenv("RIFE_HIP_STEM_RS"); E->stem_rs = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_FUSE_FLOW"); E->fuse_flow = e && e[0] == '1'; if (E->fuse_flow) g_fuse_flow_buffers = true; }
     return E;
 }

@@ -1,0 +1,81 @@
+"""stem_rs_kernel (csrc/stem_rs.h): block 3's input assembly + both stride-2 stem convolutions in one row-streaming kernel, against the
+two-kernel sequence it replaces (stem0_fused_kernel<1, 1, 256> + conv_h2s2_kernel<2, true>; RIFE_HIP_STEM_RS=0) and against the oracle.
+
+Same gather code (assemble_pixel's arithmetic in two halves), same products; stem 1 adds two K partial sums instead of running one chain over
+both 16-channel chunks, so the two engines agree to summation-order noise: block-3 flows to 1e-4 (values of O(1) px), frames within 1 LSB with
+very few channels touched.  Flows that leave the frame by hundreds of pixels are INJECTED for blocks 0..2 (the reference's Extractor does the
+same for its TTA passes, src/rife.cpp:2653-2669) so that the clamps of the gather, the zero padding of both convolutions and the strip / range
+boundaries of the kernel all see real data.  models/rife-v4.6/flownet.param:160-168."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tools import gen_frames
+from test_gpu_gather import injected_flows
+
+pytestmark = pytest.mark.gpu
+amd = importlib.import_module("rife-ncnn-vulkan_amd")
+
+
+def _engine(d, on, **kw):
+    old = os.environ.get("RIFE_HIP_STEM_RS")
+    os.environ["RIFE_HIP_STEM_RS"] = "1" if on else "0"                 # read at create time
+    try:
+        g = amd.RIFE(0, rife_v4=True, **kw); g.load(d)
+    finally:
+        if old is None: del os.environ["RIFE_HIP_STEM_RS"]
+        else: os.environ["RIFE_HIP_STEM_RS"] = old
+    return g
+
+
+@pytest.fixture(scope="module")
+def pair(modeldirs):
+    d = modeldirs["rife-v4.6"]
+    return _engine(d, True), _engine(d, False)
+
+
+SIZES = [(256, 192, 1), (640, 360, 2), (333, 241, 3), (100, 60, 4), (33, 47, 5), (1, 1, 6), (130, 9, 7), (1000, 520, 8), (1920, 1080, 9)]
+
+
+@pytest.mark.parametrize("w,h,seed", SIZES)
+def test_block3_flow_matches_the_two_kernel_sequence(pair, w, h, seed):
+    new, old = pair
+    a, c = gen_frames.noise_pair(w, h, seed) if seed % 2 else gen_frames.smooth_pair(w, h, seed)
+    inj = injected_flows(w, h, 400 + seed, 3)
+    f1, f0 = new.v4_extract_flow(a, c, 0.4, 3, inj), old.v4_extract_flow(a, c, 0.4, 3, inj)
+    d = np.abs(f1 - f0)
+    assert d.max() < 1e-4 * max(1.0, float(np.abs(f0).max())), "flow3 differs by %g (|flow| up to %g) at %s" % (float(d.max()), float(np.abs(f0).max()), np.unravel_index(np.argmax(d), d.shape))
+    # and on the flows the model itself produces
+    d2 = np.abs(new.v4_extract_flow(a, c, 0.6, 3) - old.v4_extract_flow(a, c, 0.6, 3))
+    assert d2.max() < 1e-4, float(d2.max())
+
+
+@pytest.mark.parametrize("w,h,seed", SIZES + [(3840, 2160, 10)])
+def test_frames_match_and_are_deterministic(pair, w, h, seed):
+    new, old = pair
+    if w * h > 4000000: a, c = gen_frames.tiled_real_pair(6)
+    else: a, c = gen_frames.smooth_pair(w, h, 20 + seed)
+    for x, y, t in ((a, c, 0.5), (c, a, 0.3)):                          # the second call runs on a used workspace
+        p1, p0 = new.process(x, y, t), old.process(x, y, t)
+        d = np.abs(p1.astype(np.int32) - p0.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, "%dx%d: %d of %d bytes differ, max %d" % (w, h, int((d > 0).sum()), d.size, int(d.max()))
+    x = new.process(a, c, 0.5)
+    for _ in range(3):
+        assert np.array_equal(x, new.process(a, c, 0.5)), "stem_rs_kernel is not run-to-run identical"
+
+
+@pytest.mark.parametrize("w,h,seed", [(640, 360, 31), (333, 241, 32), (1920, 1080, 33)])
+def test_against_the_oracle_on_injected_flows(pair, modeldirs, w, h, seed):
+    """The plain pass on three injected flows far outside the frame: stem_rs's gather and the fused tail, within 1 LSB of the oracle."""
+    new, _ = pair
+    o = pyoracle.OracleRIFE(rife_v4=True); o.load(modeldirs["rife-v4.6"])
+    a, c = gen_frames.smooth_pair(w, h, seed) if w < 1000 else gen_frames.tiled_real_pair(3)
+    inj = injected_flows(w, h, 500 + seed, 3)
+    wantf = o.v4_extract(a, c, 0.45, "out0", flows=inj)[:, :h, :w]
+    want8 = np.clip((wantf * 255.0 + 0.5).astype(np.int32), 0, 255).transpose(1, 2, 0)
+    got8 = new.v4_process_injected(a, c, 0.45, inj).astype(np.int32)
+    dd = np.abs(got8 - want8)
+    assert dd.max() <= 1 and (dd > 0).mean() < 1e-3, "%d of %d bytes differ, max %d" % (int((dd > 0).sum()), dd.size, int(dd.max()))
