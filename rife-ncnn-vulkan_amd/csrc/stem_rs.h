@@ -138,7 +138,11 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
             }
             if (wr) { *reinterpret_cast<f16x8*>(d + ((1 ^ gsw) << 4)) = h1; *reinterpret_cast<f16x8*>(d + SRS_A_HL + ((1 ^ gsw) << 4)) = l1; }
         }
-        const float3 w0 = warp_finish(t.a), w1 = warp_finish(t.b);
+        __builtin_amdgcn_sched_barrier(0);
+        const float3 w0 = warp_finish(t.a);
+        __builtin_amdgcn_sched_barrier(0);
+        const float3 w1 = warp_finish(t.b);
+        __builtin_amdgcn_sched_barrier(0);
         const float O[8] = {w0.x, w0.y, w0.z, w1.x, w1.y, w1.z, timestep, fm.m};
         f16x8 h0, l0;
 #pragma unroll
@@ -151,7 +155,9 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
     };
 
     // stem 0: half-resolution row h, columns tile * 32 + li of the strip -> ring B (zeros outside the half-resolution tensor: stem 1's padding)
-    auto stem0_job = [&](int strip, int h, int tile) {
+    // (half, li as parameters: the main loop passes copies the compiler cannot see through, so that it does not hoist the dozens of loop-invariant
+    // LDS addresses out of the loop - and then spill them: the budget is 128 registers)
+    auto stem0_job = [&](int strip, int h, int tile, const int half, const int li) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -196,6 +202,7 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
             unsigned char* const dq = d + (q >> 1) * (2 * SRS_B_HL) + (((q & 1) ^ sw) << 4);
             *reinterpret_cast<f16x4*>(dq) = hi4;
             *reinterpret_cast<f16x4*>(dq + SRS_B_HL) = lo4;
+            __builtin_amdgcn_sched_barrier(0);                           // one quad at a time: the register budget is 128
         }
     };
 
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
         const SrsTaps t = issue_taps(u.strip, rb, fm);
         finish(u.strip, rb, fm, t, 3 * SRS_AW);
         __syncthreads();
-        if (wv == 4 || wv == 5) stem0_job(u.strip, 2 * u.q - 1, wv - 4);
+        if (wv == 4 || wv == 5) stem0_job(u.strip, 2 * u.q - 1, wv - 4, half, li);
         __syncthreads();
     };
 
@@ -225,6 +232,8 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
     __syncthreads();
 
     for (int k = 0; k < S; k++) {
+        int hf = half, l32 = li, ln = lane;
+        asm volatile("" : "+v"(hf), "+v"(l32), "+v"(ln));               // opaque copies of the lane coordinates (see stem0_job)
         // ring A holds the rows of step k (cur).  Loads of the steps after it first: they fly during the matrix phases.
         SrsTaps tp_next;
         SrsFM fm_nn;
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (has_next) tp_next = issue_taps(nxt.strip, 4 * nxt.q, fm_next);
         if (has_nn) { fresh_nn = nn.advance(a.Hq); fm_nn = load_fm(nn.strip, 4 * nn.q); }
 
-        if (wv >= 4) stem0_job(cur.strip, 2 * cur.q + ((wv - 4) >> 1), (wv - 4) & 1);
+        if (wv >= 4) stem0_job(cur.strip, 2 * cur.q + ((wv - 4) >> 1), (wv - 4) & 1, hf, l32);
         __syncthreads();
 
         f32x16 acc;
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
             for (int dy = 0; dy < 3; dy++) rowb[dy] = (unsigned)(SRS_LDS_B + slot3(2 * cur.q - 1 + dy) * SRS_B_ROW + ck * (2 * SRS_B_HL));
             unsigned colb[3];
 #pragma unroll
-            for (int dx = 0; dx < 3; dx++) { const int m = li + (dx >> 1); colb[dx] = (unsigned)((dx & 1) * SRS_B_PAR + m * 32 + ((half ^ ((m >> 3) & 1)) << 4)); }
+            for (int dx = 0; dx < 3; dx++) { const int m = l32 + (dx >> 1); colb[dx] = (unsigned)((dx & 1) * SRS_B_PAR + m * 32 + ((hf ^ ((m >> 3) & 1)) << 4)); }
             f16x8 ah[2], al[2];
             ah[0] = *reinterpret_cast<const f16x8*>(ldsb + rowb[0] + colb[0]);
             al[0] = *reinterpret_cast<const f16x8*>(ldsb + rowb[0] + colb[0] + SRS_B_HL);
@@ -262,24 +271,28 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (ck == 1) {
-                f32x4* const sd = reinterpret_cast<f32x4*>(ldsb + SRS_LDS_STG + n * 4096 + lane * 16);
+                f32x4* const sd = reinterpret_cast<f32x4*>(ldsb + SRS_LDS_STG + n * 4096 + ln * 16);
 #pragma unroll
                 for (int q = 0; q < 4; q++) sd[q * 64] = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
             }
         }
+        // waves 4-7 are done with their matrix work: they finish their pixel of the next step while waves 0-3 run stem 1 (ring A's rows of step
+        // k are dead since the barrier above; a strip change comes with a pre-step that everybody executes together below)
+        const bool early = has_next && !fresh_next;
+        if (wv >= 4 && early) finish(nxt.strip, 4 * nxt.q, fm_next, tp_next, 4 * SRS_AW);
         __syncthreads();
         if (wv < 2) {
             const int n = wv;
-            const f32x4* const sd = reinterpret_cast<const f32x4*>(ldsb + SRS_LDS_STG + n * 4096 + lane * 16);
-            const int ox = SRS_SW * cur.strip + li;
-            const bool pok = li < SRS_SW && ox < a.Wq;
+            const f32x4* const sd = reinterpret_cast<const f32x4*>(ldsb + SRS_LDS_STG + n * 4096 + ln * 16);
+            const int ox = SRS_SW * cur.strip + l32;
+            const bool pok = l32 < SRS_SW && ox < a.Wq;
             // a lane holds channels 32 n + 16 half .. + 15 of pixel ox = the pixel's entry of chunk 2 n + half: four 8-byte pieces per plane
-            unsigned char* const o = a.out + (size_t)(2 * half + 4 * n) * a.plane + ((size_t)(cur.q + 1) * a.pitch + ox + 1) * 32;
+            unsigned char* const o = a.out + (size_t)(2 * hf + 4 * n) * a.plane + ((size_t)(cur.q + 1) * a.pitch + ox + 1) * 32;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const f32x4 p = sd[q * 64];
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbs + 64 + n * 32 + 16 * half + 4 * q);
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(lbs + 128 + n * 32 + 16 * half + 4 * q);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbs + 64 + n * 32 + 16 * hf + 4 * q);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(lbs + 128 + n * 32 + 16 * hf + 4 * q);
                 f16x4 hi4, lo4;
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
@@ -289,11 +302,12 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
                     hi4[kk] = hh; lo4[kk] = (_Float16)(v - (float)hh);
                 }
                 if (pok) { *reinterpret_cast<f16x4*>(o + 8 * q) = hi4; *reinterpret_cast<f16x4*>(o + a.plane + 8 * q) = lo4; }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (has_next) {
             if (fresh_next) prestep(nxt);
-            finish(nxt.strip, 4 * nxt.q, fm_next, tp_next, 4 * SRS_AW);
+            if (wv < 4 || fresh_next) finish(nxt.strip, 4 * nxt.q, fm_next, tp_next, 4 * SRS_AW);
         }
         __syncthreads();
         cur = nxt; nxt = nn; fm_next = fm_nn; has_next = has_nn; fresh_next = fresh_nn;
