@@ -715,6 +715,87 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
     return rc;
 }
 
+// bench-only: stem_rs_kernel (stem_rs.h) on a wp x hp frame with random frames / flows / weights, variant = SRS_* ablation bits | 0x100 * g
+// (g > 0: g workgroups per CU instead of two)
+int rife_hip_bench_stem_rs(int gpuid, int wp, int hp, int variant, int iters, float* ms_out, long long* stamps_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    const size_t P = (size_t)wp * hp;
+    const int Hq = hp / 4, Wq = wp / 4;
+    const S16Geom G(Hq, Wq);
+    uint32_t lcg = 777u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((int)(lcg >> 9) - (1 << 22)) / (float)(1 << 22); };   // [-1, 1)
+    std::vector<uint32_t> himg(P); for (auto& v : himg) { lcg = lcg * 1664525u + 1013904223u; v = lcg & 0xffffffu; }
+    std::vector<float> hF(P * 4), hM(P), hb(64 + 64);
+    for (auto& v : hF) v = rnd() * 6.f;
+    for (auto& v : hM) v = rnd();
+    for (auto& v : hb) v = rnd() * 0.1f;
+    std::vector<_Float16> hw0(9 * 2 * 32 * 8), hw1(2 * 9 * 2 * 64 * 8);
+    for (auto& v : hw0) v = (_Float16)(rnd() * 0.1f);
+    for (auto& v : hw1) v = (_Float16)(rnd() * 0.05f);
+    uint32_t *i0 = nullptr, *i1 = nullptr; float4* F = nullptr; float *M = nullptr, *bias = nullptr, *slope = nullptr; void *w0 = nullptr, *w1 = nullptr; unsigned char* out = nullptr;
+    HIPCHK(hipMalloc(&i0, P * 4)); HIPCHK(hipMalloc(&i1, P * 4)); HIPCHK(hipMalloc(&F, P * 16)); HIPCHK(hipMalloc(&M, P * 4));
+    HIPCHK(hipMalloc(&bias, 512)); HIPCHK(hipMalloc(&slope, 512)); HIPCHK(hipMalloc(&w0, hw0.size() * 2)); HIPCHK(hipMalloc(&w1, hw1.size() * 2)); HIPCHK(hipMalloc(&out, G.bytes(64)));
+    HIPCHK(hipMemcpy(i0, himg.data(), P * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(i1, himg.data(), P * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(F, hF.data(), P * 16, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(M, hM.data(), P * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(bias, hb.data(), 512, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(slope, hb.data(), 512, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w0, hw0.data(), hw0.size() * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(w1, hw1.data(), hw1.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(out, 0, G.bytes(64)));
+    StemRsArgs a;
+    a.img0 = i0; a.img1 = i1; a.F = F; a.M = M; a.w0 = w0; a.bias0 = bias; a.slope0 = slope; a.w1 = w1; a.bias1 = bias + 32; a.slope1 = slope + 32;
+    a.out = out; a.timestep = 0.5f; a.tsp = nullptr; a.wp = wp; a.hp = hp; a.Hq = Hq; a.Wq = Wq; a.pitch = G.pitch; a.plane = G.plane();
+    a.nunits = ((Wq + SRS_SW - 1) / SRS_SW) * Hq;
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpuid));
+    const int per = (variant >> 8) & 0xff;
+    const int nwg = std::min((per ? per : 2) * cus, a.nunits);
+    long long* dst = nullptr;
+    HIPCHK(hipMalloc(&dst, (size_t)nwg * 64 * 8));
+    HIPCHK(hipMemset(dst, 0, (size_t)nwg * 64 * 8));
+    a.stamps = dst;
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](auto kfn) -> int {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SRS_LDS));
+        for (int i = 0; i < 2; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(SRS_NTHR), SRS_LDS, 0, a);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(SRS_NTHR), SRS_LDS, 0, a);
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    switch (variant & 0xff) {
+        case 0: rc = run(stem_rs_kernel<0>); break;
+        case SRS_NOTAPS: rc = run(stem_rs_kernel<SRS_NOTAPS>); break;
+        case SRS_NOFM: rc = run(stem_rs_kernel<SRS_NOFM>); break;
+        case SRS_NOTAPS | SRS_NOFM: rc = run(stem_rs_kernel<SRS_NOTAPS | SRS_NOFM>); break;
+        case SRS_NOMATH: rc = run(stem_rs_kernel<SRS_NOMATH>); break;
+        case SRS_NOSTORE: rc = run(stem_rs_kernel<SRS_NOSTORE>); break;
+        case SRS_NOFINISH: rc = run(stem_rs_kernel<SRS_NOFINISH>); break;
+        case SRS_NOTAPS | SRS_NOFM | SRS_NOFINISH: rc = run(stem_rs_kernel<SRS_NOTAPS | SRS_NOFM | SRS_NOFINISH>); break;
+        case SRS_NOTAPS | SRS_NOFM | SRS_NOFINISH | SRS_NOSTORE: rc = run(stem_rs_kernel<SRS_NOTAPS | SRS_NOFM | SRS_NOFINISH | SRS_NOSTORE>); break;
+        case SRS_NOTAPS | SRS_NOFM | SRS_NOMATH | SRS_NOSTORE: rc = run(stem_rs_kernel<SRS_NOTAPS | SRS_NOFM | SRS_NOMATH | SRS_NOSTORE>); break;
+        case SRS_CLK: rc = run(stem_rs_kernel<SRS_CLK>); break;
+        case SRS_CLK | SRS_NOTAPS | SRS_NOFM | SRS_NOFINISH | SRS_NOSTORE: rc = run(stem_rs_kernel<SRS_CLK | SRS_NOTAPS | SRS_NOFM | SRS_NOFINISH | SRS_NOSTORE>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    if (rc == 0 && stamps_out && (variant & SRS_CLK)) {     // mean over the workgroups of the LAST launch, per wave and phase, in cycles per step
+        std::vector<long long> hs((size_t)nwg * 64);
+        HIPCHK(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
+        const double steps = (double)a.nunits / nwg;
+        for (int wvi = 0; wvi < 8; wvi++)
+            for (int ph = 0; ph < 8; ph++) {
+                double sum = 0;
+                for (int g = 0; g < nwg; g++) sum += (double)hs[((size_t)g * 8 + wvi) * 8 + ph];
+                stamps_out[wvi * 8 + ph] = (long long)(sum / nwg / steps);
+            }
+    }
+    (void)hipFree(dst);
+    (void)hipFree(i0); (void)hipFree(i1); (void)hipFree(F); (void)hipFree(M); (void)hipFree(bias); (void)hipFree(slope); (void)hipFree(w0); (void)hipFree(w1); (void)hipFree(out);
+    return rc;
+}
+
 // bench-only: ablations of stem0_fused_kernel<1,1> on a wp x hp frame (variant = ABL bits, see stem_fused.h)
 int rife_hip_bench_stemf(int gpuid, int wp, int hp, int variant, int iters, float* ms_out) {
     int rc;

@@ -93,8 +93,11 @@ __device__ __forceinline__ WarpLoads warp_issue(const uint32_t* __restrict__ img
     t.alpha = sample_x - (float)x0;
     t.beta = sample_y - (float)y0;
     const int xb = min(x0, w - 2);
-    __builtin_memcpy(&t.r0, __builtin_assume_aligned(img + (y0 * w + xb), 4), 8);
-    __builtin_memcpy(&t.r1, __builtin_assume_aligned(img + (y1 * w + xb), 4), 8);
+    // byte offsets as unsigned 32-bit values (frames stay far below 4 GB): base pointer in scalar registers + one VGPR per load instead of a
+    // 64-bit address computed per lane
+    const unsigned char* const base = reinterpret_cast<const unsigned char*>(img);
+    __builtin_memcpy(&t.r0, __builtin_assume_aligned(base + (unsigned)(y0 * w + xb) * 4u, 4), 8);
+    __builtin_memcpy(&t.r1, __builtin_assume_aligned(base + (unsigned)(y1 * w + xb) * 4u, 4), 8);
     t.l0 = x0 == xb; t.l1 = x1 == xb;
     return t;
 }

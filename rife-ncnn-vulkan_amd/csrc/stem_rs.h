@@ -58,7 +58,11 @@ struct StemRsArgs {
     int Hq, Wq;                  // valid pixels of out
     int pitch; unsigned plane;   // S16 geometry of out
     int nunits;                  // strips x Hq
+    long long* stamps = nullptr; // bench builds (TAG & SRS_CLK): [workgroup][wave 8][phase 8] shader cycles summed over the workgroup's steps
 };
+
+// bench-only ablation bits of TAG (timing experiments through rife_hip_bench_stem_rs; results are garbage).  The product instantiates TAG = 0.
+enum { SRS_NOTAPS = 1, SRS_NOFM = 2, SRS_NOMATH = 4, SRS_NOSTORE = 8, SRS_NOFINISH = 16, SRS_CLK = 32 };
 
 struct SrsCursor {
     int strip, q;
@@ -67,6 +71,10 @@ struct SrsCursor {
 };
 struct SrsFM { float4 f; float m; };
 struct SrsTaps { WarpLoads a, b; };
+
+// workgroup barrier for LDS traffic only: __syncthreads() would also wait for every global load in flight (vmcnt(0)) - the prefetched
+// F, M and image taps this kernel keeps in flight ACROSS its barriers
+#define SRS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 template <int TAG>
 __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem_rs_kernel(StemRsArgs a) {
@@ -110,14 +118,22 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
     auto load_fm = [&](int strip, int rb) -> SrsFM {
         const int by = rb + grow, bx = 4 * SRS_SW * strip - 3 + gcol;
         const int cx = min(max(bx, 0), Wb - 1), cy = min(max(by, 0), Hb - 1);
-        const size_t i = (size_t)cy * a.wp + cx;
-        SrsFM r; r.f = a.F[i]; r.m = a.M[i];
+        const unsigned i = (unsigned)(cy * a.wp + cx);                   // 32-bit offsets: scalar base + one VGPR (F: 16 B x 4K pixels = 134 MB)
+        SrsFM r;
+        if (RIFE_ABL(TAG & SRS_NOFM)) { r.f = make_float4(0.25f * (float)(bx & 7), -0.5f, 1.5f, 0.75f); r.m = 0.1f; return r; }
+        r.f = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(a.F) + i * 16u);
+        r.m = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.M) + i * 4u);
         return r;
     };
     auto issue_taps = [&](int strip, int rb, const SrsFM& fm) -> SrsTaps {
         const int by = rb + grow, bx = 4 * SRS_SW * strip - 3 + gcol;
         const int cx = min(max(bx, 0), Wb - 1), cy = min(max(by, 0), Hb - 1);
         SrsTaps t;
+        if (RIFE_ABL(TAG & SRS_NOTAPS)) {
+            t.a.r0 = t.a.r1 = t.b.r0 = t.b.r1 = make_uint2((unsigned)cx * 0x10101u, (unsigned)cy * 0x10101u);
+            t.a.alpha = t.b.alpha = fm.f.x - floorf(fm.f.x); t.a.beta = t.b.beta = fm.f.y - floorf(fm.f.y); t.a.l0 = t.b.l0 = true; t.a.l1 = t.b.l1 = false;
+            return t;
+        }
         t.a = warp_issue(a.img0, cx, cy, fm.f.x, fm.f.y, a.wp, a.hp);
         t.b = warp_issue(a.img1, cx, cy, fm.f.z, fm.f.w, a.wp, a.hp);
         return t;
@@ -126,6 +142,7 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
     auto finish = [&](int strip, int rb, const SrsFM& fm, const SrsTaps& t, int nactive) {
         const int by = rb + grow, bx = 4 * SRS_SW * strip - 3 + gcol;
         const bool in = by >= 0 && by < Hb && bx >= 0 && bx < Wb;
+        if (RIFE_ABL(TAG & SRS_NOFINISH)) { if (fm.m == 123.456f && t.a.alpha == 7.f && t.b.r0.x == 99u) ldsb[tid] = 1; return; }
         unsigned char* const d = ldsb + slot5(by) * SRS_A_ROW + gdst;
         const bool wr = tid < nactive;
         {   // channels 8 .. 11 (F) + four zeros first: the F, M registers die here
@@ -168,17 +185,22 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
         unsigned colb[3];
 #pragma unroll
         for (int dx = 0; dx < 3; dx++) { const int m = c + (dx >> 1); colb[dx] = (unsigned)((dx & 1) * SRS_A_PAR + m * 32 + ((half ^ ((m >> 3) & 1)) << 4)); }
-        f16x8 ah[2], al[2];                                              // fragments one tap ahead of their MFMAs, no more (registers)
-        ah[0] = *reinterpret_cast<const f16x8*>(ldsb + rowb[0] + colb[0]);
-        al[0] = *reinterpret_cast<const f16x8*>(ldsb + rowb[0] + colb[0] + SRS_A_HL);
+        f16x8 ah[3], al[3];                                              // fragments two taps ahead of their MFMAs (LDS latency > one tap's 64 cycles), no more: registers
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            ah[t] = *reinterpret_cast<const f16x8*>(ldsb + rowb[t / 3] + colb[t % 3]);
+            al[t] = *reinterpret_cast<const f16x8*>(ldsb + rowb[t / 3] + colb[t % 3] + SRS_A_HL);
+        }
 #pragma unroll
         for (int t = 0; t < 9; t++) {
-            if (t + 1 < 9) {
-                ah[(t + 1) & 1] = *reinterpret_cast<const f16x8*>(ldsb + rowb[(t + 1) / 3] + colb[(t + 1) % 3]);
-                al[(t + 1) & 1] = *reinterpret_cast<const f16x8*>(ldsb + rowb[(t + 1) / 3] + colb[(t + 1) % 3] + SRS_A_HL);
+            if (t + 2 < 9) {
+                ah[(t + 2) % 3] = *reinterpret_cast<const f16x8*>(ldsb + rowb[(t + 2) / 3] + colb[(t + 2) % 3]);
+                al[(t + 2) % 3] = *reinterpret_cast<const f16x8*>(ldsb + rowb[(t + 2) / 3] + colb[(t + 2) % 3] + SRS_A_HL);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[t], ah[t & 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[t], al[t & 1], acc, 0, 0, 0);
+            if (!RIFE_ABL(TAG & SRS_NOMATH)) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[t], ah[t % 3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[t], al[t % 3], acc, 0, 0, 0);
+            } else acc[t] += (float)ah[t % 3][0] + (float)al[t % 3][1] + (float)Wf[t][2];
             __builtin_amdgcn_sched_barrier(0);
         }
         const int hc = 2 * SRS_SW * strip - 1 + c;
@@ -202,7 +224,6 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
             unsigned char* const dq = d + (q >> 1) * (2 * SRS_B_HL) + (((q & 1) ^ sw) << 4);
             *reinterpret_cast<f16x4*>(dq) = hi4;
             *reinterpret_cast<f16x4*>(dq + SRS_B_HL) = lo4;
-            __builtin_amdgcn_sched_barrier(0);                           // one quad at a time: the register budget is 128
         }
     };
 
@@ -212,16 +233,16 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
         const SrsFM fm = load_fm(u.strip, rb);
         const SrsTaps t = issue_taps(u.strip, rb, fm);
         finish(u.strip, rb, fm, t, 3 * SRS_AW);
-        __syncthreads();
+        SRS_SYNC();
         if (wv == 4 || wv == 5) stem0_job(u.strip, 2 * u.q - 1, wv - 4, half, li);
-        __syncthreads();
+        SRS_SYNC();
     };
 
     SrsCursor cur; cur.init(u0, a.Hq);
     SrsFM fm_next;
     {
         const SrsFM fm0 = load_fm(cur.strip, 4 * cur.q);
-        __syncthreads();                                                 // biases in LDS
+        SRS_SYNC();                                                 // biases in LDS
         prestep(cur);
         const SrsTaps t0 = issue_taps(cur.strip, 4 * cur.q, fm0);
         finish(cur.strip, 4 * cur.q, fm0, t0, 4 * SRS_AW);
@@ -229,8 +250,38 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
     SrsCursor nxt = cur;
     bool has_next = S > 1, fresh_next = false;
     if (has_next) { fresh_next = nxt.advance(a.Hq); fm_next = load_fm(nxt.strip, 4 * nxt.q); }
-    __syncthreads();
+    SRS_SYNC();
 
+    // waves 0-1: output row q of the strip: own K partial sum + the partner's (LDS), bias, LeakyReLU, {hi, lo}, S16 entries.  A lane holds
+    // channels 32 n + 16 half .. + 15 of pixel ox = the pixel's entry of chunk 2 n + half: four 8-byte pieces per plane.
+    // (Measured and dropped: deferring this to the top of the next iteration, where these waves idle behind the stem-0 phase - 234 vs 227-231 us.)
+    auto finish_row = [&](const f32x16& acc, int strip, int q, const int half, const int li, const int lane) {
+        const int n = wv;
+        const f32x4* const sd = reinterpret_cast<const f32x4*>(ldsb + SRS_LDS_STG + n * 4096 + lane * 16);
+        const int ox = SRS_SW * strip + li;
+        bool pok = li < SRS_SW && ox < a.Wq;
+        unsigned char* const o = a.out + (size_t)(2 * half + 4 * n) * a.plane + ((size_t)(q + 1) * a.pitch + ox + 1) * 32;
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            const f32x4 p = sd[qd * 64];
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbs + 64 + n * 32 + 16 * half + 4 * qd);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(lbs + 128 + n * 32 + 16 * half + 4 * qd);
+            f16x4 hi4, lo4;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const float y = (acc[4 * qd + kk] + p[kk]) + b4[kk];
+                const float v = y < 0.f ? y * s4[kk] : y;
+                const _Float16 hh = (_Float16)v;
+                hi4[kk] = hh; lo4[kk] = (_Float16)(v - (float)hh);
+            }
+            if (RIFE_ABL(TAG & SRS_NOSTORE)) pok = pok && p[0] == 123.456f;
+            if (pok) { *reinterpret_cast<f16x4*>(o + 8 * qd) = hi4; *reinterpret_cast<f16x4*>(o + a.plane + 8 * qd) = lo4; }
+        }
+    };
+
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define SRS_STAMP(I) if (RIFE_ABL(TAG & SRS_CLK)) { const long long now_ = (long long)__builtin_readcyclecounter(); tph[I] += now_ - tprev; tprev = now_; }
+    if (RIFE_ABL(TAG & SRS_CLK)) tprev = (long long)__builtin_readcyclecounter();
     for (int k = 0; k < S; k++) {
         int hf = half, l32 = li, ln = lane;
         asm volatile("" : "+v"(hf), "+v"(l32), "+v"(ln));               // opaque copies of the lane coordinates (see stem0_job)
@@ -243,8 +294,11 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (has_next) tp_next = issue_taps(nxt.strip, 4 * nxt.q, fm_next);
         if (has_nn) { fresh_nn = nn.advance(a.Hq); fm_nn = load_fm(nn.strip, 4 * nn.q); }
 
+        SRS_STAMP(0)                                                     // load issue
         if (wv >= 4) stem0_job(cur.strip, 2 * cur.q + ((wv - 4) >> 1), (wv - 4) & 1, hf, l32);
-        __syncthreads();
+        SRS_STAMP(1)                                                     // stem 0
+        SRS_SYNC();
+        SRS_STAMP(2)                                                     // barrier
 
         f32x16 acc;
         if (wv < 4) {
@@ -257,17 +311,22 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
             unsigned colb[3];
 #pragma unroll
             for (int dx = 0; dx < 3; dx++) { const int m = l32 + (dx >> 1); colb[dx] = (unsigned)((dx & 1) * SRS_B_PAR + m * 32 + ((hf ^ ((m >> 3) & 1)) << 4)); }
-            f16x8 ah[2], al[2];
-            ah[0] = *reinterpret_cast<const f16x8*>(ldsb + rowb[0] + colb[0]);
-            al[0] = *reinterpret_cast<const f16x8*>(ldsb + rowb[0] + colb[0] + SRS_B_HL);
+            f16x8 ah[3], al[3];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                ah[t] = *reinterpret_cast<const f16x8*>(ldsb + rowb[t / 3] + colb[t % 3]);
+                al[t] = *reinterpret_cast<const f16x8*>(ldsb + rowb[t / 3] + colb[t % 3] + SRS_B_HL);
+            }
 #pragma unroll
             for (int t = 0; t < 9; t++) {
-                if (t + 1 < 9) {
-                    ah[(t + 1) & 1] = *reinterpret_cast<const f16x8*>(ldsb + rowb[(t + 1) / 3] + colb[(t + 1) % 3]);
-                    al[(t + 1) & 1] = *reinterpret_cast<const f16x8*>(ldsb + rowb[(t + 1) / 3] + colb[(t + 1) % 3] + SRS_B_HL);
+                if (t + 2 < 9) {
+                    ah[(t + 2) % 3] = *reinterpret_cast<const f16x8*>(ldsb + rowb[(t + 2) / 3] + colb[(t + 2) % 3]);
+                    al[(t + 2) % 3] = *reinterpret_cast<const f16x8*>(ldsb + rowb[(t + 2) / 3] + colb[(t + 2) % 3] + SRS_B_HL);
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[t], ah[t & 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[t], al[t & 1], acc, 0, 0, 0);
+                if (!RIFE_ABL(TAG & SRS_NOMATH)) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[t], ah[t % 3], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[t], al[t % 3], acc, 0, 0, 0);
+                } else acc[t] += (float)ah[t % 3][0] + (float)al[t % 3][1] + (float)Wf[t][2];
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (ck == 1) {
@@ -278,40 +337,27 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
         }
         // waves 4-7 are done with their matrix work: they finish their pixel of the next step while waves 0-3 run stem 1 (ring A's rows of step
         // k are dead since the barrier above; a strip change comes with a pre-step that everybody executes together below)
+        SRS_STAMP(3)                                                     // stem 1
         const bool early = has_next && !fresh_next;
         if (wv >= 4 && early) finish(nxt.strip, 4 * nxt.q, fm_next, tp_next, 4 * SRS_AW);
-        __syncthreads();
-        if (wv < 2) {
-            const int n = wv;
-            const f32x4* const sd = reinterpret_cast<const f32x4*>(ldsb + SRS_LDS_STG + n * 4096 + ln * 16);
-            const int ox = SRS_SW * cur.strip + l32;
-            const bool pok = l32 < SRS_SW && ox < a.Wq;
-            // a lane holds channels 32 n + 16 half .. + 15 of pixel ox = the pixel's entry of chunk 2 n + half: four 8-byte pieces per plane
-            unsigned char* const o = a.out + (size_t)(2 * hf + 4 * n) * a.plane + ((size_t)(cur.q + 1) * a.pitch + ox + 1) * 32;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const f32x4 p = sd[q * 64];
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbs + 64 + n * 32 + 16 * hf + 4 * q);
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(lbs + 128 + n * 32 + 16 * hf + 4 * q);
-                f16x4 hi4, lo4;
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    const float y = (acc[4 * q + kk] + p[kk]) + b4[kk];
-                    const float v = y < 0.f ? y * s4[kk] : y;
-                    const _Float16 hh = (_Float16)v;
-                    hi4[kk] = hh; lo4[kk] = (_Float16)(v - (float)hh);
-                }
-                if (pok) { *reinterpret_cast<f16x4*>(o + 8 * q) = hi4; *reinterpret_cast<f16x4*>(o + a.plane + 8 * q) = lo4; }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        SRS_STAMP(4)                                                     // early gather finish (waves 4-7)
+        SRS_SYNC();
+        SRS_STAMP(5)                                                     // barrier
+        if (wv < 2) finish_row(acc, cur.strip, cur.q, hf, l32, ln);
         if (has_next) {
             if (fresh_next) prestep(nxt);
             if (wv < 4 || fresh_next) finish(nxt.strip, 4 * nxt.q, fm_next, tp_next, 4 * SRS_AW);
         }
-        __syncthreads();
+        SRS_STAMP(6)                                                     // combine, gather finish (waves 0-3), stores
+        SRS_SYNC();
+        SRS_STAMP(7)                                                     // barrier
         cur = nxt; nxt = nn; fm_next = fm_nn; has_next = has_nn; fresh_next = fresh_nn;
     }
+    if (RIFE_ABL(TAG & SRS_CLK) && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) a.stamps[((size_t)blockIdx.x * 8 + wv) * 8 + i] = tph[i];
+    }
+#undef SRS_STAMP
 }
 
 }  // namespace rife
