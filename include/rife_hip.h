@@ -95,7 +95,9 @@ int rife_hip_v4_flow_dims(const rife_hip_t* r, int w, int h, int fi, int* channe
  * (1..3) from the unfused assembly kernel; 1: the same tensor read back through the product's fused stem kernel (one-hot weights; values
  * to 2^-22 relative); both 12 x hp/S x wp/S, n_inject = b.  what = 2: blob out0 before the postproc, 3 x hp x wp, n_inject = 4.
  * what = 4 / 3: the running flow F (4 channels) and mask M that IFBlock b's stem reads, 5 x hp x wp, after the flow-update kernel / as
- * written by the stem kernel that applies the last update itself (blocks 2 and 3; flownet.param:99-105, 152-158). */
+ * written by the stem kernel that applies the last update itself (blocks 2 and 3; flownet.param:99-105, 152-158).
+ * what = 5 (b = 3): the 12-channel input of IFBlock 3 read back through the product's row-streaming stem kernel (both of its convolutions with
+ * one-hot weights, eight launches; values to 2^-21 relative), 12 x hp x wp. */
 int rife_hip_v4_tap(const rife_hip_t* r, const uint8_t* in0_rgb, const uint8_t* in1_rgb, int w, int h, float timestep, int what, int b,
                     const float* const* inject, int n_inject, float* out_chw);
 /* The plain pass with blobs flow0 .. flow{n_inject - 1} injected (n_inject = 0..3): the remaining blocks and the fused tail run as in

@@ -249,7 +249,8 @@ class RIFE:
 
     def v4_tap(self, in0image, in1image, timestep, what, b, inject):
         """what 0 / 1: 12-channel input of IFBlock b (unfused kernel / through the fused stem kernel); 2: blob out0 before the postproc;
-        4 / 3: F (4 channels) and M as block b's stem finds them, after k_flow_update / as written by the stem that applies the last update itself."""
+        4 / 3: F (4 channels) and M as block b's stem finds them, after k_flow_update / as written by the stem that applies the last update itself;
+        5 (b = 3): the block input through the row-streaming stem kernel of the product."""
         a = np.ascontiguousarray(in0image, dtype=np.uint8); bb = np.ascontiguousarray(in1image, dtype=np.uint8)
         h, w, _ = a.shape
         wp, hp = (w + 31) // 32 * 32, (h + 31) // 32 * 32

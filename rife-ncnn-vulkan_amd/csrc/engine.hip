@@ -2694,13 +2694,15 @@ static int tap_prologue(const rife_hip_t* E, Ctx& c, const uint8_t* in0, const u
 //           every value, i.e. the value to 2^-22 relative;
 // what = 2: blob out0 (flownet.param:217) before the postproc, from the unfused float tail k_final_float (b ignored; n_inject = 4);
 // what = 4 / 3: F, M as block b's stem reads them: after k_flow_update / written by the stem that applies the update of flow{b-1} itself.
+// what = 5: block 3's input through stem_rs_kernel, the product's kernel for that block (see below).
 // out: planar CHW fp32, 12 x hp/S x wp/S (what 0, 1) or 3 x hp x wp (what 2).  n_inject must be b (what 0, 1) or 4 (what 2).
 static int rife_hip_v4_tap_impl(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, int what, int b,
                                 const float* const* inject, int n_inject, float* out) {
     int rc;
     if ((rc = process_common(E, w, h, timestep))) return rc;
     if (!E->v4 || E->v40) return fail(RIFE_HIP_EINVAL, "the gather taps exist for the rife-v4.6 graph only");
-    if (what < 0 || what > 4) return fail(RIFE_HIP_EINVAL, "bad tap");
+    if (what < 0 || what > 5) return fail(RIFE_HIP_EINVAL, "bad tap");
+    if (what == 5 && b != 3) return fail(RIFE_HIP_EINVAL, "the row-streaming stem kernel serves block 3");
     if (what == 2 ? n_inject != 4 : (b < 1 || b > 3 || n_inject != b)) return fail(RIFE_HIP_EINVAL, "bad block / injection count");
     if ((rc = check_device(E->gpuid))) return rc;
     Ctx c; float* tmp = nullptr;
@@ -2719,6 +2721,59 @@ static int rife_hip_v4_tap_impl(const rife_hip_t* E, const uint8_t* in0, const u
         return 0;
     };
     if (what == 4) return copy_fm(c.F, c.M);
+    if (what == 5) {
+        // Block 3's input THROUGH THE PRODUCT'S ROW-STREAMING STEM KERNEL stem_rs_kernel (stem_rs.h): both of its convolutions run with one-hot
+        // weights.  Stem 0: output channel 12 j + k = input channel k under tap (1 + g, 1 + j) (pixel parity p = 2 g + j of the block input; two
+        // parities per launch); stem 1: output channel = input channel under tap (ty, tx) in {1, 2}^2 (the four parities of the half-resolution
+        // tensor).  Eight launches return every pixel of the 12-channel block input once; each value passed the split-f16 matrix path twice
+        // (hi + lo of hi + lo: 2^-21 relative).  Bias 0, slope 1.
+        const int Hq = c.hp / 4, Wq = c.wp / 4;
+        const S16Geom G(Hq, Wq);
+        const size_t nb = G.bytes(64), pl = G.plane();
+        unsigned char* dout = nullptr; uint16_t *dw0 = nullptr, *dw1 = nullptr; float *dbias = nullptr, *dslope = nullptr;
+        if ((rc = dalloc(c, dout, nb)) || (rc = dalloc(c, dw0, (size_t)9 * 2 * 32 * 8)) || (rc = dalloc(c, dw1, (size_t)2 * 9 * 2 * 64 * 8)) ||
+            (rc = dalloc(c, dbias, 64)) || (rc = dalloc(c, dslope, 64))) return rc;
+        std::vector<float> hz(64, 0.f), ho(64, 1.f);
+        HIPCHK(hipMemcpyAsync(dbias, hz.data(), 256, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dslope, ho.data(), 256, hipMemcpyHostToDevice, st));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_rs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, SRS_LDS));
+        std::vector<unsigned char> host(nb);
+        int inv[32];                                                     // row of a 32-row block that holds channel ch (pack_weights_h2_perm)
+        for (int i = 0; i < 32; i++) inv[s16_row_channel(i)] = i;
+        for (int g = 0; g < 2; g++)
+            for (int ty = 1; ty <= 2; ty++)
+                for (int tx = 1; tx <= 2; tx++) {
+                    std::vector<uint16_t> h0((size_t)9 * 2 * 32 * 8, 0), h1((size_t)2 * 9 * 2 * 64 * 8, 0);
+                    for (int j = 0; j < 2; j++)
+                        for (int k = 0; k < 12; k++) h0[(((size_t)((1 + g) * 3 + 1 + j) * 2 + k / 8) * 32 + 12 * j + k) * 8 + k % 8] = f2h(1.f);
+                    for (int oc = 0; oc < 24; oc++)
+                        h1[((((size_t)(oc / 16) * 9 + ty * 3 + tx) * 2 + (oc % 16) / 8) * 64 + inv[oc]) * 8 + oc % 8] = f2h(1.f);
+                    HIPCHK(hipMemcpyAsync(dw0, h0.data(), h0.size() * 2, hipMemcpyHostToDevice, st));
+                    HIPCHK(hipMemcpyAsync(dw1, h1.data(), h1.size() * 2, hipMemcpyHostToDevice, st));
+                    HIPCHK(hipMemsetAsync(dout, 0, nb, st));
+                    StemRsArgs a;
+                    a.img0 = c.img0; a.img1 = c.img1; a.F = c.F; a.M = c.M; a.w0 = dw0; a.bias0 = dbias; a.slope0 = dslope; a.w1 = dw1; a.bias1 = dbias; a.slope1 = dslope;
+                    a.out = dout; a.timestep = timestep; a.tsp = nullptr; a.wp = c.wp; a.hp = c.hp; a.Hq = Hq; a.Wq = Wq; a.pitch = G.pitch; a.plane = G.plane();
+                    a.nunits = ((Wq + SRS_SW - 1) / SRS_SW) * Hq;
+                    const int nwg = std::min(2 * device_cus(), a.nunits);
+                    hipLaunchKernelGGL((stem_rs_kernel<0>), dim3(nwg), dim3(SRS_NTHR), SRS_LDS, st, a);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipMemcpyAsync(host.data(), dout, nb, hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    for (int j = 0; j < 2; j++)
+                        for (int k = 0; k < 12; k++) {
+                            const int oc = 12 * j + k;
+                            const _Float16* hi = reinterpret_cast<const _Float16*>(host.data() + (size_t)(2 * (oc / 16)) * pl);
+                            const _Float16* lo = reinterpret_cast<const _Float16*>(host.data() + (size_t)(2 * (oc / 16) + 1) * pl);
+                            for (int q = 0; q < Hq; q++)
+                                for (int x = 0; x < Wq; x++) {
+                                    const size_t e = ((size_t)(q + 1) * G.pitch + x + 1) * 16 + oc % 16;
+                                    out[((size_t)k * c.hp + 4 * q + 2 * (ty - 1) + g) * c.wp + 4 * x + 2 * (tx - 1) + j] = (float)hi[e] + (float)lo[e];
+                                }
+                        }
+                }
+        return 0;
+    }
     if (what == 3 && !pending) return fail(RIFE_HIP_EINVAL, "the flow update before this block is not fused into its stem");
     if (what == 2) {
         float4* outf = nullptr;

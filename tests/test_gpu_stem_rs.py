@@ -79,3 +79,26 @@ def test_against_the_oracle_on_injected_flows(pair, modeldirs, w, h, seed):
     got8 = new.v4_process_injected(a, c, 0.45, inj).astype(np.int32)
     dd = np.abs(got8 - want8)
     assert dd.max() <= 1 and (dd > 0).mean() < 1e-3, "%d of %d bytes differ, max %d" % (int((dd > 0).sum()), dd.size, int(dd.max()))
+
+
+@pytest.mark.parametrize("w,h,seed", [(256, 192, 41), (640, 360, 42), (333, 241, 43), (100, 60, 44), (1920, 1080, 45)])
+def test_block_input_through_stem_rs_is_the_oracles(pair, modeldirs, w, h, seed):
+    """The gather of stem_rs_kernel directly against the oracle's blob (cat_12 of flownet.param:165): the kernel runs with one-hot weights in
+    both convolutions (rife_hip_v4_tap what = 5), so its S16 output holds the 12-channel block input it assembled - every full-resolution
+    pixel, through the strip / row-ring / range-boundary logic of the kernel - to the 2^-21 of two passes through the split-f16 matrix path.
+    Flows leave the frame by hundreds of pixels."""
+    new, _ = pair
+    o = pyoracle.OracleRIFE(rife_v4=True); o.load(modeldirs["rife-v4.6"])
+    name = None
+    for line in open(os.path.join(modeldirs["rife-v4.6"], "flownet.param")):
+        f = line.split()
+        if len(f) > 6 and f[0] == "Concat" and f[2] == "2" and f[3] == "1":
+            name = f[6]                                                  # the last two-input Concat = block 3's input
+    a, c = gen_frames.noise_pair(w, h, seed) if seed % 2 else gen_frames.smooth_pair(w, h, seed)
+    inj = injected_flows(w, h, 600 + seed, 3)
+    want = o.v4_extract(a, c, 0.35, name, flows=inj)
+    assert np.abs(want[8:12]).max() > 100
+    got = new.v4_tap(a, c, 0.35, 5, 3, inj)
+    assert got.shape == want.shape
+    err = np.abs(got - want) - (6e-7 * np.abs(want) + 2.4e-7)
+    assert err.max() <= 0, "worst excess %g at %s" % (float(err.max()), np.unravel_index(np.argmax(err), err.shape))
