@@ -208,7 +208,7 @@ __device__ __forceinline__ void assemble_pixel(const uint32_t* __restrict__ img0
                                                const float4* __restrict__ F, const float* __restrict__ M, int wp, int hp, int x, int y, float o[12],
                                                const FlowPending& pend = FlowPending{}) {
     if (S == 1) {
-        const size_t i = (size_t)y * wp + x;
+        const unsigned i = (unsigned)(y * wp + x);                       // 32-bit element offsets (scalar base + one VGPR per access; frames <= 2^27 pixels)
         float4 f = F[i];
         float mk = M[i];
         if (UPD) {
@@ -227,7 +227,7 @@ __device__ __forceinline__ void assemble_pixel(const uint32_t* __restrict__ img0
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int px = sx + (k & 1), py = sy + (k >> 1);
-            const size_t i = (size_t)py * wp + px;
+            const unsigned i = (unsigned)(py * wp + px);
             float4 f = F[i];
             float mk = M[i];
             if (UPD) {
