@@ -3,7 +3,7 @@
 #   bash tools/profile_round.sh <round-tag>      -> gpurun_out/profile_<tag>/...   (copy what is to be judged into profiles/<tag>/)
 # 1) rocprofv3 --kernel-trace --stats of the bench workload (4K, rife-v4.6, one pair in flight)
 # 2) separate PMC passes of the same workload: matrix pipe / LDS / wave states, FETCH_SIZE, WRITE_SIZE (never combined with other traces)
-# 3) the dominant kernel's ablation timings and per-step clock stamps (tools/t64_bench.py)
+# 3) ablation timings and clock stamps of the dominant kernel (tools/rs_bench.py) and of the block-3 stem kernel (tools/stem_rs_bench.py)
 # 4) bench.py JSON lines for every workload, the host-path sweep
 # (tools/collect_profiles.sh <tag> copies the summaries into profiles/<tag>/; tools/round_close.sh runs the GPU suite + smoke())
 set -u
@@ -33,6 +33,7 @@ done
 rm -rf $OUT/kt $OUT/kt1080 $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES $OUT/pmc_SQ_WAIT_ANY $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 cd $ROOT
 timeout 400 python tools/rs_bench.py > $OUT/rs_bench.txt 2>&1
+timeout 300 python tools/stem_rs_bench.py > $OUT/stem_rs_bench.txt 2>&1
 
 for wl in 4k 1080p v23-1080p 4k-tta; do
     timeout 600 python bench.py --workload $wl --steps 50 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
