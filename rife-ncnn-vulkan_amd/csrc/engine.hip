@@ -2230,7 +2230,7 @@ static int process_common(const rife_hip* E, int w, int h, float timestep) {
     if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
     if (!E->loaded) return fail(RIFE_HIP_EINVAL, "process() before load()");
     if (w <= 0 || h <= 0) return fail(RIFE_HIP_EINVAL, "bad frame size");
-    if ((long long)((w + 31) / 32 * 32) * ((h + 31) / 32 * 32) > (1ll << 27))      // the gather kernels address F (16 B per pixel) with 32-bit byte offsets
+    if ((long long)((w + 31) / 32 * 32) * ((h + 31) / 32 * 32) > (1ll << 27))      // pixel indices are ints; stem_rs addresses F (16 B per pixel) with 32-bit byte offsets
         return fail(RIFE_HIP_EINVAL, "frame too large (more than 2^27 padded pixels)");
     (void)timestep;
     if (E->uhd && !E->v4 && (((w + 31) / 32 * 32 / 2) % 32 || ((h + 31) / 32 * 32 / 2) % 32))

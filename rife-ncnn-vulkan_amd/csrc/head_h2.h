@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     const bool valid = fx < fa.w;
                     uint32_t pk = 0;
                     if (valid) {
-                        const unsigned i = (unsigned)(fy * fa.wp + fx);      // 32-bit element offset: scalar base + one VGPR per access
+                        const size_t i = (size_t)fy * fa.wp + fx;
                         float4 f = RIFE_ABL(HEAD_ABL & 2) ? make_float4(0.1f, 0.2f, 0.3f, 0.4f) : fa.F[i];
                         f.x = f.x + dx; f.y = f.y + dy; f.z = f.z + dz; f.w = f.w + dw;
                         const float mm = (RIFE_ABL(HEAD_ABL & 2) ? 0.5f : fa.M[i]) + dm;
