@@ -715,6 +715,66 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
     return rc;
 }
 
+// bench-only: tail_rs_kernel (tail_rs.h) on a wp x hp frame with random trunk / flows / weights, variant = TRS_* ablation bits
+int rife_hip_bench_tail_rs(int gpuid, int wp, int hp, int variant, int iters, float* ms_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    const size_t P = (size_t)wp * hp;
+    const int Hq = hp / 4, Wq = wp / 4;
+    const S16Geom G(Hq, Wq);
+    uint32_t lcg = 4242u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((int)(lcg >> 9) - (1 << 22)) / (float)(1 << 22); };
+    std::vector<uint32_t> himg(P); for (auto& v : himg) { lcg = lcg * 1664525u + 1013904223u; v = lcg & 0xffffffu; }
+    std::vector<float> hF(P * 4), hM(P), hb(32);
+    for (auto& v : hF) v = rnd() * 6.f;
+    for (auto& v : hM) v = rnd();
+    for (auto& v : hb) v = rnd() * 0.1f;
+    std::vector<_Float16> hw((size_t)4 * 16 * 2 * 32 * 8), hx(G.bytes(64) / 2);
+    for (auto& v : hw) v = (_Float16)(rnd() * 0.05f);
+    for (auto& v : hx) v = (_Float16)(rnd() * 0.5f);
+    uint32_t *i0 = nullptr, *i1 = nullptr; float4* F = nullptr; float *M = nullptr, *bias = nullptr; void* w = nullptr; unsigned char *x = nullptr, *out = nullptr;
+    HIPCHK(hipMalloc(&i0, P * 4)); HIPCHK(hipMalloc(&i1, P * 4)); HIPCHK(hipMalloc(&F, P * 16)); HIPCHK(hipMalloc(&M, P * 4));
+    HIPCHK(hipMalloc(&bias, 128)); HIPCHK(hipMalloc(&w, hw.size() * 2)); HIPCHK(hipMalloc(&x, G.bytes(64))); HIPCHK(hipMalloc(&out, P * 3));
+    HIPCHK(hipMemcpy(i0, himg.data(), P * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(i1, himg.data(), P * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(F, hF.data(), P * 16, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(M, hM.data(), P * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(bias, hb.data(), 128, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(x, hx.data(), G.bytes(64), hipMemcpyHostToDevice));
+    TailRsArgs a;
+    a.in = x; a.w = w; a.bias = bias; a.img0 = i0; a.img1 = i1; a.F = F; a.M = M; a.out = reinterpret_cast<uint8_t*>(out);
+    a.w_ = wp; a.h_ = hp; a.wp = wp; a.hp = hp; a.Hq = Hq; a.Wq = Wq; a.pitch = G.pitch; a.plane = G.plane();
+    a.nunits = ((Wq + 31) / 32) * Hq;
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpuid));
+    const int nwg = std::min(2 * cus, a.nunits);
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](auto kfn) -> int {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, TRS_LDS));
+        for (int i = 0; i < 2; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(TRS_NTHR), TRS_LDS, 0, a);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(TRS_NTHR), TRS_LDS, 0, a);
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    switch (variant) {
+        case 0: rc = run(tail_rs_kernel<0>); break;
+        case TRS_NOTAPS: rc = run(tail_rs_kernel<TRS_NOTAPS>); break;
+        case TRS_NOFM: rc = run(tail_rs_kernel<TRS_NOFM>); break;
+        case TRS_NOROW: rc = run(tail_rs_kernel<TRS_NOROW>); break;
+        case TRS_NOTAPS | TRS_NOFM | TRS_NOROW: rc = run(tail_rs_kernel<TRS_NOTAPS | TRS_NOFM | TRS_NOROW>); break;
+        case TRS_NOMATH: rc = run(tail_rs_kernel<TRS_NOMATH>); break;
+        case TRS_NOSTORE: rc = run(tail_rs_kernel<TRS_NOSTORE>); break;
+        case TRS_NOPIX: rc = run(tail_rs_kernel<TRS_NOPIX>); break;
+        case TRS_NOTAPS | TRS_NOFM | TRS_NOROW | TRS_NOPIX: rc = run(tail_rs_kernel<TRS_NOTAPS | TRS_NOFM | TRS_NOROW | TRS_NOPIX>); break;
+        case TRS_NOTAPS | TRS_NOFM | TRS_NOROW | TRS_NOMATH | TRS_NOSTORE: rc = run(tail_rs_kernel<TRS_NOTAPS | TRS_NOFM | TRS_NOROW | TRS_NOMATH | TRS_NOSTORE>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    (void)hipFree(i0); (void)hipFree(i1); (void)hipFree(F); (void)hipFree(M); (void)hipFree(bias); (void)hipFree(w); (void)hipFree(x); (void)hipFree(out);
+    return rc;
+}
+
 // bench-only: stem_rs_kernel (stem_rs.h) on a wp x hp frame with random frames / flows / weights, variant = SRS_* ablation bits | 0x100 * g
 // (g > 0: g workgroups per CU instead of two)
 int rife_hip_bench_stem_rs(int gpuid, int wp, int hp, int variant, int iters, float* ms_out, long long* stamps_out) {

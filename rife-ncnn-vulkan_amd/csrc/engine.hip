@@ -29,6 +29,7 @@
 #include "elementwise_v2.h"
 #include "stem_fused.h"
 #include "stem_rs.h"
+#include "tail_rs.h"
 #include "head_h2.h"
 #include "conv_t64.h"
 #include "conv_row.h"
@@ -917,6 +918,9 @@ struct rife_hip {
     // block 3: block-input assembly + both stem convolutions in one row-streaming kernel (stem_rs.h) instead of stem0_fused_kernel + conv_h2s2_kernel
     // (RIFE_HIP_STEM_RS=0 at create time: A/B, the comparison test)
     bool stem_rs = true;
+    // block 3's head + the tail of the graph + postproc in one row-streaming kernel (tail_rs.h) instead of head_h2_kernel<EPI_FINAL, true>
+    // (RIFE_HIP_TAIL_RS=0 at create time: A/B, the comparison test)
+    bool tail_rs = true;
     // RIFE_HIP_FUSE_FLOW=1 (A/B, parity taps): the flow updates after blocks 1 and 2 inside the fused stems of blocks 2 and 3 (stem_fused.h UPD)
     // instead of two k_flow_update launches.  Bit-identical, and measured SLOWER at 4K (432 vs 442 frames/s, same call): the update kernels
     // run at 6 - 7 TB/s, the stems are bound by gather latency and VALU issue and every load added to them costs more than the pass it removes
@@ -1091,6 +1095,29 @@ static int launch_stem_rs(const rife_hip& E, Ctx& c, const rife_hip::Block& B, u
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("stem_rs launch: ") + hipGetErrorString(e));
     return 0;
 }
+// block 3 of rife-v4.6: last S16 trunk tensor + F, M + frames -> u8 frame (tail_rs.h); two workgroups per CU, all resident
+static int launch_tail_rs(const rife_hip::Block& B, const unsigned char* in, int Hq, int Wq, const FinalArgs& fin, hipStream_t st) {
+    {
+        int dev = 0; (void)hipGetDevice(&dev);
+        static std::mutex mu; static std::map<int, bool> done;
+        std::lock_guard<std::mutex> g(mu);
+        if (!done[dev]) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_rs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, TRS_LDS));
+            done[dev] = true;
+        }
+    }
+    const S16Geom G(Hq, Wq);
+    TailRsArgs a;
+    a.in = in; a.w = B.head.d_wh; a.bias = B.head.d_bias; a.img0 = fin.img0; a.img1 = fin.img1; a.F = fin.F; a.M = fin.M; a.out = fin.out;
+    a.w_ = fin.w; a.h_ = fin.h; a.wp = fin.wp; a.hp = fin.hp; a.Hq = Hq; a.Wq = Wq; a.pitch = G.pitch; a.plane = G.plane();
+    a.nunits = ((Wq + 31) / 32) * Hq;
+    const int nwg = std::min(2 * device_cus(), a.nunits);
+    hipLaunchKernelGGL((tail_rs_kernel<0>), dim3(nwg), dim3(TRS_NTHR), TRS_LDS, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("tail_rs launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
 // can block b's two stems run as one stem_rs launch?  (64-channel block 3 at scale 1 on the S16 trunk, 12 -> 32 -> 64 channels, uniform shapes)
 static bool block_on_stem_rs(const rife_hip& E, const Ctx& c, int b) {
     const rife_hip::Block& B = E.blk[b];
@@ -1227,6 +1254,8 @@ after_stem0:
         }
         if (!(phases & PH_HEAD)) return 0;
         Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);      // eight layers: the trunk output is back in PA
+        if (fin && E.tail_rs && b == 3 && B.c == 64 && B.head.cout == 24 && B.head.d_wh && Ht * 4 == c.hp && Wt * 4 == c.wp)
+            return launch_tail_rs(B, PA, Ht, Wt, *fin, st);
         return launch_conv(B.head, {reinterpret_cast<float*>(PA), B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st, fin, G.pitch, G.plane());
     }
     if (phases != PH_ALL) return fail(RIFE_HIP_EINVAL, "phased block execution needs the S16 trunk path");
@@ -2116,6 +2145,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_RS"); E->rs = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_STEM_RS"); E->stem_rs = !(e && e[0] == '0'); }
+    { const char* e = getenv("RIFE_HIP_TAIL_RS"); E->tail_rs = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_FUSE_FLOW"); E->fuse_flow = e && e[0] == '1'; if (E->fuse_flow) g_fuse_flow_buffers = true; }
     return E;
 }

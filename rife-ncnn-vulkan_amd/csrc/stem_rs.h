@@ -76,6 +76,15 @@ struct SrsTaps { WarpLoads a, b; };
 // F, M and image taps this kernel keeps in flight ACROSS its barriers
 #define SRS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// 8-byte global store the compiler does not see (tail_rs.h, trs_store_dword: a store the compiler knows to be in flight turns its next wait for
+// a loaded value into vmcnt(0), which drains the prefetched F, M and taps of waves 0-1 every step)
+__device__ __forceinline__ void srs_store_b64(unsigned char* base, unsigned off, f16x4 v) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 d;
+    __builtin_memcpy(&d, &v, 8);
+    asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(off), "v"(d), "s"(base) : "memory");
+}
+
 template <int TAG>
 __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem_rs_kernel(StemRsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
         const f32x4* const sd = reinterpret_cast<const f32x4*>(ldsb + SRS_LDS_STG + n * 4096 + lane * 16);
         const int ox = SRS_SW * strip + li;
         bool pok = li < SRS_SW && ox < a.Wq;
-        unsigned char* const o = a.out + (size_t)(2 * half + 4 * n) * a.plane + ((size_t)(q + 1) * a.pitch + ox + 1) * 32;
+        const unsigned o = (unsigned)(2 * half + 4 * n) * a.plane + (unsigned)((q + 1) * a.pitch + ox + 1) * 32u;      // S16 tensors stay below 4 GB (block_on_s16)
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
             const f32x4 p = sd[qd * 64];
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(SRS_NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))
                 hi4[kk] = hh; lo4[kk] = (_Float16)(v - (float)hh);
             }
             if (RIFE_ABL(TAG & SRS_NOSTORE)) pok = pok && p[0] == 123.456f;
-            if (pok) { *reinterpret_cast<f16x4*>(o + 8 * qd) = hi4; *reinterpret_cast<f16x4*>(o + a.plane + 8 * qd) = lo4; }
+            if (pok) { srs_store_b64(a.out, o + 8u * qd, hi4); srs_store_b64(a.out, o + a.plane + 8u * qd, lo4); }
         }
     };
 
