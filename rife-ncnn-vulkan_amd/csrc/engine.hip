@@ -921,6 +921,7 @@ struct rife_hip {
     // block 3's head + the tail of the graph + postproc in one row-streaming kernel (tail_rs.h) instead of head_h2_kernel<EPI_FINAL, true>
     // (RIFE_HIP_TAIL_RS=0 at create time: A/B, the comparison test)
     bool tail_rs = true;
+    bool tail_rs_always = false;      // RIFE_HIP_TAIL_RS=2: at every frame size (tests)
     // RIFE_HIP_FUSE_FLOW=1 (A/B, parity taps): the flow updates after blocks 1 and 2 inside the fused stems of blocks 2 and 3 (stem_fused.h UPD)
     // instead of two k_flow_update launches.  Bit-identical, and measured SLOWER at 4K (432 vs 442 frames/s, same call): the update kernels
     // run at 6 - 7 TB/s, the stems are bound by gather latency and VALU issue and every load added to them costs more than the pass it removes
@@ -1254,7 +1255,10 @@ after_stem0:
         }
         if (!(phases & PH_HEAD)) return 0;
         Timed t(E.prof, B.head.cls, B.head.flops_per_pixel * Ht * Wt, st);      // eight layers: the trunk output is back in PA
-        if (fin && E.tail_rs && b == 3 && B.c == 64 && B.head.cout == 24 && B.head.d_wh && Ht * 4 == c.hp && Wt * 4 == c.wp)
+        // the row-streaming tail where every workgroup has at least 16 steps to amortise its prologue over (4K: 32; 1080p: 8 - there the tile kernel
+        // is as fast or faster: head_b3 0.037 vs 0.039 ms per pair, same call)
+        if (fin && E.tail_rs && b == 3 && B.c == 64 && B.head.cout == 24 && B.head.d_wh && Ht * 4 == c.hp && Wt * 4 == c.wp &&
+            (E.tail_rs_always || ((Wt + 31) / 32) * Ht >= 32 * device_cus()))
             return launch_tail_rs(B, PA, Ht, Wt, *fin, st);
         return launch_conv(B.head, {reinterpret_cast<float*>(PA), B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st, fin, G.pitch, G.plane());
     }
@@ -2145,7 +2149,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_RS"); E->rs = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_STEM_RS"); E->stem_rs = !(e && e[0] == '0'); }
-    { const char* e = getenv("RIFE_HIP_TAIL_RS"); E->tail_rs = !(e && e[0] == '0'); }
+    { const char* e = getenv("RIFE_HIP_TAIL_RS"); E->tail_rs = !(e && e[0] == '0'); E->tail_rs_always = e && e[0] == '2'; }
     { const char* e = getenv("RIFE_HIP_FUSE_FLOW"); E->fuse_flow = e && e[0] == '1'; if (E->fuse_flow) g_fuse_flow_buffers = true; }
     return E;
 }

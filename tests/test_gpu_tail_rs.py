@@ -22,7 +22,7 @@ amd = importlib.import_module("rife-ncnn-vulkan_amd")
 
 def _engine(d, on):
     old = os.environ.get("RIFE_HIP_TAIL_RS")
-    os.environ["RIFE_HIP_TAIL_RS"] = "1" if on else "0"                 # read at create time
+    os.environ["RIFE_HIP_TAIL_RS"] = "2" if on else "0"                 # read at create time; 2 = at every frame size (the product takes it from 4K-class frames up)
     try:
         g = amd.RIFE(0, rife_v4=True); g.load(d)
     finally:
