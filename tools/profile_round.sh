@@ -34,6 +34,7 @@ rm -rf $OUT/kt $OUT/kt1080 $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES $OUT/pmc_SQ_WAIT_AN
 cd $ROOT
 timeout 400 python tools/rs_bench.py > $OUT/rs_bench.txt 2>&1
 timeout 300 python tools/stem_rs_bench.py > $OUT/stem_rs_bench.txt 2>&1
+timeout 300 python tools/tail_rs_bench.py > $OUT/tail_rs_bench.txt 2>&1
 
 for wl in 4k 1080p v23-1080p 4k-tta; do
     timeout 600 python bench.py --workload $wl --steps 50 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
