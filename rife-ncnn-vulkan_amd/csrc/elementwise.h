@@ -425,6 +425,52 @@ __global__ void k_v4_spatial_avg(Ptr8 fl, int W, int H) {
     for (int ti = 0; ti < 8; ti++) q[ti][4] = m;
 }
 
+// Both consensus steps of a `-x -z` block in one pass over the sixteen flow tensors (reference src/rife.cpp:3477-3512 temporal, 3515-3821 spatial;
+// shaders rife_v4_flow_tta_temporal_avg.comp, rife_v4_flow_tta_avg.comp): k_v4_temporal_merge on (forward, reversed) of every orientation, then
+// k_v4_spatial_avg on the eight forward tensors; the reversed direction's spatial consensus is the forward one with (x, y) <-> (z, w) and -m - the
+// same sums term by term (the temporal step leaves b = (a.z, a.w, a.x, a.y, -a.m)), so it is written, not recomputed.  Same operations in the
+// same order as the two kernels: bit-identical tensors; every entry is read once and written once instead of twice.
+struct Ptr8x2 { void* f[8]; void* r[8]; };
+__global__ void k_v4_consensus(Ptr8x2 fl, int W, int H) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= W) return;
+    float *qf[8], *qr[8];
+    float ax[8], ay[8], az[8], aw[8], am[8];
+#pragma unroll
+    for (int ti = 0; ti < 8; ti++) {
+        const size_t o = tta_index(ti, i, j, W, H) * 8;
+        qf[ti] = reinterpret_cast<float*>(fl.f[ti]) + o; qr[ti] = reinterpret_cast<float*>(fl.r[ti]) + o;
+        const float* a = qf[ti]; const float* b = qr[ti];
+        ax[ti] = (a[0] + b[2]) * 0.5f; ay[ti] = (a[1] + b[3]) * 0.5f; az[ti] = (a[2] + b[0]) * 0.5f; aw[ti] = (a[3] + b[1]) * 0.5f;
+        am[ti] = (a[4] - b[4]) * 0.5f;
+    }
+    const float x = (ax[0] + -ax[1] + -ax[2] + ax[3] + ay[4] + ay[5] + -ay[6] + -ay[7]) * 0.125f;
+    const float y = (ay[0] + ay[1] + -ay[2] + -ay[3] + ax[4] + -ax[5] + -ax[6] + ax[7]) * 0.125f;
+    const float z = (az[0] + -az[1] + -az[2] + az[3] + aw[4] + aw[5] + -aw[6] + -aw[7]) * 0.125f;
+    const float w = (aw[0] + aw[1] + -aw[2] + -aw[3] + az[4] + -az[5] + -az[6] + az[7]) * 0.125f;
+    const float m = (am[0] + am[1] + am[2] + am[3] + am[4] + am[5] + am[6] + am[7]) * 0.125f;
+    // the reversed tensors' own consensus: sums over b = (az, aw, ax, ay, -am) in the same order
+    const float xr = (az[0] + -az[1] + -az[2] + az[3] + aw[4] + aw[5] + -aw[6] + -aw[7]) * 0.125f;
+    const float yr = (aw[0] + aw[1] + -aw[2] + -aw[3] + az[4] + -az[5] + -az[6] + az[7]) * 0.125f;
+    const float zr = (ax[0] + -ax[1] + -ax[2] + ax[3] + ay[4] + ay[5] + -ay[6] + -ay[7]) * 0.125f;
+    const float wr = (ay[0] + ay[1] + -ay[2] + -ay[3] + ax[4] + -ax[5] + -ax[6] + ax[7]) * 0.125f;
+    const float mr = (-am[0] + -am[1] + -am[2] + -am[3] + -am[4] + -am[5] + -am[6] + -am[7]) * 0.125f;
+#define RIFE_ORI(q, X, Y, Z, Wv)                                                                         \
+    q[0][0] = X;  q[0][1] = Y;  q[0][2] = Z;  q[0][3] = Wv;                                              \
+    q[1][0] = -X; q[1][1] = Y;  q[1][2] = -Z; q[1][3] = Wv;                                              \
+    q[2][0] = -X; q[2][1] = -Y; q[2][2] = -Z; q[2][3] = -Wv;                                             \
+    q[3][0] = X;  q[3][1] = -Y; q[3][2] = Z;  q[3][3] = -Wv;                                             \
+    q[4][0] = Y;  q[4][1] = X;  q[4][2] = Wv; q[4][3] = Z;                                               \
+    q[5][0] = -Y; q[5][1] = X;  q[5][2] = -Wv; q[5][3] = Z;                                              \
+    q[6][0] = -Y; q[6][1] = -X; q[6][2] = -Wv; q[6][3] = -Z;                                             \
+    q[7][0] = Y;  q[7][1] = -X; q[7][2] = Wv; q[7][3] = -Z;
+    RIFE_ORI(qf, x, y, z, w)
+    RIFE_ORI(qr, xr, yr, zr, wr)
+#undef RIFE_ORI
+#pragma unroll
+    for (int ti = 0; ti < 8; ti++) { qf[ti][4] = m; qr[ti][4] = mr; }
+}
+
 // tail of the graph without postproc: out0 (3 x hp x wp) kept as float4 per padded pixel, for the TTA averaging
 __global__ void k_final_float(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, const float4* __restrict__ F,
                               const float* __restrict__ M, const float* __restrict__ flow3, float4* __restrict__ out, int wp, int hp) {

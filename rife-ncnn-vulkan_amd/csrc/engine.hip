@@ -922,6 +922,9 @@ struct rife_hip {
     // (RIFE_HIP_TAIL_RS=0 at create time: A/B, the comparison test)
     bool tail_rs = true;
     bool tail_rs_always = false;      // RIFE_HIP_TAIL_RS=2: at every frame size (tests)
+    // -x -z: temporal + spatial flow consensus of a block in one kernel (k_v4_consensus); RIFE_HIP_TTA_CONSENSUS=0 at create time: the two steps as
+    // separate kernels (8 + 2 launches per block; A/B, the bit-identity test)
+    bool tta_consensus = true;
     // RIFE_HIP_FUSE_FLOW=1 (A/B, parity taps): the flow updates after blocks 1 and 2 inside the fused stems of blocks 2 and 3 (stem_fused.h UPD)
     // instead of two k_flow_update launches.  Bit-identical, and measured SLOWER at 4K (432 vs 442 frames/s, same call): the update kernels
     // run at 6 - 7 TB/s, the stems are bound by gather latency and VALU issue and every load added to them costs more than the pass it removes
@@ -1502,6 +1505,7 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
         }
         HIPCHK(hipGetLastError());
     }
+    const bool fused_consensus = ntemp == 2 && nori == 8 && E.tta_consensus;
     for (int fi = 0; fi < 4; fi++) {
         const int Wf = wp / E.flow_div(fi), Hf = hp / E.flow_div(fi);
         if ((rc = fork())) return rc;
@@ -1511,7 +1515,7 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
                 Ctx& c = *E.tta_ctx[dir][ti];
                 if ((rc = run_block_convs(E, c, fi, dir ? 1.f - timestep : timestep))) return rc;
             }
-            if (ntemp == 2) {
+            if (ntemp == 2 && !fused_consensus) {
                 Timed t(E.prof, "tta_merge", 0, ls);
                 const size_t npix = (size_t)Wf * Hf;
                 hipLaunchKernelGGL(k_v4_temporal_merge, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ls,
@@ -1520,7 +1524,13 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
             }
         }
         if ((rc = join())) return rc;
-        if (nori == 8) {
+        if (fused_consensus) {       // -x -z: temporal and spatial consensus of the sixteen flow tensors in one pass (k_v4_consensus)
+            Timed t(E.prof, "tta_merge", 0, st);
+            Ptr8x2 f;
+            for (int ti = 0; ti < 8; ti++) { f.f[ti] = E.tta_ctx[0][ti]->flow[fi]; f.r[ti] = E.tta_ctx[1][ti]->flow[fi]; }
+            hipLaunchKernelGGL(k_v4_consensus, grid2d(Wf, Hf), dim3(256), 0, st, f, Wf, Hf);
+            HIPCHK(hipGetLastError());
+        } else if (nori == 8) {
             Timed t(E.prof, "tta_merge", 0, st);
             for (int dir = 0; dir < ntemp; dir++) {
                 Ptr8 f;
@@ -2149,6 +2159,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_RS"); E->rs = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_STEM_RS"); E->stem_rs = !(e && e[0] == '0'); }
+    { const char* e = getenv("RIFE_HIP_TTA_CONSENSUS"); E->tta_consensus = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_TAIL_RS"); E->tail_rs = !(e && e[0] == '0'); E->tail_rs_always = e && e[0] == '2'; }
     { const char* e = getenv("RIFE_HIP_FUSE_FLOW"); E->fuse_flow = e && e[0] == '1'; if (E->fuse_flow) g_fuse_flow_buffers = true; }
     return E;

@@ -241,3 +241,18 @@ def test_4k_pass_is_run_to_run_stable(engines):
         fl = [g.v4_extract_flow(a, b, 0.5, fi) for _ in range(3)]
         for f in fl[1:]:
             assert np.array_equal(f, fl[0]), fi
+
+
+@pytest.mark.parametrize("w,h", [(100, 60), (256, 192), (333, 241)])
+def test_fused_tta_consensus_is_bit_identical_to_the_two_kernels(modeldirs, w, h, monkeypatch):
+    """`-x -z`: k_v4_consensus (temporal + spatial flow consensus of a block in one pass over the sixteen flow tensors) against the two separate
+    kernels (RIFE_HIP_TTA_CONSENSUS=0): the same additions in the same order, so the frames are the same bytes.
+    Reference src/rife.cpp:3477-3512, 3515-3821."""
+    a, b = gen_frames.smooth_pair(w, h, 77)
+    monkeypatch.setenv("RIFE_HIP_TTA_CONSENSUS", "0")
+    g0 = amd.RIFE(0, tta_mode=True, tta_temporal_mode=True, rife_v4=True); g0.load(modeldirs["rife-v4.6"])
+    monkeypatch.delenv("RIFE_HIP_TTA_CONSENSUS")
+    g1 = amd.RIFE(0, tta_mode=True, tta_temporal_mode=True, rife_v4=True); g1.load(modeldirs["rife-v4.6"])
+    for t in (0.5, 0.3):
+        x0, x1 = g0.process(a, b, t), g1.process(a, b, t)
+        assert np.array_equal(x0, x1), "%d bytes differ" % int((x0 != x1).sum())
