@@ -18,13 +18,16 @@ amd = importlib.import_module("rife-ncnn-vulkan_amd")
 
 
 def _engine(modeldir, t64, **kw):
-    old = os.environ.get("RIFE_HIP_T64"), os.environ.get("RIFE_HIP_RS")
+    keys = ("RIFE_HIP_T64", "RIFE_HIP_RS", "RIFE_HIP_STEM_RS", "RIFE_HIP_TAIL_RS")
+    old = tuple(os.environ.get(k) for k in keys)
     os.environ["RIFE_HIP_T64"] = "1" if t64 else "0"      # read by rife_hip_create
     os.environ["RIFE_HIP_RS"] = "0"                        # conv_t64 itself, not the row-streaming kernel that serves block 3 by default (tests below)
+    os.environ["RIFE_HIP_STEM_RS"] = "0"                   # nor the row-streaming stem / tail kernels around it (last-bit differences of their own:
+    os.environ["RIFE_HIP_TAIL_RS"] = "0"                   #  tests/test_gpu_stem_rs.py, test_gpu_tail_rs.py)
     try:
         g = amd.RIFE(0, rife_v4=True, **kw)
     finally:
-        for k, v in zip(("RIFE_HIP_T64", "RIFE_HIP_RS"), old):
+        for k, v in zip(keys, old):
             if v is None:
                 del os.environ[k]
             else:
