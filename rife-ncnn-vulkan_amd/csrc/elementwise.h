@@ -378,9 +378,11 @@ struct Ptr8 { void* p[8]; };
 struct Ptr16 { const void* p[16]; };
 
 // u8 HWC RGB (w x h) -> the 8 orientations of the zero-padded RGBX image
+// (thread blocks of the orientation kernels are 2-D TILES, tta_block(): the transposed orientations 4..7 walk their buffers along the other axis,
+// and a 256 x 1 block reads / writes them one element per cache line)
 __global__ void k_preproc_tta(const uint8_t* __restrict__ rgb, int w, int h, Ptr8 outs, int wp, int hp) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= wp) return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= wp || y >= hp) return;
     uint32_t v = 0;
     if (x < w && y < h) {
         const uint8_t* p = rgb + ((size_t)y * w + x) * 3;
@@ -403,8 +405,8 @@ __global__ void k_v4_temporal_merge(float* __restrict__ f, float* __restrict__ r
 
 // 8-orientation flow / mask consensus, in place on the eight [.][.][8] tensors; W x H = size of orientation 0
 __global__ void k_v4_spatial_avg(Ptr8 fl, int W, int H) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= W) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (j >= W || i >= H) return;
     float* q[8];
 #pragma unroll
     for (int ti = 0; ti < 8; ti++) q[ti] = reinterpret_cast<float*>(fl.p[ti]) + tta_index(ti, i, j, W, H) * 8;
@@ -432,8 +434,8 @@ __global__ void k_v4_spatial_avg(Ptr8 fl, int W, int H) {
 // same order as the two kernels: bit-identical tensors; every entry is read once and written once instead of twice.
 struct Ptr8x2 { void* f[8]; void* r[8]; };
 __global__ void k_v4_consensus(Ptr8x2 fl, int W, int H) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= W) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (j >= W || i >= H) return;
     float *qf[8], *qr[8];
     float ax[8], ay[8], az[8], aw[8], am[8];
 #pragma unroll
@@ -492,7 +494,7 @@ __global__ void k_final_float(const uint32_t* __restrict__ img0, const uint32_t*
 // gather nori (1 | 8) orientations x ntemp (1 | 2) directions of out0 back to the base frame, average, postproc.
 // outs.p[ti] = forward outputs, outs.p[8 + ti] = time-reversed outputs.
 __global__ void k_postproc_tta(Ptr16 outs, int nori, int ntemp, uint8_t* __restrict__ out, int w, int h, int wp, int hp) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
     float v[3], vr[3];
 #pragma unroll

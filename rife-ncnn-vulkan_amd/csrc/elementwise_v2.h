@@ -247,8 +247,8 @@ __global__ void k2_temporal_merge(float4* __restrict__ f, float4* __restrict__ r
 // v2 8-orientation flow consensus, in place on eight float4 fields; W x H = size of orientation 0 (rife.cpp:1543-1667;
 // GPU twin rife_v2_flow_tta_avg.comp)
 __global__ void k2_spatial_avg(Ptr8 fl, int W, int H) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= W) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;      // 2-D thread tiles (tta_block)
+    if (j >= W || i >= H) return;
     float4* q[8];
     float4 v[8];
 #pragma unroll

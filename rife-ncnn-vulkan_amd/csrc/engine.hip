@@ -1052,6 +1052,10 @@ struct Timed {
 };
 
 static inline dim3 grid2d(int w, int h) { return dim3((w + 255) / 256, h); }
+// tiles of the kernels that touch all eight TTA orientations of a plane: a wave = 8 columns x 8 rows (32-byte and 16-byte elements: 256- / 128-byte
+// runs in the straight AND in the transposed buffers) or 16 x 4 rows of a 16 x 16 block (4-byte elements: 64-byte runs both ways)
+static inline dim3 tta_block(int elem_bytes) { return elem_bytes >= 16 ? dim3(8, 32) : dim3(16, 16); }
+static inline dim3 tta_grid(int w, int h, int elem_bytes) { const dim3 b = tta_block(elem_bytes); return dim3((w + b.x - 1) / b.x, (h + b.y - 1) / b.y); }
 // rife_preproc.comp: u8 HWC RGB -> zero-padded RGBX; four pixels per lane when the frame allows 4-byte loads
 static inline void launch_preproc(hipStream_t st, const uint8_t* rgb, int w, int h, uint32_t* out, int wp, int hp) {
     if ((w & 3) == 0 && (reinterpret_cast<uintptr_t>(rgb) & 3) == 0) hipLaunchKernelGGL(k_preproc4, dim3((wp / 4 + 255) / 256, hp), dim3(256), 0, st, rgb, w, h, out, wp, hp);
@@ -1493,12 +1497,11 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
     };
     {
         Timed t(E.prof, "preproc", 0, st);
-        dim3 g = grid2d(wp, hp);
         if (nori == 8) {
             Ptr8 a, b;
             for (int ti = 0; ti < 8; ti++) { a.p[ti] = E.tta_ctx[0][ti]->img0; b.p[ti] = E.tta_ctx[0][ti]->img1; }
-            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in0, w, h, a, wp, hp);
-            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in1, w, h, b, wp, hp);
+            hipLaunchKernelGGL(k_preproc_tta, tta_grid(wp, hp, 4), tta_block(4), 0, st, d_in0, w, h, a, wp, hp);
+            hipLaunchKernelGGL(k_preproc_tta, tta_grid(wp, hp, 4), tta_block(4), 0, st, d_in1, w, h, b, wp, hp);
         } else {
             launch_preproc(st, d_in0, w, h, E.tta_ctx[0][0]->img0, wp, hp);
             launch_preproc(st, d_in1, w, h, E.tta_ctx[0][0]->img1, wp, hp);
@@ -1528,14 +1531,14 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
             Timed t(E.prof, "tta_merge", 0, st);
             Ptr8x2 f;
             for (int ti = 0; ti < 8; ti++) { f.f[ti] = E.tta_ctx[0][ti]->flow[fi]; f.r[ti] = E.tta_ctx[1][ti]->flow[fi]; }
-            hipLaunchKernelGGL(k_v4_consensus, grid2d(Wf, Hf), dim3(256), 0, st, f, Wf, Hf);
+            hipLaunchKernelGGL(k_v4_consensus, tta_grid(Wf, Hf, 32), tta_block(32), 0, st, f, Wf, Hf);
             HIPCHK(hipGetLastError());
         } else if (nori == 8) {
             Timed t(E.prof, "tta_merge", 0, st);
             for (int dir = 0; dir < ntemp; dir++) {
                 Ptr8 f;
                 for (int ti = 0; ti < 8; ti++) f.p[ti] = E.tta_ctx[dir][ti]->flow[fi];
-                hipLaunchKernelGGL(k_v4_spatial_avg, grid2d(Wf, Hf), dim3(256), 0, st, f, Wf, Hf);
+                hipLaunchKernelGGL(k_v4_spatial_avg, tta_grid(Wf, Hf, 32), tta_block(32), 0, st, f, Wf, Hf);
             }
             HIPCHK(hipGetLastError());
         }
@@ -1563,7 +1566,7 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
             }
         if ((rc = join())) return rc;
         Timed t(E.prof, "final", 0, st);
-        hipLaunchKernelGGL(k_postproc_tta, grid2d(w, h), dim3(256), 0, st, outs, nori, ntemp, d_out, w, h, wp, hp);
+        hipLaunchKernelGGL(k_postproc_tta, tta_grid(w, h, 16), tta_block(16), 0, st, outs, nori, ntemp, d_out, w, h, wp, hp);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1801,12 +1804,11 @@ static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     }
     {
         Timed t(E.prof, "preproc", 0, st);
-        dim3 g = grid2d(wp, hp);
         if (nori == 8) {
             Ptr8 a, b;
             for (int ti = 0; ti < 8; ti++) { a.p[ti] = c.timg0[ti]; b.p[ti] = c.timg1[ti]; }
-            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in0, c.w, c.h, a, wp, hp);
-            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in1, c.w, c.h, b, wp, hp);
+            hipLaunchKernelGGL(k_preproc_tta, tta_grid(wp, hp, 4), tta_block(4), 0, st, d_in0, c.w, c.h, a, wp, hp);
+            hipLaunchKernelGGL(k_preproc_tta, tta_grid(wp, hp, 4), tta_block(4), 0, st, d_in1, c.w, c.h, b, wp, hp);
         } else {
             launch_preproc(st, d_in0, c.w, c.h, c.timg0[0], wp, hp);
             launch_preproc(st, d_in1, c.w, c.h, c.timg1[0], wp, hp);
@@ -1831,7 +1833,7 @@ static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
         for (int d = 0; d < ntemp; d++) {
             Ptr8 f;
             for (int ti = 0; ti < 8; ti++) f.p[ti] = c.tflow[d][ti];
-            hipLaunchKernelGGL(k2_spatial_avg, grid2d(wp / 2, hp / 2), dim3(256), 0, st, f, wp / 2, hp / 2);
+            hipLaunchKernelGGL(k2_spatial_avg, tta_grid(wp / 2, hp / 2, 16), tta_block(16), 0, st, f, wp / 2, hp / 2);
         }
         if (ntemp == 2)
             for (int ti = 0; ti < 8; ti++) hipLaunchKernelGGL(k2_temporal_merge, dim3(gflow), dim3(256), 0, st, c.tflow[0][ti], c.tflow[1][ti], nflow);
@@ -1847,7 +1849,7 @@ static int run_v2(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
         Timed t(E.prof, "final", 0, st);
         Ptr16 outs;
         for (int d = 0; d < 2; d++) for (int ti = 0; ti < 8; ti++) outs.p[d * 8 + ti] = c.toutf[d][ti];
-        hipLaunchKernelGGL(k_postproc_tta, grid2d(c.w, c.h), dim3(256), 0, st, outs, nori, ntemp, d_out, c.w, c.h, wp, hp);
+        hipLaunchKernelGGL(k_postproc_tta, tta_grid(c.w, c.h, 16), tta_block(16), 0, st, outs, nori, ntemp, d_out, c.w, c.h, wp, hp);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1888,12 +1890,11 @@ static int run_v1(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     int rc;
     {
         Timed t(E.prof, "preproc", 0, st);
-        dim3 g = grid2d(wp, hp);
         if (nori == 8) {
             Ptr8 a, b;
             for (int ti = 0; ti < 8; ti++) { a.p[ti] = c.timg0[ti]; b.p[ti] = c.timg1[ti]; }
-            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in0, c.w, c.h, a, wp, hp);
-            hipLaunchKernelGGL(k_preproc_tta, g, dim3(256), 0, st, d_in1, c.w, c.h, b, wp, hp);
+            hipLaunchKernelGGL(k_preproc_tta, tta_grid(wp, hp, 4), tta_block(4), 0, st, d_in0, c.w, c.h, a, wp, hp);
+            hipLaunchKernelGGL(k_preproc_tta, tta_grid(wp, hp, 4), tta_block(4), 0, st, d_in1, c.w, c.h, b, wp, hp);
         } else {
             launch_preproc(st, d_in0, c.w, c.h, c.timg0[0], wp, hp);
             launch_preproc(st, d_in1, c.w, c.h, c.timg1[0], wp, hp);
@@ -2007,7 +2008,7 @@ static int run_v1(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
             Ptr8 f;
             for (int ti = 0; ti < 8; ti++) f.p[ti] = aux(ti < 4 ? 0 : 1).v[8 + d * 8 + ti].p;
             const GView f0 = aux(0).v[8 + d * 8];
-            hipLaunchKernelGGL(kg_v1_spatial_avg, grid2d(f0.w, f0.h), dim3(256), 0, st, f, f0.ld, f0.w, f0.h);
+            hipLaunchKernelGGL(kg_v1_spatial_avg, tta_grid(f0.w, f0.h, 16), tta_block(16), 0, st, f, f0.ld, f0.w, f0.h);
         }
         if (ntemp == 2)
             for (int ti = 0; ti < 8; ti++) {
@@ -2032,7 +2033,7 @@ static int run_v1(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
         Timed t(E.prof, "final", 0, st);
         Ptr16 outs;
         for (int d = 0; d < 2; d++) for (int ti = 0; ti < 8; ti++) outs.p[d * 8 + ti] = c.toutf[d][ti];
-        hipLaunchKernelGGL(k_postproc_tta, grid2d(c.w, c.h), dim3(256), 0, st, outs, nori, ntemp, d_out, c.w, c.h, wp, hp);
+        hipLaunchKernelGGL(k_postproc_tta, tta_grid(c.w, c.h, 16), tta_block(16), 0, st, outs, nori, ntemp, d_out, c.w, c.h, wp, hp);
         HIPCHK(hipGetLastError());
     }
     return 0;

@@ -251,8 +251,8 @@ __global__ void kg_v1_temporal_merge(GView f, GView r) {
 }
 
 __global__ void kg_v1_spatial_avg(Ptr8 fl, int ld, int W, int H) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= W) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;      // 2-D thread tiles (tta_block)
+    if (j >= W || i >= H) return;
     float* q[8];
 #pragma unroll
     for (int ti = 0; ti < 8; ti++) q[ti] = reinterpret_cast<float*>(fl.p[ti]) + tta_index(ti, i, j, W, H) * ld;
