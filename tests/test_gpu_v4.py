@@ -146,6 +146,18 @@ def test_tta_modes_within_1_lsb(modeldirs, tta, temporal, w, h):
     assert np.array_equal(got, g.process(a, b, 0.3))      # deterministic
 
 
+def test_tta_4k_within_1_lsb(modeldirs):
+    """BASELINE config 5 at size: rife-v4.6 3840 x 2160 with `-x -z` (16 passes, the flow consensus after every block, the output average) on the
+    reference's real frame pair tiled 6 x 6, against the oracle's 16-pass restatement (src/rife.cpp:3246-4145).  ~2 minutes of oracle time."""
+    a, b = gen_frames.tiled_real_pair(6)
+    d = modeldirs["rife-v4.6"]
+    g = amd.RIFE(0, tta_mode=True, tta_temporal_mode=True, rife_v4=True); g.load(d)
+    o = pyoracle.OracleRIFE(tta_mode=True, tta_temporal_mode=True, rife_v4=True); o.set_gpu_crop(1); o.load(d)
+    mx, f0, f1, psnr = lsb_report(g.process(a, b, 0.5), o.process(a, b, 0.5))
+    assert mx <= 1, (mx, f0, f1, psnr)
+    assert f0 > 0.999, (mx, f0, f1, psnr)
+
+
 def test_tta_differs_from_plain(engines, modeldirs):
     """Sanity: the ensemble really changes the result (otherwise the test above proves nothing)."""
     g, _ = engines
