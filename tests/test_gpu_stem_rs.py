@@ -102,3 +102,16 @@ def test_block_input_through_stem_rs_is_the_oracles(pair, modeldirs, w, h, seed)
     assert got.shape == want.shape
     err = np.abs(got - want) - (6e-7 * np.abs(want) + 2.4e-7)
     assert err.max() <= 0, "worst excess %g at %s" % (float(err.max()), np.unravel_index(np.argmax(err), err.shape))
+
+
+def test_row_streaming_kernels_are_run_to_run_stable(modeldirs, monkeypatch):
+    """stem_rs_kernel and tail_rs_kernel keep loads in flight across their barriers and fill the register file of a CU with two workgroups (the
+    condition under which the packed-fp32 build of the tile stems was unstable in round 2): 200 identical calls at 640 x 360 and 60 at
+    1920 x 1080 (tail_rs forced at every size) return the same bytes every time."""
+    monkeypatch.setenv("RIFE_HIP_TAIL_RS", "2")
+    g = amd.RIFE(0, rife_v4=True); g.load(modeldirs["rife-v4.6"])
+    for (w, h, n) in ((640, 360, 200), (1920, 1080, 60)):
+        a, c = gen_frames.noise_pair(w, h, 5) if w < 1000 else gen_frames.tiled_real_pair(3)
+        ref = g.process(a, c, 0.37)
+        bad = sum(int(not np.array_equal(ref, g.process(a, c, 0.37))) for _ in range(n))
+        assert bad == 0, "%d of %d calls at %dx%d differ from the first" % (bad, n, w, h)
