@@ -2,7 +2,9 @@
 
 rife.Warp (src/warp.cpp:96-168, src/warp.comp:24-69) is fused into three places of the rife-v4.6 schedule: the block-input assembly inside
 the fused stem kernels of blocks 1-3 (stem_fused.h; flownet.param:52-62, 107-115, 160-165) and the tail of the graph inside the last head kernel
-(head_h2.h EPI_FINAL; flownet.param:202-217).  End-to-end parity (tests/test_gpu_v4.py) sees that code only behind ~50 further layers and with the
+(head_h2.h EPI_FINAL; flownet.param:202-217).  (Since round 3 the product runs block 3's stems on stem_rs_kernel and, from 4K-class frames up,
+the tail on tail_rs_kernel - the same gather code in two halves; tests/test_gpu_stem_rs.py and test_gpu_tail_rs.py repeat these checks on them.
+The tile kernels tested here still serve blocks 1 / 2, smaller frames, and every frame when the row-streaming kernels are switched off.)  End-to-end parity (tests/test_gpu_v4.py) sees that code only behind ~50 further layers and with the
 small flows a synthetic model produces.  Here the blobs flow0..flow{b-1} are INJECTED on both sides (the reference's Extractor does the same for
 its TTA passes, src/rife.cpp:2653-2669), so that the sampling positions are far outside the frame in places, and three things are compared:
   1. the 12-channel block input from the unfused assembly kernel k_assemble<S> (same assemble_pixel / warp_rgbx code): BIT FOR BIT;
