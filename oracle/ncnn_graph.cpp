@@ -319,6 +319,17 @@ int Extractor::forward_layer(int li) {
         if (blobs[b].empty()) { std::fprintf(stderr, "oracle: blob %s missing\n", net->blob_names[b].c_str()); return -3; }
     const int nt = net->num_threads;
     const std::string& t = L.type;
+    if (!net->custom.empty()) {
+        auto cu = net->custom.find(t);
+        if (cu != net->custom.end()) {
+            std::vector<Mat> bottoms, tops(L.tops.size());
+            for (int b : L.bottoms) bottoms.push_back(blobs[b]);
+            int r = cu->second(bottoms, tops);
+            if (r) return r;
+            for (size_t i = 0; i < L.tops.size(); i++) blobs[L.tops[i]] = tops[i];
+            return 0;
+        }
+    }
     if (t == "Input") {
         std::fprintf(stderr, "oracle: input blob %s not bound\n", net->blob_names[L.tops[0]].c_str());
         return -4;
@@ -326,7 +337,13 @@ int Extractor::forward_layer(int li) {
         for (int o : L.tops) blobs[o] = blobs[L.bottoms[0]];
     } else if (t == "Concat") {
         int w = blobs[L.bottoms[0]].w, h = blobs[L.bottoms[0]].h, c = 0;
-        for (int b : L.bottoms) c += blobs[b].c;
+        for (int b : L.bottoms) {
+            if (blobs[b].w != w || blobs[b].h != h) {   // e.g. -u on a padded size that is not a multiple of 64: the graph's pyramid does not close
+                std::fprintf(stderr, "oracle: Concat %s: %dx%d vs %dx%d\n", L.name.c_str(), blobs[b].w, blobs[b].h, w, h);
+                return -14;
+            }
+            c += blobs[b].c;
+        }
         Mat out(w, h, c); int q = 0;
         for (int b : L.bottoms) {
             const Mat& m = blobs[b];

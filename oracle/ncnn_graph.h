@@ -17,6 +17,7 @@
 // anything in this directory.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -71,6 +72,9 @@ struct Net {
     std::vector<int> producer;               // blob -> layer index
     int num_threads = 1;
     size_t bin_bytes_consumed = 0, bin_bytes_total = 0;
+    // Layer types executed OUTSIDE the interpreter (ncnn::Net::register_custom_layer).  Only oracle/refbuild uses it: there `rife.Warp`
+    // is the reference's own compiled Warp::forward (src/warp.cpp:96-168) instead of warp() below.  Empty in liboracle.so.
+    std::map<std::string, std::function<int(const std::vector<Mat>& bottoms, std::vector<Mat>& tops)>> custom;
 
     // returns 0 on success (reference: ncnn::Net::load_param / load_model, rife.cpp:112-121)
     int load_param(const std::string& path);
