@@ -34,6 +34,7 @@
 #include "conv_t64.h"
 #include "conv_row.h"
 #include "conv_rs.h"
+#include "conv_ks.h"
 #include "graph_kernels.h"
 #include "model_hashes.h"
 #include "ncnn_model.h"
@@ -758,6 +759,50 @@ static int launch_row(const ConvLayer& L, const unsigned char* in, unsigned char
     return 0;
 }
 
+// the same coarse-block layers on the weight-stationary K-split kernel (conv_ks.h; round 4): C = 128 (block 1) and C = 96 (block 2).
+// RIFE_HIP_KS (create time) = bit mask: 1 = 128 channels, 2 = 96 channels where conv_row served them (small grids), 4 = 96 channels at every
+// size (instead of conv_t64), 0 = conv_row / conv_t64 as in round 3 (A/B, tests/test_gpu_ks.py).
+template <int C, int NB, int CPW>
+static int launch_ks_cfg(const unsigned char* img, const KsArgs& a0, int tiles_x, int gy, hipStream_t st) {
+    using K = KsCfg<C, NB, CPW>;
+    {
+        int dev = 0; (void)hipGetDevice(&dev);
+        static std::mutex mu; static std::map<int, bool> done;
+        std::lock_guard<std::mutex> g(mu);
+        if (!done[dev]) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ks_kernel<C, NB, CPW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS));
+            done[dev] = true;
+        }
+    }
+    KsArgs a = a0;
+    a.img = img;
+    // ranges per N group: one workgroup per CU (150 KB of LDS), all resident at once also when gy pairs share the launch; a multiple of the
+    // strip count where possible, so that no range crosses a strip (a crossing costs a pipeline drain and refill)
+    int G = std::max(1, device_cus() / (K::NG * gy));
+    G = std::min(G, a.nunits);
+    if (G >= tiles_x) G = G / tiles_x * tiles_x;
+    hipLaunchKernelGGL((conv_ks_kernel<C, NB, CPW, 0>), dim3(G * K::NG, gy), dim3(K::NTHR), K::LDS, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_ks launch: ") + hipGetErrorString(e));
+    return 0;
+}
+static bool ks_serves(int ks_mask, int C) { return (C == 128 && (ks_mask & 1)) || (C == 96 && (ks_mask & 6)); }
+static int launch_ks(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, int nb = 0,
+                     const unsigned char* const* inb = nullptr, unsigned char* const* outb = nullptr) {
+    const unsigned char* const rimg = L.cout == 96 ? L.d_row : L.d_t64;
+    if (!rimg) return fail(RIFE_HIP_EINVAL, "layer has no conv_row image");
+    if (nb > 4) return fail(RIFE_HIP_EINVAL, "conv_ks batches at most four pairs");
+    const S16Geom G(H, W);
+    KsArgs a;
+    a.in = in; a.out = out; a.img = rimg; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.nunits = G.tiles_x * H; a.skip = 1;
+    a.nb = nb;
+    for (int k = 0; k < nb; k++) { a.inb[k] = inb[k]; a.outb[k] = outb[k]; }
+    const int gy = nb > 0 ? nb : 1;
+    if (L.cout == 128) return launch_ks_cfg<128, 2, 2>(rimg, a, G.tiles_x, gy, st);
+    if (L.cout == 96) return launch_ks_cfg<96, 3, 2>(rimg, a, G.tiles_x, gy, st);
+    return fail(RIFE_HIP_EINVAL, "conv_ks serves 96 and 128 channels");
+}
+
 // ------------------------------------------------------------------------------------------------
 // profiler (rife_hip_profile_*): HIP events on the launch stream around every kernel
 // ------------------------------------------------------------------------------------------------
@@ -915,6 +960,8 @@ struct rife_hip {
     bool t64 = true;
     // block-3 trunk on the row-streaming kernel (conv_rs.h) instead of conv_t64 (RIFE_HIP_RS=0 at create time: A/B, bit-equality test)
     bool rs = true;
+    // coarse-block trunks on the weight-stationary K-split kernel (conv_ks.h): bit mask by channel count, see launch_ks (RIFE_HIP_KS at create time)
+    int ks_mask = 3;
     // block 3: block-input assembly + both stem convolutions in one row-streaming kernel (stem_rs.h) instead of stem0_fused_kernel + conv_h2s2_kernel
     // (RIFE_HIP_STEM_RS=0 at create time: A/B, the comparison test)
     bool stem_rs = true;
@@ -1139,7 +1186,7 @@ static bool block_on_row_kernel(const rife_hip& E, const Ctx& c, int b) {
     const rife_hip::Block& B = E.blk[b];
     const int s = B.scale, Ht = c.hp / s / 4, Wt = c.wp / s / 4;
     const int ptiles = ((Ht + 7) / 8) * ((Wt + 31) / 32), cus = device_cus();
-    const bool row_small = b == 2 && B.c == 96 && ptiles <= cus;                               // fewer 8 x 32 tiles than the chip has CUs
+    const bool row_small = b == 2 && B.c == 96 && (ptiles <= cus || (E.ks_mask & 4));          // fewer 8 x 32 tiles than the chip has CUs (or conv_ks at every size)
     return (b == 1 && B.c == 128) || (b == 0 && B.c == 192 && ((Wt + 31) / 32) * Ht <= cus * 5 / 8) || row_small;      // MI355X: 160 of 256
 }
 
@@ -1254,7 +1301,8 @@ after_stem0:
         unsigned char *pc = PA, *pn = PB;
         if (phases & PH_TRUNK) for (int i = 0; i < 8; i++) {
             Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
-            if (rowk) rc = launch_row(B.res[i], pc, pn, Ht, Wt, st);
+            if (rowk && ks_serves(E.ks_mask, B.c)) rc = launch_ks(B.res[i], pc, pn, Ht, Wt, st);
+            else if (rowk) rc = launch_row(B.res[i], pc, pn, Ht, Wt, st);
             else if (E.rs && B.c == 64 && (Ht + 1) / 2 >= RS_MIN_PAIRS) rc = launch_rs(B.res[i], pc, pn, Ht, Wt, st, (i & 1) != 0);      // tiny tensors: conv_t64
             else rc = launch_t64(B.res[i], pc, pn, Ht, Wt, st, (i & 1) == 0);
             if (rc) return rc;
@@ -1392,7 +1440,9 @@ static int run_v4_group(const rife_hip& E, Ctx* const* cs, int G, const uint8_t*
             for (int i = 0; i < 8; i++) {
                 for (int g = 0; g < G; g++) { pin[g] = cs[g]->P[b][i & 1]; pout[g] = cs[g]->P[b][(i & 1) ^ 1]; }
                 Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt * G, lead);
-                if ((rc = launch_row(B.res[i], nullptr, nullptr, Ht, Wt, lead, G, pin, pout))) return rc;
+                if (ks_serves(E.ks_mask, B.c)) rc = launch_ks(B.res[i], nullptr, nullptr, Ht, Wt, lead, G, pin, pout);
+                else rc = launch_row(B.res[i], nullptr, nullptr, Ht, Wt, lead, G, pin, pout);
+                if (rc) return rc;
             }
         }
         HIPCHK(hipEventRecord(cs[0]->ev_group, lead));
@@ -2159,6 +2209,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     E->frame_pool->gpuid = gpuid;
     { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_RS"); E->rs = !(e && e[0] == '0'); }
+    { const char* e = getenv("RIFE_HIP_KS"); if (e && e[0] >= '0' && e[0] <= '9') E->ks_mask = atoi(e); }
     { const char* e = getenv("RIFE_HIP_STEM_RS"); E->stem_rs = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_TTA_CONSENSUS"); E->tta_consensus = !(e && e[0] == '0'); }
     { const char* e = getenv("RIFE_HIP_TAIL_RS"); E->tail_rs = !(e && e[0] == '0'); E->tail_rs_always = e && e[0] == '2'; }
