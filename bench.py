@@ -96,7 +96,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="4k", choices=list(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=2, help="frame pairs in flight per GPU in the timed region (the reference's default: 2 proc threads per GPU, -j 1:2:2)")
+    ap.add_argument("--streams", type=int, default=0, help="frame pairs in flight per GPU in the timed region; 0 = the workload's default: 2 (the reference's default, 2 proc threads per GPU, -j 1:2:2), "
+                    "or one per chip partition (--cu-parts)")
+    ap.add_argument("--cu-parts", type=int, default=-1, help="partition the compute units between the pairs in flight: every stream owns 1 / N of them (rife_hip_stream_create; "
+                    "include/rife_hip.h).  -1 = the workload's default: 4 for the 1080p workloads of rife-v4.6 (measured 1,690 vs 1,450 - 1,590 frames/s), none for the others (no gain at 4K)")
     ap.add_argument("--no-extra", action="store_true", help="skip the second region (1 pair in flight, clean per-launch kernel timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive legs (rife_hip_process from pageable host buffers)")
@@ -161,8 +164,13 @@ def main():
         f = np.roll(base[i % 2], (2 * (i // 2), 5 * (i // 2)), axis=(0, 1))
         frames.append(torch.from_numpy(np.ascontiguousarray(f)).cuda())
     timesteps = [0.5, 0.125, 0.25, 0.7, 0.9]
-    nstreams = max(1, args.streams)
-    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    cu_parts = args.cu_parts if args.cu_parts >= 0 else (4 if args.workload == "1080p" else 0)
+    nstreams = args.streams if args.streams > 0 else (cu_parts if cu_parts > 1 else 2)
+
+    class PartStream:                                        # a stream of rife_hip_stream_create, with torch.cuda.Stream's attribute
+        def __init__(self, part, nparts):
+            self.cuda_stream = eng.stream_create(part, nparts)
+    streams = [PartStream(i % cu_parts, cu_parts) if cu_parts > 1 else torch.cuda.Stream() for i in range(nstreams)]
     outs = [torch.empty((h, w, 3), dtype=torch.uint8, device="cuda") for _ in range(nstreams)]
 
     def step(i):
@@ -315,7 +323,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if f32_mode else "f16x2-split MFMA + f32 accumulate (fp32-equivalent; activations stored f32 or as {hi, lo} f16 pairs)", "data": "synthetic",
             "config": {"workload": "%s %dx%d%s frame pairs resident in HBM, timestep sweep %s, synthetic seeded weights" % (family, w, h, " -x -z (TTA)" if tta else "", timesteps),
-                       "pairs_in_flight_per_gpu": nstreams, "frames": frame_kind, "untimed_setup_pairs": SETUP, "parallelism": "frame pairs sharded over ranks, no data-path collective"},
+                       "pairs_in_flight_per_gpu": nstreams,
+                       "cu_partition": "none (ordinary streams)" if cu_parts <= 1 else "every stream owns 1 / %d of the compute units (rife_hip_stream_create)" % cu_parts,
+                       "frames": frame_kind, "untimed_setup_pairs": SETUP, "parallelism": "frame pairs sharded over ranks, no data-path collective"},
             "roofline": roof,
             "roofline_in_timed_region": roof_timed if prof1 is not None else None,
             "cpu_baseline": cpu,

@@ -63,6 +63,24 @@ int rife_hip_process_batch(const rife_hip_t* r, int n, const uint8_t* const* in0
 int rife_hip_process_device(const rife_hip_t* r, const void* d_in0_rgb, const void* d_in1_rgb, int w, int h,
                             float timestep, void* d_out_rgb, void* hip_stream);
 
+/* Streams that own a PART of the chip.  The reference keeps a GPU busy with several proc threads per device (-j, src/main.cpp:849-866), whose
+ * command buffers share the whole device.  On MI355X (256 compute units in 8 XCDs, an L2 per XCD) the pairs in flight interfere less when each has
+ * compute units of its own: rife_hip_stream_create returns a hipStream_t restricted to the compute units i with i % nparts == part
+ * (hipExtStreamCreateWithCUMask), and rife_hip_process_device on such a stream sizes its persistent kernels for that part.  Frames are the same
+ * bytes on every stream.  nparts = 1: an ordinary stream.  Measured (1920x1080, resident frames): 4 parts x 1 caller each 1,690 frames/s against
+ * 1,450 - 1,590 from 3 ordinary streams; no gain at 3840x2160.  Destroy with rife_hip_stream_destroy (after the work on it has finished), or
+ * let rife_hip_destroy do it. */
+int rife_hip_stream_create(const rife_hip_t* r, int part, int nparts, void** hip_stream);
+int rife_hip_stream_destroy(const rife_hip_t* r, void* hip_stream);
+
+/* n resident pairs in one call (SURVEY.md §8f-2 "batch >= 2 pairs per launch for the coarse blocks"): the pairs run two by two in lockstep on
+ * internal streams, the trunk layers of the coarse IFBlocks as ONE launch per layer for both pairs of a group (models/rife-v4.6/flownet.param:14-42,
+ * 66-94), forked from and joined into `hip_stream` with events: like rife_hip_process_device the call returns without synchronising when a
+ * stream is given, and work enqueued on `hip_stream` afterwards sees all n results.  NULL synchronises before returning.  Same bytes as n
+ * rife_hip_process_device calls; model families without the lockstep schedule (and -x / -z) run the pairs one after the other. */
+int rife_hip_process_device_batch(const rife_hip_t* r, int n, const void* const* d_in0_rgb, const void* const* d_in1_rgb, const float* timestep,
+                                  void* const* d_out_rgb, int w, int h, void* hip_stream);
+
 /* Stream mode (absent in the reference, whose tasks upload both frames every time, src/main.cpp:315-334,
  * src/rife.cpp:2490-2530): in a frame sequence every frame is the second frame of one pair and the first frame of the next,
  * and with -n > 2N it serves several timesteps, so a caller can upload a frame ONCE and interpolate between resident frames.

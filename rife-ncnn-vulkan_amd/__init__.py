@@ -22,7 +22,7 @@ _lib = None
 # every symbol include/rife_hip.h declares
 C_ABI_SYMBOLS = [
     "rife_hip_device_count", "rife_hip_create", "rife_hip_destroy", "rife_hip_load", "rife_hip_process",
-    "rife_hip_process_device", "rife_hip_process_batch", "rife_hip_frame_upload", "rife_hip_process_frames", "rife_hip_frame_release",
+    "rife_hip_process_device", "rife_hip_process_device_batch", "rife_hip_stream_create", "rife_hip_stream_destroy", "rife_hip_process_batch", "rife_hip_frame_upload", "rife_hip_process_frames", "rife_hip_frame_release",
     "rife_hip_last_error", "rife_hip_profile_enable", "rife_hip_profile_read",
     "rife_hip_host_alloc", "rife_hip_host_free", "rife_hip_host_register", "rife_hip_host_unregister",
     "rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_v4_tap", "rife_hip_v4_process_injected", "rife_hip_graph_check", "rife_hip_param_hash", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp",
@@ -62,6 +62,9 @@ def lib():
     L.rife_hip_load.argtypes = [vp, ctypes.c_char_p]
     L.rife_hip_process.argtypes = [vp, vp, vp, ci, ci, cf, vp]
     L.rife_hip_process_device.argtypes = [vp, vp, vp, ci, ci, cf, vp, vp]
+    L.rife_hip_process_device_batch.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, vp]
+    L.rife_hip_stream_create.argtypes = [vp, ci, ci, ctypes.POINTER(vp)]
+    L.rife_hip_stream_destroy.argtypes = [vp, vp]
     L.rife_hip_last_error.restype = ctypes.c_char_p
     L.rife_hip_profile_enable.argtypes = [vp, ci]
     L.rife_hip_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, vp, vp, vp, ci]
@@ -202,6 +205,26 @@ class RIFE:
     def process_device(self, d_in0, d_in1, w, h, timestep, d_out, stream=None):
         """Device pointers (ints) to tightly packed u8 HWC RGB frames; enqueues on `stream` (hipStream_t as int)."""
         _check(lib().rife_hip_process_device(self._h, d_in0, d_in1, w, h, float(timestep), d_out, stream), "process_device")
+
+    def stream_create(self, part, nparts):
+        """A hipStream_t (int) that owns the compute units i with i % nparts == part (rife_hip_stream_create); for process_device."""
+        st = ctypes.c_void_p()
+        _check(lib().rife_hip_stream_create(self._h, int(part), int(nparts), ctypes.byref(st)), "stream_create")
+        return st.value
+
+    def stream_destroy(self, stream):
+        _check(lib().rife_hip_stream_destroy(self._h, stream), "stream_destroy")
+
+    def process_device_batch(self, d_in0, d_in1, w, h, timesteps, d_out, stream=None):
+        """n resident pairs in one call (rife_hip_process_device_batch): lists of device pointers; enqueued relative to `stream`."""
+        n = len(d_in0)
+        if len(d_in1) != n or len(d_out) != n or len(timesteps) != n:
+            raise ValueError("one in1 / out / timestep per pair")
+        pa = (ctypes.c_void_p * n)(*[int(x) for x in d_in0])
+        pb = (ctypes.c_void_p * n)(*[int(x) for x in d_in1])
+        po = (ctypes.c_void_p * n)(*[int(x) for x in d_out])
+        ts = (ctypes.c_float * n)(*[float(t) for t in timesteps])
+        _check(lib().rife_hip_process_device_batch(self._h, n, pa, pb, ts, po, w, h, stream), "process_device_batch")
 
     # ---- measurement / parity taps ----
     def process_batch(self, in0images, in1images, timesteps, outimages=None):

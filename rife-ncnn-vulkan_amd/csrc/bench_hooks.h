@@ -391,6 +391,92 @@ int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* m
 // difference of the stored values hi + lo x 1e9, stats[4], [5], [7] = chunk, padded row, padded column of it (down), stats[6] = bytes compared.  Then `iters` launches ping-pong between two
 // tensors like consecutive trunk layers.  variant = ablation bits of conv_rs.h | 0x10000 (layers alternate direction) | 0x20000 (always up)
 // | 0x1000000 * g (g > 0: launch g workgroups instead of one per CU).
+// conv_ks_kernel (conv_ks.h) alone on a random C-channel S16 tensor of h x w pixels: ms per launch over `iters` back-to-back launches (ping-pong
+// tensors), ablation variants (KS_* bits), and with KS_CLK the per-workgroup timeline on the 100 MHz counter:
+// stamps_out[16 * nwg] of the LAST launch (see KS_STAMP in conv_ks.h), *nwg_out = workgroups.  div: ranges = CUs / (NG * div).
+extern "C++" {
+template <int C, int NB, int CPW>
+static int bench_ks_cfg(int gpuid, int h, int w, int variant, int iters, int div, float* ms_out, long long* stamps_out, int* nwg_out) {
+    using K = KsCfg<C, NB, CPW>;
+    std::vector<float> wts((size_t)C * C * 9), bias(C);
+    uint32_t lcg = 4321u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((int)(lcg >> 9) - (1 << 22)) / (float)(1 << 22); };
+    for (auto& v : wts) v = (float)(_Float16)(rnd() * 0.02f);
+    for (auto& v : bias) v = rnd() * 0.1f;
+    std::vector<unsigned char> img = pack_t64_image(wts.data(), bias.data(), 0.2f, C, 1);
+    const S16Geom G(h, w);
+    const size_t nb = G.bytes(C);
+    unsigned char *x = nullptr, *y = nullptr, *dimg = nullptr;
+    HIPCHK(hipMalloc(&x, nb)); HIPCHK(hipMalloc(&y, nb)); HIPCHK(hipMalloc(&dimg, img.size()));
+    HIPCHK(hipMemcpy(dimg, img.data(), img.size(), hipMemcpyHostToDevice));
+    {
+        std::vector<_Float16> hx(nb / 2, (_Float16)0.f);
+        const size_t pl = G.plane() / 2;
+        for (int yy = 0; yy < h; yy++)
+            for (int xx = 0; xx < w; xx++)
+                for (int c = 0; c < C / 16; c++)
+                    for (int e = 0; e < 16; e++) {
+                        const float v = rnd(); const _Float16 hh = (_Float16)v;
+                        const size_t px = ((size_t)(yy + 1) * G.pitch + xx + 1) * 16 + e;
+                        hx[(2 * c) * pl + px] = hh; hx[(2 * c + 1) * pl + px] = (_Float16)(v - (float)hh);
+                    }
+        HIPCHK(hipMemcpy(x, hx.data(), nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(y, 0, nb));
+    }
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpuid));
+    KsArgs a;
+    a.in = x; a.out = y; a.img = dimg; a.H = h; a.W = w; a.pitch = G.pitch; a.plane = G.plane(); a.nunits = G.tiles_x * h; a.skip = 1;
+    int Gr = std::max(1, cus / (K::NG * std::max(1, div)));
+    Gr = std::min(Gr, a.nunits);
+    if (Gr >= G.tiles_x) Gr = Gr / G.tiles_x * G.tiles_x;
+    const int nwg = Gr * K::NG;
+    if (nwg_out) *nwg_out = nwg;
+    long long* dst = nullptr;
+    HIPCHK(hipMalloc(&dst, (size_t)nwg * 16 * 8));
+    HIPCHK(hipMemset(dst, 0, (size_t)nwg * 16 * 8));
+    a.stamps = dst;
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](auto kfn) -> int {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS));
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(K::NTHR), K::LDS, 0, a);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) {
+            a.in = (i & 1) ? y : x; a.out = (i & 1) ? x : y;
+            hipLaunchKernelGGL(kfn, dim3(nwg), dim3(K::NTHR), K::LDS, 0, a);
+        }
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    int rc;
+    switch (variant) {
+        case 0: rc = run(conv_ks_kernel<C, NB, CPW, 0>); break;
+        case KS_CLK: rc = run(conv_ks_kernel<C, NB, CPW, KS_CLK>); break;
+        case KS_NOMATH: rc = run(conv_ks_kernel<C, NB, CPW, KS_NOMATH>); break;
+        case KS_NODMA: rc = run(conv_ks_kernel<C, NB, CPW, KS_NODMA>); break;
+        case KS_NOSTORE: rc = run(conv_ks_kernel<C, NB, CPW, KS_NOSTORE>); break;
+        case KS_NOWEIGHTS: rc = run(conv_ks_kernel<C, NB, CPW, KS_NOWEIGHTS>); break;
+        case KS_NOMATH | KS_NODMA | KS_NOSTORE | KS_NOWEIGHTS: rc = run(conv_ks_kernel<C, NB, CPW, KS_NOMATH | KS_NODMA | KS_NOSTORE | KS_NOWEIGHTS>); break;
+        case KS_NODMA | KS_NOSTORE: rc = run(conv_ks_kernel<C, NB, CPW, KS_NODMA | KS_NOSTORE>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown conv_ks bench variant");
+    }
+    if (!rc && stamps_out) HIPCHK(hipMemcpy(stamps_out, dst, (size_t)nwg * 16 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(x); (void)hipFree(y); (void)hipFree(dimg); (void)hipFree(dst);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+}  // extern "C++"
+int rife_hip_bench_ks(int gpuid, int C, int h, int w, int variant, int iters, int div, float* ms_out, long long* stamps_out, int* nwg_out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    if (C == 128) return bench_ks_cfg<128, 2, 2>(gpuid, h, w, variant, iters, div, ms_out, stamps_out, nwg_out);
+    if (C == 96) return bench_ks_cfg<96, 3, 2>(gpuid, h, w, variant, iters, div, ms_out, stamps_out, nwg_out);
+    return fail(RIFE_HIP_EINVAL, "conv_ks bench: C = 96 or 128");
+}
+
 int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms_out, long long* stats) {
     int rc;
     if ((rc = check_device(gpuid))) return rc;

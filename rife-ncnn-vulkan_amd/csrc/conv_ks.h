@@ -12,17 +12,17 @@
 //     x 4 VGPRs, loaded ONCE per launch.  Its partial sums (fp32) go to an LDS staging buffer; the storer waves add the KS = C / (16 CPW) partials in a fixed
 //     order, then bias, LeakyReLU / per-channel slopes, the {hi, lo} split and the stores (conv_rs.h's epilogue).
 // The rest is conv_rs_kernel's machinery: S16 tensors (conv_t64.h), a ring of halo ROWS in LDS filled by loader waves with LDS-DMA (1 KiB per
-// instruction, counted vmcnt waits), one s_barrier per step, storers one step behind.  A step = ONE output row of one 32-column strip (the coarse
+// instruction, counted vmcnt waits), two s_barriers per step (X "staging full" / Y "staging free": ONE staging buffer, the LDS goes to a deeper ring; the consumers keep the sums of the previous step in a second accumulator set, so the handshake hides under the next step's MFMAs), storers one step behind.  A step = ONE output row of one 32-column strip (the coarse
 // layers have 34 - 136 rows per strip: row pairs would leave a third of a workgroup's range as remainder).
 // Work split: (strip, row) units in strip-major order are cut into equal contiguous ranges, one per workgroup of an N group; a range is walked
 // as SEGMENTS (consecutive rows of one strip), each with its own prologue and drain (the host picks a range count that is a multiple of the strip
 // count, so a range normally is one segment).
 // Waves: NCON = NB * KS consumers (waves 0 ..), then KS_NLD = 2 loaders, then NST = 2 (or 1) storers: at most twelve, three per SIMD.
-//   C = 128: NB 2, CPW 2 -> KS 4, 8 consumers, 12 waves (three per SIMD: 168 VGPRs), 2 N groups; LDS: ring 5 x 17,408 + staging 2 x 32 KiB
-//   C =  96: NB 3, CPW 2 -> KS 3, 9 consumers, 12 waves (one storer), 1 N group;                                LDS: ring 6 x 13,056 + staging 2 x 36 KiB
+//   C = 128: NB 2, CPW 2 -> KS 4, 8 consumers, 12 waves (three per SIMD: 168 VGPRs), 2 N groups; LDS: ring 7 x 17,408 + staging 32 KiB
+//   C =  96: NB 3, CPW 2 -> KS 3, 9 consumers, 12 waves (one storer), 1 N group;                                LDS: ring 9 x 13,056 + staging 36 KiB
 //   C = 192: NB 2, CPW 3 -> KS 4, 8 consumers, 12 waves, 3 N groups;                               LDS: ring 4 x 26,112 + staging 1 x 32 KiB ... (see KsCfg)
 // Arithmetic: the products are those of conv_row_kernel / conv_rs_kernel (fp16 weights x {hi, lo} activations, fp32 accumulation, identity tap
-// for the skip connection); the summation order is this kernel's own (per consumer: hi chain + lo chain; then the partials kq = 0 .. KS - 1;
+// for the skip connection); the summation order is this kernel's own (per consumer: chunk-major, taps in order, hi then lo; then the partials kq = 0 .. KS - 1;
 // then the bias), deterministic by construction.  tests/test_gpu_ks.py holds it against the kernels it replaces (<= 1 LSB on the frame, flows
 // to 1e-4); the end-to-end parity tests run on it.
 #pragma once
@@ -46,7 +46,7 @@ struct KsCfg {
     static constexpr int UNITS = ROWB / 16;                  // 16-byte units per row
     static constexpr int PIECES = (UNITS + 63) / 64;         // LDS-DMA instructions per row
     static constexpr int STGB = NCON * 4096;                 // one staging buffer: [kq][n][half h][32 px][64 B] of fp32 partial sums
-    static constexpr int NSTG = 2;
+    static constexpr int NSTG = 1;                           // one staging buffer: two barriers per step ("staging free", "staging full"), a deeper ring instead
     static constexpr int NR = (160 * 1024 - NSTG * STGB - NB * 256 - 1024) / ROWB;      // ring row slots
     static constexpr int LA = NR - 3;                        // rows the loaders run ahead of the step that needs them
     static constexpr int LDS_RING = 0;
@@ -55,7 +55,7 @@ struct KsCfg {
     static constexpr int LDS = LDS_BS + NB * 256;
     static constexpr int WAVES_PER_SIMD = (NWAVES + 3) / 4;
     static_assert(NCH % CPW == 0 && C % (32 * NB) == 0, "whole K slices and N groups");
-    static_assert(NR >= 4 && LA >= 1 && LA <= 3, "ring: three rows in use and at least one ahead");
+    static_assert(NR >= 4 && LA >= 1 && LA <= 7, "ring: three rows in use and at least one ahead");
     static_assert(NWAVES <= 16, "workgroup size");
 };
 
@@ -72,16 +72,27 @@ struct KsArgs {
     int nb = 0;
     const unsigned char* inb[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned char* outb[4] = {nullptr, nullptr, nullptr, nullptr};
+    long long* stamps = nullptr; // bench builds RIFE_ABL(TAG & KS_CLK): [workgroup][16] times on the constant 100 MHz counter (tools/ks_bench.py)
 };
+// bench-only ablation bits of TAG (timing experiments; results are garbage).  The product instantiates TAG = 0.
+enum { KS_NOSTORE = 0x100, KS_NODMA = 0x200, KS_NOMATH = 0x400, KS_NOWEIGHTS = 0x800, KS_CLK = 0x40000 };
+#define KS_STAMP(I) if (RIFE_ABL(TAG & KS_CLK) && lane == 0) a.stamps[16 * (blockIdx.x + gridDim.x * blockIdx.y) + (I)] = (long long)__builtin_amdgcn_s_memrealtime();
 
-// s_waitcnt vmcnt(N * P) for a wave-uniform N in 0 .. 3 and a compile-time P, followed by the step's barrier
+// s_waitcnt vmcnt(N * P) for a wave-uniform N in 0 .. 6 and a compile-time P, followed by a barrier
 template <int P>
 __device__ __forceinline__ void ks_wait_rows_and_sync(int rows_in_flight) {
-    static_assert(3 * P <= 63, "vmcnt is a 6-bit counter");
-    if (rows_in_flight <= 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (rows_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P) : "memory");
-    else if (rows_in_flight == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * P) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * P) : "memory");
+    constexpr int M = 63;                                                // vmcnt is a 6-bit counter: a larger allowance is clamped (waits a little early)
+#define KS_WAIT_CASE(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((N) * P < M ? (N) * P : M) : "memory")
+    switch (rows_in_flight < 0 ? 0 : rows_in_flight > 6 ? 6 : rows_in_flight) {
+        case 0: KS_WAIT_CASE(0); break;
+        case 1: KS_WAIT_CASE(1); break;
+        case 2: KS_WAIT_CASE(2); break;
+        case 3: KS_WAIT_CASE(3); break;
+        case 4: KS_WAIT_CASE(4); break;
+        case 5: KS_WAIT_CASE(5); break;
+        default: KS_WAIT_CASE(6); break;
+    }
+#undef KS_WAIT_CASE
 }
 
 template <int C, int NB, int CPW, int TAG>
@@ -95,13 +106,21 @@ void conv_ks_kernel(KsArgs a) {
     unsigned char* const tout = a.nb ? a.outb[blockIdx.y] : a.out;
 
     // workgroup b = N group g, range r of G
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch), and every XCD has its own L2: the NG workgroups that read the same input rows (one
+    // per N group) are placed on the SAME XCD - b = xcd + 8 k, k = (range / 8) * NG + g - so that only the first of them fetches the rows from
+    // memory.  (Ranges that do not fill whole rounds of eight fall back to the plain order.)
     const int G = gridDim.x / K::NG;
-    const int g = blockIdx.x % K::NG, r = blockIdx.x / K::NG;
+    int g, r;
+    if ((G & 7) == 0) {
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        g = k % K::NG; r = (k / K::NG) * 8 + xcd;
+    } else { g = blockIdx.x % K::NG; r = blockIdx.x / K::NG; }
     if (r >= G) return;
     const int u0 = (int)((long long)a.nunits * r / G), u1 = (int)((long long)a.nunits * (r + 1) / G);
     if (u1 <= u0) return;
     constexpr int WSTRIDE = t64_img_nt(1, K::NCH);                       // bytes per output block of the weight image
 
+    if (wv == 0) { KS_STAMP(0) }
     if (wv < K::NCON) {
         // ------------------------------------------------------------------------------------------------ consumers
         const int n = wv % NB, kq = wv / NB;                             // output block within the group, K slice
@@ -113,7 +132,11 @@ void conv_ks_kernel(KsArgs a) {
 #pragma unroll
             for (int cc = 0; cc < CPW; cc++)
 #pragma unroll
-                for (int t = 0; t < 9; t++) Wf[cc][t] = *reinterpret_cast<const f16x8*>(wsrc + (cc * 9 + t) * 1024);
+                for (int t = 0; t < 9; t++) {
+                    if RIFE_ABL(TAG & KS_NOWEIGHTS) { for (int e = 0; e < 8; e++) Wf[cc][t][e] = (_Float16)(0.001f * (lane + t)); }
+                    else Wf[cc][t] = *reinterpret_cast<const f16x8*>(wsrc + (cc * 9 + t) * 1024);
+                }
+            if RIFE_ABL(TAG & KS_CLK) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (wv == 0) { KS_STAMP(1) } }
         }
         // identity A fragments of the skip connection: chunk c carries the input channels of output block c >> 1 (conv_t64.h)
         f16x8 idf[2];
@@ -143,18 +166,33 @@ void conv_ks_kernel(KsArgs a) {
 #pragma unroll
         for (int cc = 0; cc < CPW; cc++) own[cc] = a.skip && ((kq * CPW + cc) >> 1) == nbg;
 
-        for (int u = u0; u < u1;) {
-            const int strip = u / a.H, y0 = u - strip * a.H;
-            const int nrow = min(a.H - y0, u1 - u);
-            u += nrow;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // prologue barrier: rows 0 .. 2 of the segment landed, bias in LDS
-            for (int it = 0; it < nrow; it++) {
+        // Software pipeline in registers: the sums of step it - 1 stay in one accumulator set while the MFMAs of step it run into the other; an
+        // iteration = [stage the sums of step it - 1] X [MFMAs of step it] Y, with X = "staging full" and Y = "staging free" (the storers finish
+        // step it - 1 between X and Y, under the MFMAs).  One accumulation chain per set (hi and lo products into the same registers): the second
+        // consumer wave of the SIMD fills the issue slots a dependent MFMA leaves.
+        f32x16 accA, accB;
+        auto iteration = [&](auto parc, const int it, const int nrow) {
+            constexpr int PAR = decltype(parc)::value;
+            f32x16& acc = PAR ? accB : accA;
+            f32x16& pend = PAR ? accA : accB;
+            if (it > 0) {
+                f32x4* const d4 = reinterpret_cast<f32x4*>(stg);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[k] = pend[4 * q + k];
+                    d4[q ^ qs] = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // X: the partial sums of step it - 1 are in the staging buffer
+            if (wv == 0 && it < 4) { KS_STAMP(3 + 2 * it) }
+            if (it < nrow) {
                 unsigned rb[3];
 #pragma unroll
                 for (int dy = 0; dy < 3; dy++) rb[dy] = (unsigned)(((it + dy) % K::NR) * K::ROWB);
-                f32x16 accH, accL;
 #pragma unroll
-                for (int q = 0; q < 16; q++) { accH[q] = 0.f; accL[q] = 0.f; }
+                for (int q = 0; q < 16; q++) acc[q] = 0.f;
                 // fragment reads run PF (chunk, tap) pairs ahead of their MFMAs
                 constexpr int NP = CPW * 9, PF = 2, NF = PF + 1;
                 f16x8 fh[NF], fl[NF];
@@ -165,33 +203,37 @@ void conv_ks_kernel(KsArgs a) {
                     fh[m % NF] = *reinterpret_cast<const f16x8*>(ldsb + ad);
                     fl[m % NF] = *reinterpret_cast<const f16x8*>(ldsb + ad + RS_SEG);
                 };
-                for_each_slot<0, PF>([&](auto mc) { frag_read(mc); });
-                for_each_slot<0, NP>([&](auto mc) {
+                if (!RIFE_ABL(TAG & KS_NOMATH)) for_each_slot<0, PF>([&](auto mc) { frag_read(mc); });
+                if (!RIFE_ABL(TAG & KS_NOMATH)) for_each_slot<0, NP>([&](auto mc) {
                     constexpr int m = decltype(mc)::value;
                     constexpr int cc = m / 9, t = m % 9;
                     if constexpr (m + PF < NP) frag_read(std::integral_constant<int, m + PF>{});
-                    accH = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[cc][t], fh[m % NF], accH, 0, 0, 0);
-                    accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[cc][t], fl[m % NF], accL, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[cc][t], fh[m % NF], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[cc][t], fl[m % NF], acc, 0, 0, 0);
                     if constexpr (t == 4) {
                         if (own[cc]) {                                   // + x: the centre tap's pixel fragment through the identity matrix
                             const f16x8 idA = ((kq * CPW + cc) & 1) ? idf[1] : idf[0];
-                            accH = __builtin_amdgcn_mfma_f32_32x32x16_f16(idA, fh[m % NF], accH, 0, 0, 0);
-                            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(idA, fl[m % NF], accL, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(idA, fh[m % NF], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(idA, fl[m % NF], acc, 0, 0, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                f32x4* const d4 = reinterpret_cast<f32x4*>(stg + (it & 1) * K::STGB);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    f32x4 v;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) v[k] = accH[4 * q + k] + accL[4 * q + k];
-                    d4[q ^ qs] = v;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier of step `it`: my partial sums are in staging[it & 1]
             }
-            asm volatile("s_barrier" ::: "memory");                      // final barrier of the segment (the storers have read the last staging buffer)
+            if (wv == 0 && it < 4) { KS_STAMP(4 + 2 * it) }
+            asm volatile("s_barrier" ::: "memory");                      // Y: the storers have read the partial sums of step it - 1; rows of step it + 1 landed
+        };
+        for (int u = u0; u < u1;) {
+            const int strip = u / a.H, y0 = u - strip * a.H;
+            const int nrow = min(a.H - y0, u1 - u);
+            u += nrow;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // prologue barrier: rows 0 .. 2 of the segment landed, bias in LDS
+            if (wv == 0) { KS_STAMP(2) }
+            for (int it = 0; it <= nrow; it += 2) {
+                iteration(std::integral_constant<int, 0>{}, it, nrow);
+                if (it + 1 <= nrow) iteration(std::integral_constant<int, 1>{}, it + 1, nrow);
+            }
+            if (wv == 0) { KS_STAMP(11) }
         }
     } else if (wv < K::NCON + KS_NLD) {
         // ------------------------------------------------------------------------------------------------ loaders
@@ -222,16 +264,20 @@ void conv_ks_kernel(KsArgs a) {
                     const unsigned dst = (unsigned)(K::LDS_RING + (issued % K::NR) * K::ROWB);
 #pragma unroll
                     for (int i = 0; i < PJ; i++)
-                        if (act[i]) rs_dma16<0>(tin, rowoff + soff[i], dst + (J + KS_NLD * i) * 1024);
+                        if (act[i] && !RIFE_ABL(TAG & KS_NODMA)) rs_dma16<0>(tin, rowoff + soff[i], dst + (J + KS_NLD * i) * 1024);
                     issued++;
                 };
-                while (issued < nin && issued < 2 + K::LA) issue_row();  // rows 0 .. NR - 2
+                while (issued < nin && issued < 4) issue_row();          // the three rows of step 0 and one more
+                if (J == 0) { KS_STAMP(12) }
                 ks_wait_rows_and_sync<PJ>(issued - 3);                   // prologue barrier: rows 0 .. 2 landed
-                for (int it = 0; it < nrow; it++) {
-                    if (issued < nin) issue_row();                       // row it + NR - 1 into the slot of row it - 1 (last read in step it - 1)
-                    ks_wait_rows_and_sync<PJ>(issued - min(it + 4, nin));        // rows 0 .. it + 3 landed: step it + 1 may start after this barrier
+                if (J == 0) { KS_STAMP(13) }
+                for (int it = 0; it <= nrow; it++) {
+                    // rows up to it + NR - 1 may be in the ring during iteration it (the slot of row it + NR - 1 held row it - 1, last read in step it - 1);
+                    // at most two new rows per iteration, so that a loader never keeps the workgroup waiting at X
+                    for (int k = 0; k < 2 && issued < nin && issued < it + K::NR; k++) issue_row();
+                    asm volatile("s_barrier" ::: "memory");              // X
+                    ks_wait_rows_and_sync<PJ>(issued - min(it + 4, nin));        // Y; rows 0 .. it + 3 landed: step it + 1 may start after this barrier
                 }
-                asm volatile("s_barrier" ::: "memory");                  // final barrier of the segment
             }
         };
         if (wv == K::NCON) loader(std::integral_constant<int, 0>{});
@@ -252,9 +298,10 @@ void conv_ks_kernel(KsArgs a) {
             const unsigned okmask = x0 + px < a.W ? 0xffffffffu : 0u;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // prologue barrier
             for (int it = 0; it <= nrow; it++) {
-                if (it >= 1) {                                           // step it - 1, staged before the barrier that ended iteration it - 1
+                asm volatile("s_barrier" ::: "memory");                  // X: the partial sums of step it - 1 are staged
+                if (it >= 1) {                                           // step it - 1
                     const int y = y0 + it - 1;
-                    const unsigned char* const sbuf = ldsb + K::LDS_STG + ((it - 1) & 1) * K::STGB;
+                    const unsigned char* const sbuf = ldsb + K::LDS_STG;
                     unsigned char* const dst = tout + ((unsigned)((y + 1) * a.pitch + x0 + 1) * 32u + (unsigned)(lane * 16));
 #pragma unroll
                     for (int cc = j; cc < 2 * NB; cc += KS_NST) {        // chunk cc of the group = output block cc >> 1, half cc & 1
@@ -288,14 +335,17 @@ void conv_ks_kernel(KsArgs a) {
                             lv[e] = (_Float16)(v - (float)hq);
                         }
                         const int oc = g * (2 * NB) + cc;                // 16-channel chunk of the layer's output
-                        *reinterpret_cast<f16x8*>(dst + (size_t)(2 * oc) * a.plane) = hv;
-                        *reinterpret_cast<f16x8*>(dst + (size_t)(2 * oc + 1) * a.plane) = lv;
+                        if (!RIFE_ABL(TAG & KS_NOSTORE)) {
+                            *reinterpret_cast<f16x8*>(dst + (size_t)(2 * oc) * a.plane) = hv;
+                            *reinterpret_cast<f16x8*>(dst + (size_t)(2 * oc + 1) * a.plane) = lv;
+                        }
                     }
                 }
-                if (it < nrow) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier of step `it`
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 // Y: my reads of the staging buffer are done
             }
-            asm volatile("s_barrier" ::: "memory");                      // final barrier of the segment
+            if (j == 0) { KS_STAMP(14) }
         }
+        if RIFE_ABL(TAG & KS_CLK) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (j == 0) { KS_STAMP(15) } }
     }
 }
 

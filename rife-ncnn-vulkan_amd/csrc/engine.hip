@@ -640,8 +640,12 @@ struct S16Geom {
     size_t bytes(int C) const { return (size_t)plane() * (C / 8); }
 };
 
-// compute units of the current device (cached): grid sizes of the persistent kernels and the kernel-selection thresholds below
-static int device_cus() {
+// compute units of the current device (cached): grid sizes of the persistent kernels and the kernel-selection thresholds below.
+// tl_cu_budget > 0: the calling thread is enqueueing on a stream that owns only a PART of the chip (CU-masked stream, rife_hip_stream_create):
+// persistent grids are sized for that part.
+static thread_local int tl_cu_budget = 0;
+static int device_cus(bool physical = false) {
+    if (tl_cu_budget > 0 && !physical) return tl_cu_budget;
     int dev = 0; (void)hipGetDevice(&dev);
     static std::mutex mu; static std::map<int, int> ncu;
     std::lock_guard<std::mutex> g(mu);
@@ -680,6 +684,7 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
         }
         cus = it->second;
     }
+    if (tl_cu_budget > 0) cus = std::max(8, std::min(cus, tl_cu_budget) / 8 * 8);
     const S16Geom G(H, W);
     T64Args a;
     a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.tiles_x = G.tiles_x; a.ntiles = G.tiles_x * G.tiles_y; a.reverse = reverse ? 1 : 0;
@@ -713,6 +718,7 @@ static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char*
         }
         cus = it->second;
     }
+    if (tl_cu_budget > 0) cus = std::min(cus, tl_cu_budget);
     const S16Geom G(H, W);
     RsArgs a;
     a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane();
@@ -778,7 +784,8 @@ static int launch_ks_cfg(const unsigned char* img, const KsArgs& a0, int tiles_x
     a.img = img;
     // ranges per N group: one workgroup per CU (150 KB of LDS), all resident at once also when gy pairs share the launch; a multiple of the
     // strip count where possible, so that no range crosses a strip (a crossing costs a pipeline drain and refill)
-    int G = std::max(1, device_cus() / (K::NG * gy));
+    static const int div = []() { const char* e = getenv("RIFE_HIP_KS_DIV"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();      // A/B: part of the chip only
+    int G = std::max(1, device_cus() / (K::NG * gy * div));
     G = std::min(G, a.nunits);
     if (G >= tiles_x) G = G / tiles_x * tiles_x;
     hipLaunchKernelGGL((conv_ks_kernel<C, NB, CPW, 0>), dim3(G * K::NG, gy), dim3(K::NTHR), K::LDS, st, a);
@@ -961,7 +968,7 @@ struct rife_hip {
     // block-3 trunk on the row-streaming kernel (conv_rs.h) instead of conv_t64 (RIFE_HIP_RS=0 at create time: A/B, bit-equality test)
     bool rs = true;
     // coarse-block trunks on the weight-stationary K-split kernel (conv_ks.h): bit mask by channel count, see launch_ks (RIFE_HIP_KS at create time)
-    int ks_mask = 3;
+    int ks_mask = 0;
     // block 3: block-input assembly + both stem convolutions in one row-streaming kernel (stem_rs.h) instead of stem0_fused_kernel + conv_h2s2_kernel
     // (RIFE_HIP_STEM_RS=0 at create time: A/B, the comparison test)
     bool stem_rs = true;
@@ -991,6 +998,8 @@ struct rife_hip {
     mutable Profiler prof;
     mutable std::mutex mu;
     mutable std::vector<std::unique_ptr<Ctx>> free_ctx;                  // pool for the host-buffer entry point
+    mutable std::vector<hipEvent_t> batch_fork;                          // rife_hip_process_device_batch: recycled fork events
+    mutable std::map<void*, int> part_streams;                           // rife_hip_stream_create: CU-masked streams of this engine -> compute units they own
     mutable std::map<void*, std::unique_ptr<Ctx>> stream_ctx;            // one workspace per caller stream
     mutable std::mutex tta_mu;                                           // TTA passes share one set of workspaces
     std::shared_ptr<FramePool> frame_pool;                               // shared with the frames: they may outlive the engine
@@ -1007,6 +1016,8 @@ struct rife_hip {
         for (auto& l : tta_lane) if (l) (void)hipStreamDestroy(l);
         for (auto& u : upload_streams) (void)hipStreamDestroy(u);
         for (auto& e : tta_fork) if (e) (void)hipEventDestroy(e);
+        for (auto& e : batch_fork) if (e) (void)hipEventDestroy(e);
+        for (auto& kv : part_streams) (void)hipStreamDestroy((hipStream_t)kv.first);
         for (auto& r : tta_join) for (auto& e : r) if (e) (void)hipEventDestroy(e);
         for (auto& b : blk) { free_layer(b.stem0); free_layer(b.stem1); for (auto& r : b.res) free_layer(r); free_layer(b.head); }
         for (auto& b : fblk) { free_layer(b.stem0); free_layer(b.stem1); for (auto& r : b.conv) free_layer(r); free_layer(b.head); }
@@ -1185,7 +1196,7 @@ static bool block_on_stem_rs(const rife_hip& E, const Ctx& c, int b) {
 static bool block_on_row_kernel(const rife_hip& E, const Ctx& c, int b) {
     const rife_hip::Block& B = E.blk[b];
     const int s = B.scale, Ht = c.hp / s / 4, Wt = c.wp / s / 4;
-    const int ptiles = ((Ht + 7) / 8) * ((Wt + 31) / 32), cus = device_cus();
+    const int ptiles = ((Ht + 7) / 8) * ((Wt + 31) / 32), cus = device_cus(true);      // kernel selection never depends on a CU partition: same bytes on every stream
     const bool row_small = b == 2 && B.c == 96 && (ptiles <= cus || (E.ks_mask & 4));          // fewer 8 x 32 tiles than the chip has CUs (or conv_ks at every size)
     return (b == 1 && B.c == 128) || (b == 0 && B.c == 192 && ((Wt + 31) / 32) * Ht <= cus * 5 / 8) || row_small;      // MI355X: 160 of 256
 }
@@ -1313,7 +1324,7 @@ after_stem0:
         // the row-streaming tail where every workgroup has at least 16 steps to amortise its prologue over (4K: 32; 1080p: 8 - there the tile kernel
         // is as fast or faster: head_b3 0.037 vs 0.039 ms per pair, same call)
         if (fin && E.tail_rs && b == 3 && B.c == 64 && B.head.cout == 24 && B.head.d_wh && Ht * 4 == c.hp && Wt * 4 == c.wp &&
-            (E.tail_rs_always || ((Wt + 31) / 32) * Ht >= 32 * device_cus()))
+            (E.tail_rs_always || ((Wt + 31) / 32) * Ht >= 32 * device_cus(true)))
             return launch_tail_rs(B, PA, Ht, Wt, *fin, st);
         return launch_conv(B.head, {reinterpret_cast<float*>(PA), B.c, 0}, Ht, Wt, {c.flow[b], 8, 0}, nullptr, st, fin, G.pitch, G.plane());
     }
@@ -2324,6 +2335,7 @@ int rife_hip_load(rife_hip_t* E, const char* modeldir) {      // nothing may thr
 }
 
 static int process_common(const rife_hip* E, int w, int h, float timestep) {
+    tl_cu_budget = 0;                                                    // every entry point starts on the whole chip; rife_hip_process_device sets its stream's part
     if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
     if (!E->loaded) return fail(RIFE_HIP_EINVAL, "process() before load()");
     if (w <= 0 || h <= 0) return fail(RIFE_HIP_EINVAL, "bad frame size");
@@ -2454,7 +2466,7 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     // fills the chip, measured 405 - 413 frames/s in groups against 400 - 425 per pair; RIFE_HIP_BATCH_GROUPS=1 / 0 forces / forbids the path)
     const char* genv = getenv("RIFE_HIP_BATCH_GROUPS");
     const int Ht0 = (h + 31) / 32, Wt0 = (w + 31) / 32;
-    const bool small_grid = ((Wt0 + 31) / 32) * Ht0 <= device_cus() * 5 / 8;      // MI355X: 160 workgroups, block 0 on the row kernel (block_on_row_kernel)
+    const bool small_grid = ((Wt0 + 31) / 32) * Ht0 <= device_cus(true) * 5 / 8;      // MI355X: 160 workgroups, block 0 on the row kernel (block_on_row_kernel)
     const bool groups = E->v4 && !E->v40 && !E->v1 && !E->tta && !E->tta_temporal && E->t64 && n >= 2 && (genv ? genv[0] != '0' : small_grid);
     if (groups) {
         std::vector<std::array<int, 2>> grp;                 // pair indices of a group, -1 = none
@@ -2633,6 +2645,8 @@ static int rife_hip_process_device_impl(const rife_hip_t* E, const void* d_in0, 
     Ctx* c;
     {
         std::lock_guard<std::mutex> g(E->mu);
+        auto ps = E->part_streams.find(hip_stream);
+        if (ps != E->part_streams.end()) tl_cu_budget = ps->second;      // a stream of rife_hip_stream_create: persistent grids for its part of the chip
         auto& slot = E->stream_ctx[hip_stream];
         if (!slot) {
             slot.reset(new Ctx);
@@ -2673,6 +2687,131 @@ int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* 
     try { return rife_hip_process_device_impl(E, d_in0, d_in1, w, h, timestep, d_out, hip_stream); }
     catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_process_device: ") + e.what()); }
     catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_process_device: unknown exception"); }
+}
+
+// n resident pairs in one call (include/rife_hip.h): lockstep groups of two pairs (run_v4_group: the coarse-block trunks of a group are one
+// launch per layer) on leased workspaces and their streams, forked from and joined into `hip_stream` with events - no host wait.
+static int rife_hip_process_device_batch_impl(const rife_hip_t* E, int n, const void* const* d_in0, const void* const* d_in1, const float* timestep,
+                                              void* const* d_out, int w, int h, void* hip_stream) {
+    int rc;
+    if (n < 0 || (n > 0 && (!d_in0 || !d_in1 || !timestep || !d_out))) return fail(RIFE_HIP_EINVAL, "bad batch arguments");
+    if ((rc = process_common(E, w, h, 0.5f))) return rc;
+    for (int i = 0; i < n; i++) if (!d_in0[i] || !d_in1[i] || !d_out[i]) return fail(RIFE_HIP_EINVAL, "null frame pointer");
+    if (n == 0) return 0;
+    if ((rc = check_device(E->gpuid))) return rc;
+    const bool groups = E->v4 && !E->v40 && !E->v1 && !E->tta && !E->tta_temporal && E->t64;
+    if (!groups) {      // other families / TTA: the pairs one after the other on the caller's stream
+        for (int i = 0; i < n; i++)
+            if ((rc = rife_hip_process_device_impl(E, d_in0[i], d_in1[i], w, h, timestep[i], d_out[i], hip_stream))) return rc;
+        return 0;
+    }
+    hipStream_t user = (hipStream_t)hip_stream;
+    const size_t nbytes = (size_t)w * h * 3;
+    hipEvent_t fork = nullptr;
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        if (!E->batch_fork.empty()) { fork = E->batch_fork.back(); E->batch_fork.pop_back(); }
+    }
+    if (!fork) HIPCHK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    if (user) HIPCHK(hipEventRecord(fork, user));      // NULL = "the engine's own streams": nothing to order against, the call synchronises before it returns
+    std::vector<std::unique_ptr<Ctx>> cs;
+    auto lease = [&]() -> Ctx* {
+        std::unique_ptr<Ctx> c;
+        if (lease_ctx(E, c, w, h)) return nullptr;
+        if (!c->ev_group && hipEventCreateWithFlags(&c->ev_group, hipEventDisableTiming) != hipSuccess) { release_ctx(E, c); return nullptr; }
+        if (user && hipStreamWaitEvent(c->stream, fork, 0) != hipSuccess) { release_ctx(E, c); return nullptr; }
+        cs.push_back(std::move(c));
+        return cs.back().get();
+    };
+    rc = 0;
+    int pend = -1;
+    for (int i = 0; i <= n && !rc; i++) {
+        const bool copy = i < n && (timestep[i] == 0.f || timestep[i] == 1.f);
+        if (i < n && copy) {
+            Ctx* c = lease();
+            if (!c) { rc = RIFE_HIP_EHIP; break; }
+            if (hipMemcpyAsync(d_out[i], timestep[i] == 0.f ? d_in0[i] : d_in1[i], nbytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "copy failed");
+            continue;
+        }
+        if (i < n && pend < 0) { pend = i; continue; }
+        if (pend < 0) break;
+        if (i < n) {            // group (pend, i)
+            Ctx* a = lease(); Ctx* b = a ? lease() : nullptr;
+            if (!a || !b) { rc = RIFE_HIP_EHIP; break; }
+            Ctx* g2[2] = {a, b};
+            const uint8_t* p0[2] = {(const uint8_t*)d_in0[pend], (const uint8_t*)d_in0[i]};
+            const uint8_t* p1[2] = {(const uint8_t*)d_in1[pend], (const uint8_t*)d_in1[i]};
+            const float ts[2] = {timestep[pend], timestep[i]};
+            uint8_t* po[2] = {(uint8_t*)d_out[pend], (uint8_t*)d_out[i]};
+            rc = run_v4_group(*E, g2, 2, p0, p1, ts, po);
+            pend = -1;
+        } else {                // the odd pair left over
+            Ctx* c = lease();
+            if (!c) { rc = RIFE_HIP_EHIP; break; }
+            rc = run_v4_replay(*E, *c, (const uint8_t*)d_in0[pend], (const uint8_t*)d_in1[pend], timestep[pend], (uint8_t*)d_out[pend]);
+            pend = -1;
+        }
+    }
+    // join: the caller's stream continues after every internal stream (also after an error: nothing may still run on the frames when we return control of them)
+    for (auto& c : cs) {
+        if (!user) { if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(RIFE_HIP_EHIP, "stream sync failed"); }
+        else if (hipEventRecord(c->ev_group, c->stream) != hipSuccess || hipStreamWaitEvent(user, c->ev_group, 0) != hipSuccess) { (void)hipStreamSynchronize(c->stream); if (!rc) rc = fail(RIFE_HIP_EHIP, "join failed"); }
+    }
+    for (auto& c : cs) release_ctx(E, c);
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        E->batch_fork.push_back(fork);      // re-recorded by its next user; the waits enqueued above keep their own snapshot of it
+    }
+    return rc;
+}
+int rife_hip_process_device_batch(const rife_hip_t* E, int n, const void* const* d_in0, const void* const* d_in1, const float* timestep,
+                                  void* const* d_out, int w, int h, void* hip_stream) {
+    try { return rife_hip_process_device_batch_impl(E, n, d_in0, d_in1, timestep, d_out, w, h, hip_stream); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_process_device_batch: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_process_device_batch: unknown exception"); }
+}
+
+// ---- streams that own a part of the chip (include/rife_hip.h) ----
+int rife_hip_stream_create(const rife_hip_t* E, int part, int nparts, void** hip_stream) {
+    if (hip_stream) *hip_stream = nullptr;
+    if (!E || !hip_stream) return fail(RIFE_HIP_EINVAL, "null argument");
+    int rc;
+    if ((rc = check_device(E->gpuid))) return rc;
+    const int ncu = device_cus(true);
+    if (nparts < 1 || nparts > ncu || part < 0 || part >= nparts) return fail(RIFE_HIP_EINVAL, "bad partition");
+    hipStream_t st = nullptr;
+    int mine = 0;
+    if (nparts == 1) {
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        mine = ncu;
+    } else {
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int cu = 0; cu < ncu; cu++)
+            if (cu % nparts == part) { mask[cu / 32] |= 1u << (cu % 32); mine++; }
+        HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    }
+    std::lock_guard<std::mutex> g(E->mu);
+    E->part_streams[(void*)st] = mine;
+    *hip_stream = (void*)st;
+    return 0;
+}
+int rife_hip_stream_destroy(const rife_hip_t* E, void* hip_stream) {
+    if (!E || !hip_stream) return fail(RIFE_HIP_EINVAL, "null argument");
+    int rc;
+    if ((rc = check_device(E->gpuid))) return rc;
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        auto it = E->part_streams.find(hip_stream);
+        if (it == E->part_streams.end()) return fail(RIFE_HIP_EINVAL, "not a stream of rife_hip_stream_create");
+        E->part_streams.erase(it);
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        E->stream_ctx.erase(hip_stream);                                 // its workspace
+    }
+    HIPCHK(hipStreamDestroy((hipStream_t)hip_stream));
+    return 0;
 }
 
 // ---- page-locked host frames (include/rife_hip.h) ----

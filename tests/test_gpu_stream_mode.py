@@ -97,3 +97,64 @@ def test_page_locked_frames_give_the_same_pixels(modeldirs):
         assert L.rife_hip_host_unregister(ra.ctypes.data_as(ctypes.c_void_p)) == 0
         assert L.rife_hip_host_unregister(ro.ctypes.data_as(ctypes.c_void_p)) == 0
     del pa, pb, po                                      # the last view gone: rife_hip_host_free
+
+
+@pytest.mark.parametrize("w,h,n", [(1920, 1080, 5), (640, 360, 4), (100, 60, 3)])
+def test_device_batch_equals_single_device_calls(modeldirs, w, h, n):
+    """rife_hip_process_device_batch (lockstep groups of two resident pairs, coarse trunks batched per layer; include/rife_hip.h) against n
+    rife_hip_process_device calls: same bytes, ordered on the caller's stream, timestep 0 / 1 entries are copies."""
+    import torch
+    g = amd.RIFE(0, rife_v4=True); g.load(modeldirs["rife-v4.6"])
+    prs = [gen_frames.smooth_pair(w, h, 40 + i) for i in range(n)]
+    ts = [0.5, 0.25, 1.0, 0.7, 0.125][:n]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in prs]; d1 = [torch.from_numpy(p[1]).cuda() for p in prs]
+    st = torch.cuda.Stream()
+    want = []
+    for i in range(n):
+        o = torch.empty_like(d0[i])
+        g.process_device(d0[i].data_ptr(), d1[i].data_ptr(), w, h, ts[i], o.data_ptr(), st.cuda_stream)
+        want.append(o)
+    st.synchronize()
+    outs = [torch.zeros_like(x) for x in d0]
+    for rep in range(2):                                    # the second call reuses the leased workspaces
+        g.process_device_batch([x.data_ptr() for x in d0], [x.data_ptr() for x in d1], w, h, ts, [o.data_ptr() for o in outs], st.cuda_stream)
+        with torch.cuda.stream(st):
+            got = [o.clone() for o in outs]                # enqueued on the caller's stream AFTER the batch: must see every result
+        st.synchronize()
+        for i in range(n):
+            assert torch.equal(got[i], want[i]), "pair %d (rep %d)" % (i, rep)
+    g.process_device_batch([x.data_ptr() for x in d0], [x.data_ptr() for x in d1], w, h, ts, [o.data_ptr() for o in outs], None)      # NULL stream: synchronous
+    for i in range(n):
+        assert torch.equal(outs[i], want[i])
+
+
+def test_partition_streams_give_the_same_bytes(modeldirs):
+    """rife_hip_stream_create: streams that own a quarter of the compute units each (hipExtStreamCreateWithCUMask), four pairs in flight from four
+    threads: the same bytes as the host-frame call, whatever part of the chip a pair ran on; errors for bad partitions and foreign streams."""
+    import ctypes
+    import torch
+    g = amd.RIFE(0, rife_v4=True); g.load(modeldirs["rife-v4.6"])
+    w, h = 1920, 1080
+    prs = [gen_frames.smooth_pair(w, h, 60 + i) for i in range(4)]
+    want = [g.process(p[0], p[1], 0.5) for p in prs]
+    strs = [g.stream_create(i, 4) for i in range(4)]
+    d0 = [torch.from_numpy(p[0]).cuda() for p in prs]; d1 = [torch.from_numpy(p[1]).cuda() for p in prs]
+    outs = [torch.zeros_like(x) for x in d0]
+    def worker(i):
+        for _ in range(3):
+            g.process_device(d0[i].data_ptr(), d1[i].data_ptr(), w, h, 0.5, outs[i].data_ptr(), strs[i])
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert np.array_equal(outs[i].cpu().numpy(), want[i]), "pair %d on part %d of 4" % (i, i)
+    for s in strs:
+        g.stream_destroy(s)
+    with pytest.raises(amd.RifeError):
+        g.stream_create(4, 4)
+    with pytest.raises(amd.RifeError):
+        g.stream_destroy(torch.cuda.Stream().cuda_stream)
+    one = g.stream_create(0, 1)                             # nparts = 1: an ordinary stream; left to rife_hip_destroy
+    g.process_device(d0[0].data_ptr(), d1[0].data_ptr(), w, h, 0.5, outs[0].data_ptr(), one)
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[0].cpu().numpy(), want[0])

@@ -10,7 +10,9 @@ amd = importlib.import_module("rife-ncnn-vulkan_amd")
 import torch
 from tools import gen_frames, gen_models
 
-masks = [int(x) for x in sys.argv[1:]] or [0, 1, 3, 7]
+masks = [int(x) for x in sys.argv[1:] if not x.startswith("div=")] or [0, 1, 3, 7]
+for x in sys.argv[1:]:
+    if x.startswith("div="): os.environ["RIFE_HIP_KS_DIV"] = x[4:]
 d = gen_models.ensure(None, "rife-v4.6")
 os.makedirs("gpurun_out", exist_ok=True)
 log = open("gpurun_out/ks_ab.txt", "a")
@@ -53,6 +55,6 @@ for (w, h, npairs) in ((1920, 1080, 64), (3840, 2160, 32)):
                 th = [threading.Thread(target=worker, args=(i, n)) for i in range(2)]
                 [t.start() for t in th]; [t.join() for t in th]
                 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-            say("%dx%d KS=%d rep %d: %.1f frames/s (2 in flight), kernel ms/pair %.3f | %s | vs KS=%d: %d of %d bytes differ, max %d; deterministic %s" %
+            say("[div %s] " % os.environ.get("RIFE_HIP_KS_DIV", "1") + "%dx%d KS=%d rep %d: %.1f frames/s (2 in flight), kernel ms/pair %.3f | %s | vs KS=%d: %d of %d bytes differ, max %d; deterministic %s" %
                 (w, h, m, rep, 2 * npairs / dt, tot, cls, masks[0], int((df > 0).sum()), df.size, int(df.max()), np.array_equal(out, again)))
     del eng
