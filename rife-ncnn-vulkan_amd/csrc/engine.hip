@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/rife_hip.h"
+#include "../../include/rife_hip_test.h"      // the parity taps and single-kernel entry points this library also exports
 #include "conv_mfma.h"
 #include "elementwise.h"
 #include "elementwise_v2.h"
@@ -703,7 +704,7 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
 // workgroup's range bottom-up; consecutive layers alternate so that a layer starts on the rows its predecessor wrote last.
 static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool descend = false) {
     if (!L.d_t64 || L.cout != 64) return fail(RIFE_HIP_EINVAL, "layer has no 64-channel conv_t64 image");
-    if ((H + 1) / 2 < RS_MIN_PAIRS) return fail(RIFE_HIP_EINVAL, "conv_rs needs at least 7 rows");
+    if ((H + 1) / 2 < RS_MIN_PAIRS) return fail(RIFE_HIP_EINVAL, "conv_rs needs at least " + std::to_string(2 * RS_MIN_PAIRS - 1) + " rows");
     int dev = 0; (void)hipGetDevice(&dev);
     static std::mutex mu; static std::map<int, int> ncu;
     int cus;
@@ -1188,7 +1189,8 @@ static int launch_tail_rs(const rife_hip::Block& B, const unsigned char* in, int
 static bool block_on_stem_rs(const rife_hip& E, const Ctx& c, int b) {
     const rife_hip::Block& B = E.blk[b];
     return E.stem_rs && b == 3 && B.scale == 1 && B.c == 64 && B.stem0.d_wh && B.stem0.cout == 32 && B.stem1.d_whp && B.stem1.cout == 64 &&
-           g_trunk_h2 && g_fuse_stem && (c.hp % 4) == 0 && (c.wp % 4) == 0;
+           g_trunk_h2 && g_fuse_stem && (c.hp % 4) == 0 && (c.wp % 4) == 0 &&
+           (long long)c.wp * c.hp <= (1ll << 27);                       // the kernel addresses F (16 B per pixel) with 32-bit byte offsets; larger frames take the tile stems
 }
 
 // One IFBlock: stems, 8 residual convs, head -> flow[b]   (flownet.param:11-46, 63-98, 116-151, 166-201)
@@ -1219,8 +1221,20 @@ static int ensure_s16(Ctx& c, int b, int Ht, int Wt, int C) {
     if (c.P[b][0] && c.P[b][1]) return 0;
     const size_t nb = S16Geom(Ht, Wt).bytes(C);
     int rc;
+    if (c.stream) {      // a lazy hipMalloc inside a hipGraph capture would be illegal: the warm-up pass before a capture allocates everything (run_v4_replay)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c.stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(RIFE_HIP_EHIP, "S16 trunk tensors requested while the stream is capturing");
+    }
     for (int k = 0; k < 2; k++) {
-        if ((rc = dalloc(c, c.P[b][k], nb))) { c.P[b][0] = c.P[b][1] = nullptr; return rc; }
+        if ((rc = dalloc(c, c.P[b][k], nb))) {
+            if (k == 1) {                                                // the first buffer goes back: it is the newest entry of the workspace's allocation list
+                if (!c.allocs.empty() && c.allocs.back() == (void*)c.P[b][0]) c.allocs.pop_back();
+                (void)hipFree(c.P[b][0]);
+            }
+            c.P[b][0] = c.P[b][1] = nullptr;
+            return rc;
+        }
         if (c.stream) HIPCHK(hipMemsetAsync(c.P[b][k], 0, nb, c.stream));
         else HIPCHK(hipMemset(c.P[b][k], 0, nb));
     }
@@ -2339,7 +2353,7 @@ static int process_common(const rife_hip* E, int w, int h, float timestep) {
     if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
     if (!E->loaded) return fail(RIFE_HIP_EINVAL, "process() before load()");
     if (w <= 0 || h <= 0) return fail(RIFE_HIP_EINVAL, "bad frame size");
-    if ((long long)((w + 31) / 32 * 32) * ((h + 31) / 32 * 32) > (1ll << 27))      // pixel indices are ints; stem_rs addresses F (16 B per pixel) with 32-bit byte offsets
+    if ((long long)((w + 31) / 32 * 32) * ((h + 31) / 32 * 32) > (1ll << 27))      // element indices are ints and the widest full-resolution tensor has 16 channels; (stem_rs has its own gate, block_on_stem_rs)
         return fail(RIFE_HIP_EINVAL, "frame too large (more than 2^27 padded pixels)");
     (void)timestep;
     if (E->uhd && !E->v4 && (((w + 31) / 32 * 32 / 2) % 32 || ((h + 31) / 32 * 32 / 2) % 32))
@@ -3079,6 +3093,9 @@ static int rife_hip_v4_tap_impl(const rife_hip_t* E, const uint8_t* in0, const u
 }
 int rife_hip_v4_tap(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, int what, int b,
                     const float* const* inject, int n_inject, float* out) {      // nothing may throw across the C boundary
+    if (!in0 || !in1 || !out) return fail(RIFE_HIP_EINVAL, "null frame / output pointer");
+    if (n_inject > 0 && !inject) return fail(RIFE_HIP_EINVAL, "n_inject > 0 without blobs");
+    for (int k = 0; k < n_inject && k < 4; k++) if (!inject[k]) return fail(RIFE_HIP_EINVAL, "null injected blob");
     try { return rife_hip_v4_tap_impl(E, in0, in1, w, h, timestep, what, b, inject, n_inject, out); }
     catch (const std::exception& e) { return fail(RIFE_HIP_EINVAL, std::string("v4_tap: ") + e.what()); }
 }
@@ -3112,6 +3129,9 @@ static int rife_hip_v4_process_injected_impl(const rife_hip_t* E, const uint8_t*
 }
 int rife_hip_v4_process_injected(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep,
                                  const float* const* inject, int n_inject, uint8_t* out) {      // nothing may throw across the C boundary
+    if (!in0 || !in1 || !out) return fail(RIFE_HIP_EINVAL, "null frame / output pointer");
+    if (n_inject > 0 && !inject) return fail(RIFE_HIP_EINVAL, "n_inject > 0 without blobs");
+    for (int k = 0; k < n_inject && k < 4; k++) if (!inject[k]) return fail(RIFE_HIP_EINVAL, "null injected blob");
     try { return rife_hip_v4_process_injected_impl(E, in0, in1, w, h, timestep, inject, n_inject, out); }
     catch (const std::exception& e) { return fail(RIFE_HIP_EINVAL, std::string("v4_process_injected: ") + e.what()); }
 }

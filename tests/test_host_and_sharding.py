@@ -16,8 +16,11 @@ amd = importlib.import_module("rife-ncnn-vulkan_amd")
 
 
 def test_c_abi_exports_every_declared_symbol():
+    # the product header and the test-surface header (stage taps, single-kernel entry points) together declare everything the library exports
     hdr = open(os.path.join(ROOT, "include", "rife_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(rife_hip_[a-z0-9_]+)\s*\(", hdr)))
+    test_hdr = open(os.path.join(ROOT, "include", "rife_hip_test.h")).read()
+    assert "rife_hip_test.h" not in hdr and not re.search(r"rife_hip_(op_|v4_tap|v4_process_injected|v4_extract_flow)", hdr)
+    declared = sorted(set(re.findall(r"\b(rife_hip_[a-z0-9_]+)\s*\(", hdr + test_hdr)))
     assert declared == sorted(amd.C_ABI_SYMBOLS)
     L = ctypes.CDLL(amd.LIB_PATH)
     for s in declared:
