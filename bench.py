@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive legs (rife_hip_process from pageable host buffers)")
     ap.add_argument("--frames", default="f1", choices=["f1", "f2"], help="synthetic frame content (SURVEY 8(d)): f1 = the reference's real frame pair tiled to size, f2 = smooth synthetic at native resolution")
+    ap.add_argument("--no-numa-pin", action="store_true", help="do not restrict the rank to the CPUs of its GPU's NUMA node (read from /sys/class/drm/card*/device/numa_node)")
+    ap.add_argument("--share-gpu", action="store_true", help="TEST MODE for a 1-GPU box: all ranks use device 0 and rendezvous over gloo (RCCL refuses two ranks on one device); "
+                    "exercises the N-rank code paths (sharding, barriers, the all-ranks host-buffer leg) on real HIP work.  The line is labelled and is not a scaling measurement")
     ap.add_argument("--dry-run", action="store_true", help="CPU plumbing check (gloo): launcher, sharding, barrier, MAX over ranks, JSON; no HIP work")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -126,16 +129,29 @@ def main():
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.share_gpu:
+        local = 0
     if local >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d device(s) visible)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
+    sh0 = importlib.import_module("rife-ncnn-vulkan_amd.sharding")
+    numa = None
+    if not args.no_numa_pin and world > 1:
+        # one rank per GPU: its caller threads, the batch workers and the runtime's staging copies stay on the socket the GPU hangs off
+        props = torch.cuda.get_device_properties(local)
+        pci = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
+        numa = sh0.pin_to_gpu_numa(pci)
     dist = None
     rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         rccl_ranks = dist.get_world_size()
+    coll_dev = "cpu" if args.share_gpu else "cuda"          # where the 1-element barrier / MAX tensors live
 
     amd = importlib.import_module("rife-ncnn-vulkan_amd")
     from tools import gen_frames, gen_models
@@ -208,13 +224,13 @@ def main():
     # THE timed region (`value`): K steps, nothing but the product path (the per-launch HIP events of the profiler cost 5 % at
     # 4K and 20 % at 1080p, so they are kept out of it) ...
     elapsed = sh.timed_steps(lambda i: run_steps(i, args.steps), 1, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
-                             make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+                             make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device=coll_dev))
     # the same K-step region repeated (>= 50 pairs, median / p10 / p90): `value` stays the FIRST region, exactly K steps
     reps = max(3, -(-150 // max(1, args.steps)))
     region_fps = [world * args.steps / elapsed]
     for _ in range(reps - 1):
         el = sh.timed_steps(lambda i: run_steps(i, args.steps), 1, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
-                            make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+                            make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device=coll_dev))
         region_fps.append(world * args.steps / el)
     # PCIe-inclusive legs: the boundary call the reference CLI makes (RIFE::process on host frames: H2D x2 + pass + D2H inside the
     # call, src/rife.cpp:2522-2530, 3176-3186) from pageable host memory, 1 and 2 caller threads (the reference's default -j 1:2:2)
@@ -256,7 +272,7 @@ def main():
             for i in range(3):
                 host_step(i, 0)
             return sh.timed_steps(region, 1, dist=dist, device_sync=torch.cuda.synchronize,
-                                  make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+                                  make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device=coll_dev))
         for kind, bufs in (("pageable", pageable), ("page_locked", pinned)):
             for nt in (1, 2, 3):
                 host["%s_caller_threads_%d" % (kind, nt)] = round(world * args.steps / host_run(bufs, nt), 3)
@@ -269,14 +285,37 @@ def main():
             ts = [timesteps[i % len(timesteps)] for i in range(args.steps)]
             eng.process_batch(a0[:3], a1[:3], ts[:3], bouts[:3])
             return sh.timed_steps(lambda _: eng.process_batch(a0, a1, ts, bouts), 1, dist=dist, device_sync=torch.cuda.synchronize,
-                                  make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+                                  make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device=coll_dev))
         host["process_batch_one_thread_pageable"] = round(world * args.steps / batch_run(pageable), 3)
         host["process_batch_one_thread_page_locked"] = round(world * args.steps / batch_run(pinned), 3)
+    # N > 1: the host-buffer path on ALL ranks at once - what can stop a node from scaling is not on the GPUs (pairs are independent, no collective)
+    # but under them: every rank pulls 3 x w x h x 3 bytes per pair through host DRAM and its PCIe root.  One caller per rank, rife_hip_process_batch over
+    # the K pairs, all ranks inside one barrier-bracketed region; whole-job frames/s and the aggregate host <-> device traffic.
+    host_all = None
+    if world > 1 and not args.no_host_path and not tta:
+        host_all = {}
+        per_pair_bytes = 3.0 * w * h * 3
+        for kind in ("pageable", "page_locked"):
+            if kind == "pageable":
+                hin = [f.cpu().numpy() for f in frames]
+                bouts = [np.empty((h, w, 3), np.uint8) for _ in range(args.steps)]
+            else:
+                hin = [amd.pinned_empty((h, w, 3)) for _ in frames]
+                for dst, src in zip(hin, frames):
+                    dst[...] = src.cpu().numpy()
+                bouts = [amd.pinned_empty((h, w, 3)) for _ in range(min(args.steps, 8))]
+                bouts = [bouts[i % len(bouts)] for i in range(args.steps)]
+            a0 = [hin[i % nfr] for i in range(args.steps)]; a1 = [hin[(i + 1) % nfr] for i in range(args.steps)]
+            ts = [timesteps[i % len(timesteps)] for i in range(args.steps)]
+            eng.process_batch(a0[:3], a1[:3], ts[:3], bouts[:3])
+            rate, el = sh.all_ranks_rate(args.steps, lambda: eng.process_batch(a0, a1, ts, bouts), dist=dist, device_sync=torch.cuda.synchronize,
+                                         make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device=coll_dev))
+            host_all[kind] = {"frames_per_s": round(rate, 3), "host_device_GBps": round(rate * per_pair_bytes / 1e9, 2)}
     # ... and the same K steps again with HIP events around every launch on its stream (`roofline_in_timed_region`)
     sh.barrier(dist, torch.cuda.synchronize)
     eng.profile_enable(True)
     elapsed_instr = sh.timed_steps(lambda i: run_steps(i, args.steps), 1, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
-                                   make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+                                   make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device=coll_dev))
     prof = eng.profile_read()
     eng.profile_enable(False)
     # second region, same K steps with ONE pair in flight: kernels of different pairs no longer overlap, so the HIP-event time of
@@ -290,7 +329,7 @@ def main():
         sh.barrier(dist, torch.cuda.synchronize)
         eng.profile_enable(True)
         el1 = sh.timed_steps(step, args.steps, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
-                             make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device="cuda"))
+                             make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device=coll_dev))
         prof1 = eng.profile_read()
         eng.profile_enable(False)
         fps1 = world * args.steps / el1
@@ -325,13 +364,15 @@ def main():
             "config": {"workload": "%s %dx%d%s frame pairs resident in HBM, timestep sweep %s, synthetic seeded weights" % (family, w, h, " -x -z (TTA)" if tta else "", timesteps),
                        "pairs_in_flight_per_gpu": nstreams,
                        "cu_partition": "none (ordinary streams)" if cu_parts <= 1 else "every stream owns 1 / %d of the compute units (rife_hip_stream_create)" % cu_parts,
-                       "frames": frame_kind, "untimed_setup_pairs": SETUP, "parallelism": "frame pairs sharded over ranks, no data-path collective"},
+                       "frames": frame_kind, "untimed_setup_pairs": SETUP, "parallelism": "frame pairs sharded over ranks, no data-path collective" + (" [--share-gpu TEST MODE: all ranks on ONE device over gloo - not a scaling measurement]" if args.share_gpu else "")},
             "roofline": roof,
             "roofline_in_timed_region": roof_timed if prof1 is not None else None,
             "cpu_baseline": cpu,
             "extra": {"frames_per_s_repeated_regions": dict(percentiles(region_fps), pairs_measured=reps * args.steps * world,
                                                             note="the K-step timed region repeated %d times back to back; `value` is the first" % reps),
                       "frames_per_s_host_buffers": None if host is None else dict(host, note="rife_hip_process on host frames: 2 x H2D + pass + D2H inside the call (PCIe-inclusive; never `value`); page_locked = frames from rife_hip_host_alloc; process_batch_one_thread = ONE caller, rife_hip_process_batch over the region's K pairs"),
+                      "frames_per_s_host_buffers_all_ranks": None if host_all is None else dict(host_all, note="every rank at once: one caller per rank, rife_hip_process_batch over its K host-frame pairs, one barrier-bracketed region; whole-job rate = pairs of all ranks / MAX elapsed (PCIe-inclusive; never `value`)"),
+                      "numa": numa,
                       "frames_per_s_same_region_with_per_launch_events": round(world * args.steps / elapsed_instr, 3),
                       "frames_per_s_with_1_pair_in_flight": None if fps1 is None else round(fps1, 3), "kernel_ms_per_pair": round(all_ms / args.steps, 4), "conv_ms_per_pair": round(conv_ms / args.steps, 4),
                       "conv_tflops_overall": round(gflop_pair / max(conv_ms / args.steps, 1e-9), 2),
@@ -359,8 +400,12 @@ def dry_run(args, rank, world):
     mine = sh.shard_pairs(args.steps * world, rank, world)            # weak scaling: K pairs per rank
     assert len(mine) == args.steps
     elapsed = sh.timed_steps(lambda i: time.sleep(0.001), args.steps, first_index=args.warmup, dist=dist)
+    # the all-ranks host-buffer leg (N > 1): same plumbing, a sleep instead of rife_hip_process_batch; rank r "processes" K pairs in (r + 1) x 10 ms
+    rate_all, el_all = sh.all_ranks_rate(args.steps, lambda: time.sleep(0.01 * (rank + 1)), dist=dist)
+    numa = sh.pin_to_gpu_numa("0000:00:00.0", setaffinity=lambda cpus: None)      # lookup only (no such card on a CPU box): must not raise
     if rank == 0:
         print(json.dumps({"metric": "dry run: launcher / sharding / barrier plumbing (no GPU work)", "value": round(world * args.steps / elapsed, 3), "unit": "steps/s",
+                          "extra": {"all_ranks_leg": {"units_per_s": round(rate_all, 3), "max_elapsed_s": round(el_all, 4), "units": world * args.steps}, "numa": numa},
                           "n_gpus": world, "rccl_ranks": ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run",
                           "config": {"workload": "dry run on CPU (gloo)", "parallelism": "frame pairs sharded over ranks, no data-path collective"}}))

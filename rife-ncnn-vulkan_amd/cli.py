@@ -8,6 +8,10 @@ Same flags, defaults, validation and frame/timestep schedule as the reference; t
 (load -> proc -> save, bounded queues of 8, `-j load:proc[,proc..]:save`, one RIFE replica per `-g` id,
 src/main.cpp:248-436, 819-904) is re-hosted on Python threads (decode/encode via PIL; the GPU call releases the GIL).
 This is host glue ("next" row): all arithmetic stays in librife_hip.so.
+
+ROLE: the TEST HARNESS of the command-line contract.  The product's command line is the C++ binary `rife-hip` (csrc/main.cpp, `make -C csrc`);
+this module restates the same schedule / validation logic in Python so that tests/test_cli.py can check both against the reference's rules and
+against each other (same frames from the same arguments) without a subprocess per case.
 """
 import getopt
 import math

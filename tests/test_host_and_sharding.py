@@ -131,6 +131,48 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert r1.returncode == 0 and json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
 
 
+def test_bench_dry_run_covers_the_all_ranks_host_leg():
+    """N > 1: the host-buffer leg runs on every rank inside ONE barrier-bracketed region (bench.py, sharding.all_ranks_rate): the whole-job rate is
+    the pairs of all ranks over the SLOWEST rank's time.  Dry run: rank r sleeps (r + 1) x 10 ms for its K pairs, so 2 ranks x 4 pairs take >= 20 ms."""
+    import json
+    r = _bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    leg = d["extra"]["all_ranks_leg"]
+    assert leg["units"] == 8 and leg["max_elapsed_s"] >= 0.02 * 0.9
+    assert abs(leg["units_per_s"] - 8 / leg["max_elapsed_s"]) / leg["units_per_s"] < 0.02
+    assert d["extra"]["numa"] == {"pci": "0000:00:00.0", "numa_node": None, "cpus": None, "pinned": False}
+
+
+def test_numa_node_of_a_gpu_comes_from_sysfs(tmp_path):
+    """Rank placement reads the GPU's NUMA node from /sys/class/drm/card*/device/numa_node - no hard-coded topology (fake sysfs tree here)."""
+    sh = importlib.import_module("rife-ncnn-vulkan_amd.sharding")
+    sysfs = tmp_path / "sys"
+    for card, addr, node in ((0, "0000:05:00.0", 0), (1, "0000:c1:00.0", 1), (2, "0000:d5:00.0", -1)):
+        pci = sysfs / "devices" / "pci" / addr
+        pci.mkdir(parents=True)
+        (pci / "numa_node").write_text("%d\n" % node)
+        drm = sysfs / "class" / "drm" / ("card%d" % card)
+        drm.mkdir(parents=True)
+        os.symlink(str(pci), str(drm / "device"))
+    (sysfs / "class" / "drm" / "card1-DP-1").mkdir()                      # connectors sit next to the cards: must be ignored
+    for node, cpus in ((0, "0-3,16-19"), (1, "4-7,20-23")):
+        nd = sysfs / "devices" / "system" / "node" / ("node%d" % node)
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cpus + "\n")
+    assert sh.numa_node_of_pci("0000:C1:00.0", str(sysfs)) == 1
+    assert sh.numa_node_of_pci("0000:05:00.0", str(sysfs)) == 0
+    assert sh.numa_node_of_pci("0000:d5:00.0", str(sysfs)) is None        # the kernel says -1: unknown
+    assert sh.numa_node_of_pci("0000:ff:00.0", str(sysfs)) is None
+    assert sh.cpus_of_node(1, str(sysfs)) == {4, 5, 6, 7, 20, 21, 22, 23}
+    pinned = []
+    rep = sh.pin_to_gpu_numa("0000:c1:00.0", str(sysfs), setaffinity=pinned.append, allowed=range(0, 22))
+    assert rep["numa_node"] == 1 and rep["pinned"] and rep["cpus"] == 6 and pinned == [{4, 5, 6, 7, 20, 21}]
+    pinned.clear()
+    rep = sh.pin_to_gpu_numa("0000:d5:00.0", str(sysfs), setaffinity=pinned.append, allowed=range(64))
+    assert not rep["pinned"] and pinned == []
+
+
 def test_bench_refuses_a_launcher_world_that_differs_from_gpus():
     r = _bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
