@@ -76,6 +76,42 @@ def roofline_of(dom, family, w, h, f32_mode):
             "mfma_frac_issued": round(tflops * mfma_factor / F16_MFMA_PEAK_TFLOPS, 4)}
 
 
+DOMINANT_SYMBOL = {"rife-v4.6": "conv_rs_kernel", "rife-v2.3": "conv_h2_kernel<3, 9, 0>"}
+
+
+def live_traffic(workload, family, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel, measured IN THIS RUN on this box: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+    counters alone, never mixed with other trace domains) over tools/prof_run.py on the same workload, one pair in flight.  KiB counters;
+    FETCH_SIZE x 2 is the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md.  None (with the reason) if rocprofv3 is not usable here."""
+    import glob, shutil, subprocess, tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    from tools import pmc_summary
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rife_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "tools", "prof_run.py"), "--workload", workload, "--pairs", "2"],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (ctr, r.returncode)
+            rows = pmc_summary.summarize(files[0], DOMINANT_SYMBOL[family])
+            if not rows:
+                return None, "no dispatch of %s in the %s pass" % (DOMINANT_SYMBOL[family], ctr)
+            vals[ctr] = sum(dd[ctr] * dd["_dispatches"] for _, dd in rows) / sum(dd["_dispatches"] for _, dd in rows)
+        except Exception as e:
+            return None, "%s pass: %s" % (ctr, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(vals["FETCH_SIZE"] * 2 * 1024 + vals["WRITE_SIZE"] * 1024), ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes of tools/prof_run.py --workload %s --pairs 2 inside "
+                                                                             "this bench.py run; FETCH_SIZE x 2 = gfx950 correction)" % workload)
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -99,11 +135,12 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="frame pairs in flight per GPU in the timed region; 0 = the workload's default: 2 (the reference's default, 2 proc threads per GPU, -j 1:2:2), "
                     "or one per chip partition (--cu-parts)")
     ap.add_argument("--cu-parts", type=int, default=-1, help="partition the compute units between the pairs in flight: every stream owns 1 / N of them (rife_hip_stream_create; "
-                    "include/rife_hip.h).  -1 = the workload's default: 4 for the 1080p workloads of rife-v4.6 (measured 1,690 vs 1,450 - 1,590 frames/s), none for the others (no gain at 4K)")
+                    "include/rife_hip.h).  -1 = the workload's default: 4 for the 1080p workloads (rife-v4.6: measured 1,690 vs 1,450 - 1,590 frames/s; rife-v2.3: 478 vs 448 - 470), none for the 4K ones (no gain)")
     ap.add_argument("--no-extra", action="store_true", help="skip the second region (1 pair in flight, clean per-launch kernel timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive legs (rife_hip_process from pageable host buffers)")
     ap.add_argument("--frames", default="f1", choices=["f1", "f2"], help="synthetic frame content (SURVEY 8(d)): f1 = the reference's real frame pair tiled to size, f2 = smooth synthetic at native resolution")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (then the committed figure is used)")
     ap.add_argument("--no-numa-pin", action="store_true", help="do not restrict the rank to the CPUs of its GPU's NUMA node (read from /sys/class/drm/card*/device/numa_node)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST MODE for a 1-GPU box: all ranks use device 0 and rendezvous over gloo (RCCL refuses two ranks on one device); "
                     "exercises the N-rank code paths (sharding, barriers, the all-ranks host-buffer leg) on real HIP work.  The line is labelled and is not a scaling measurement")
@@ -180,7 +217,7 @@ def main():
         f = np.roll(base[i % 2], (2 * (i // 2), 5 * (i // 2)), axis=(0, 1))
         frames.append(torch.from_numpy(np.ascontiguousarray(f)).cuda())
     timesteps = [0.5, 0.125, 0.25, 0.7, 0.9]
-    cu_parts = args.cu_parts if args.cu_parts >= 0 else (4 if args.workload == "1080p" else 0)
+    cu_parts = args.cu_parts if args.cu_parts >= 0 else (4 if args.workload in ("1080p", "v23-1080p") else 0)
     nstreams = args.streams if args.streams > 0 else (cu_parts if cu_parts > 1 else 2)
 
     class PartStream:                                        # a stream of rife_hip_stream_create, with torch.cuda.Stream's attribute
@@ -347,11 +384,19 @@ def main():
             roof = roofline_of(prof1.get(DOMINANT[family][0], dict(ms=0.0, launches=0, flops=0.0)), family, w, h, f32_mode)
             if roof is not None:
                 roof["measured_in"] = "HIP events on the launch stream over a region of the same %d steps with 1 pair in flight (non-overlapping launches); roofline_in_timed_region = the timed region repeated with the events on" % args.steps
-        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "pmc_%s.json" % args.workload) for r in ("r3", "r2")) if os.path.exists(f)), "")
-        if roof is not None and traffic_file:
+        # roofline.traffic: measured live in this run (two rocprofv3 --pmc passes in child processes, after the timed regions); if rocprofv3 cannot
+        # run here, the committed figure of the newest round that has one for THIS workload, labelled as such
+        if roof is not None and world == 1 and not args.no_live_traffic:
+            tb, src = live_traffic(args.workload, family)
+            if tb is not None:
+                roof["traffic"], roof["traffic_source"] = tb, src
+            else:
+                roof["traffic_live_failed"] = src
+        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "pmc_%s.json" % args.workload.replace("-", "_")) for r in ("r4", "r3", "r2")) if os.path.exists(f)), "")
+        if roof is not None and roof.get("traffic") is None and traffic_file:
             tf = json.load(open(traffic_file))                   # from the committed rocprofv3 --pmc passes (not live)
             roof["traffic"] = tf["hbm_bytes_per_launch"]
-            roof["traffic_source"] = tf["source"]
+            roof["traffic_source"] = "committed, not live: " + tf["source"]
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(modeldir, family, w * h, 16 if tta and tta_temporal else 1, (w, h))
