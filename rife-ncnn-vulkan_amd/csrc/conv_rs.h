@@ -222,7 +222,10 @@ __device__ __forceinline__ void rs_consumer(const RsArgs& a, unsigned char* cons
     RS_SYNC_LGKM();                                                      // the last step's staging writes have landed
 }
 
-template <int TAG>
+// SPLIT (round 4, A/B RIFE_HIP_RS_SPLIT): 1 = the epilogue of a row pair is shared by all four io waves - loader j finishes the chunks 0, 1 of row j
+// (before it issues the step's LDS-DMA: its stores are then OLDER than every load its counted vmcnt wait leaves in flight, so the wait stays
+// sufficient, merely stricter), storer j the chunks 2, 3: bias / LeakyReLU / split VALU and the global stores on all four SIMDs instead of two.
+template <int TAG, int SPLIT = 0>
 __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_rs_kernel(RsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -237,6 +240,34 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int ufirst = a.descend ? u1 - 1 : u0;
     // every iteration ends with RS_SYNC_*: all eight waves execute the same S + 2 of them
 
+    // epilogue of chunks [cc0, cc1) of output row j of the step staged in buffer `sb`, at (strip, pair) = (cstrip, cp): y = slope(sum + bias), split into
+    // {hi, lo}, zeros outside the valid pixels; lane = (pixel l >> 1, half l & 1) of a 16-channel chunk: 16 bytes of the hi plane and 16 of the lo plane
+    auto epilogue = [&](const int j, const int sb, const int cstrip, const int cp, const int cc0, const int cc1, const float slope) {
+        const int px = lane >> 1, jh = lane & 1, qs = (px >> 1) & 3;
+        const int y = 2 * cp + j, x0 = 32 * cstrip;
+        if (!(y < a.H) || RIFE_ABL(TAG & RS_NOSTORE)) return;
+        const unsigned okmask = x0 + px < a.W ? 0xffffffffu : 0u;
+        const unsigned char* src = ldsb + RS_LDS_STG + sb * (2 * RS_STG_ROW) + j * RS_STG_ROW + px * 64;
+        unsigned char* dst = a.out + ((unsigned)((y + 1) * a.pitch + x0 + 1) * 32u + (unsigned)(lane * 16));
+        for (int cc = cc0; cc < cc1; cc++) {
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(src + cc * 2048 + (((2 * jh) ^ qs) << 4));
+            const f32x4 r1 = *reinterpret_cast<const f32x4*>(src + cc * 2048 + (((2 * jh + 1) ^ qs) << 4));
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(ldsb + RS_LDS_BS + (16 * cc + 8 * jh) * 4);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(ldsb + RS_LDS_BS + (16 * cc + 8 * jh + 4) * 4);
+            f16x8 hv, lv;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float yv = (e < 4 ? r0[e & 3] : r1[e & 3]) + (e < 4 ? b0[e & 3] : b1[e & 3]);
+                float v = yv < 0.f ? yv * slope : yv;
+                v = __uint_as_float(__float_as_uint(v) & okmask);
+                const _Float16 hh = (_Float16)v;
+                hv[e] = hh;
+                lv[e] = (_Float16)(v - (float)hh);
+            }
+            *reinterpret_cast<f16x8*>(dst + (size_t)(2 * cc) * a.plane) = hv;
+            *reinterpret_cast<f16x8*>(dst + (size_t)(2 * cc + 1) * a.plane) = lv;
+        }
+    };
     if (wv < 4) {
         // ------------------------------------------------------------------------------------------------ consumers
         if RIFE_ABL(TAG & RS_PRIO) __builtin_amdgcn_s_setprio(2);             // A/B only: raised priority of the matrix waves measured 3 - 5 % SLOWER (their loader / storer starve, the barrier waits)
@@ -291,12 +322,27 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
         else if (ahead == 9) RS_SYNC_VM(9);                                                                  \
         else RS_SYNC_VM(18);
         RS_WAIT_AHEAD()                                                  // rows of steps 0 and 1 landed
+        if (SPLIT) {
+            // my half of the epilogue (chunks 0, 1 of row j of the step staged two iterations ago), then the loads: S + 2 iterations like the storers
+            const float slope = reinterpret_cast<const float*>(a.img + 4 * t64_wch(2))[64];
+            RsCursor ecur; ecur.init(ufirst, a.npairs);
+            for (int it = 0; it <= S + 1; it++) {
+                if (it >= 2) { epilogue(j, (it - 2) % RS_NSTG, ecur.strip, ecur.p, 0, 2, slope); ecur.advance(a.npairs, a.descend); }
+                if (it < S) {
+                    if (it + RS_AHEAD < S) { const bool f = cur.advance(a.npairs, a.descend); ahead = load_step(f); }
+                    else ahead = 0;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of the staging buffer are done before the barrier lets the consumers reuse it
+                    RS_WAIT_AHEAD()
+                } else if (it == S) RS_SYNC_LGKM();                      // the consumers' final barrier
+            }
+        } else {
         for (int it = 0; it < S; it++) {
             if (it + RS_AHEAD < S) { const bool f = cur.advance(a.npairs, a.descend); ahead = load_step(f); }
             else ahead = 0;
             RS_WAIT_AHEAD()                                              // rows of step it + 2 landed: the consumers prefetch step it + 1's first fragments before the NEXT barrier
         }
         RS_SYNC_BARE();                                                  // the consumers' final barrier
+        }
 #undef RS_WAIT_AHEAD
     } else {
         // ------------------------------------------------------------------------------------------------ storers
@@ -311,7 +357,8 @@ __global__ __launch_bounds__(RS_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int it = 0; it <= S + 1; it++) {
             if (it >= 2) {                                               // step it - 2, staged at the end of iteration it - 2
                 const int y = 2 * cur.p + j, x0 = 32 * cur.strip;
-                if (y < a.H && !RIFE_ABL(TAG & RS_NOSTORE)) {
+                if (SPLIT) epilogue(j, (it - 2) % RS_NSTG, cur.strip, cur.p, 2, 4, slope);
+                else if (y < a.H && !RIFE_ABL(TAG & RS_NOSTORE)) {
                     const unsigned okmask = x0 + px < a.W ? 0xffffffffu : 0u;
                     const unsigned char* src = ldsb + RS_LDS_STG + ((it - 2) % RS_NSTG) * (2 * RS_STG_ROW) + j * RS_STG_ROW + px * 64;
                     unsigned char* dst = a.out + ((unsigned)((y + 1) * a.pitch + x0 + 1) * 32u + (unsigned)(lane * 16));

@@ -702,6 +702,7 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
 
 // the same 64 -> 64 layer on the row-streaming kernel (conv_rs.h): one workgroup per CU, specialised waves.  descend: walk every
 // workgroup's range bottom-up; consecutive layers alternate so that a layer starts on the rows its predecessor wrote last.
+static const bool g_rs_split = []() { const char* e = getenv("RIFE_HIP_RS_SPLIT"); return e && e[0] == '1'; }();      // A/B: epilogue shared by all four io waves (conv_rs.h, SPLIT)
 static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool descend = false) {
     if (!L.d_t64 || L.cout != 64) return fail(RIFE_HIP_EINVAL, "layer has no 64-channel conv_t64 image");
     if ((H + 1) / 2 < RS_MIN_PAIRS) return fail(RIFE_HIP_EINVAL, "conv_rs needs at least " + std::to_string(2 * RS_MIN_PAIRS - 1) + " rows");
@@ -713,6 +714,7 @@ static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char*
         auto it = ncu.find(dev);
         if (it == ncu.end()) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rs_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS));
             int n = 0;
             HIPCHK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
             it = ncu.emplace(dev, std::max(1, n)).first;
@@ -725,7 +727,8 @@ static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char*
     a.in = in; a.out = out; a.img = L.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane();
     a.npairs = (H + 1) / 2; a.nunits = G.tiles_x * a.npairs; a.descend = descend ? 1 : 0;
     const int nwg = std::min(cus, a.nunits);                             // one workgroup per CU (154 KB of LDS), all resident
-    hipLaunchKernelGGL((conv_rs_kernel<0>), dim3(nwg), dim3(RS_NTHR), RS_LDS, st, a);
+    if (g_rs_split) hipLaunchKernelGGL((conv_rs_kernel<0, 1>), dim3(nwg), dim3(RS_NTHR), RS_LDS, st, a);
+    else hipLaunchKernelGGL((conv_rs_kernel<0>), dim3(nwg), dim3(RS_NTHR), RS_LDS, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_rs launch: ") + hipGetErrorString(e));
     return 0;
