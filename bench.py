@@ -206,10 +206,14 @@ def main():
     # synthetic pair generated at full size; frames 2, 3 = frames 0, 1 shifted by a few pixels (no upsampled content: the matrix pipe clocks with
     # the toggle rate of its operands)
     nfr = 4
+    base = None
     if args.frames == "f1" and w % 640 == 0 and h % 360 == 0 and w // 640 == h // 360:
-        base = gen_frames.tiled_real_pair(w // 640)
-        frame_kind = "F1: images/0.png, 1.png of the reference tiled %d x %d" % (w // 640, w // 640)
-    else:
+        try:
+            base = gen_frames.tiled_real_pair(w // 640)
+            frame_kind = "F1: images/0.png, 1.png of the reference tiled %d x %d" % (w // 640, w // 640)
+        except Exception as e:                               # no PIL / no fixture PNGs on this box: the synthetic frames instead (labelled)
+            sys.stderr.write("bench.py: F1 frames unavailable (%s); using F2\n" % e)
+    if base is None:
         base = gen_frames.smooth_pair_native(w, h, 1000 + rank)
         frame_kind = "F2: smooth synthetic pair generated at %dx%d" % (w, h)
     frames = []

@@ -6,12 +6,15 @@
 //  plus the in-tree custom layer `rife.Warp`
 // (reference src/warp.cpp:96-168).
 //
-// PARITY UNPINNED: Tencent/ncnn is an un-vendored submodule of the reference
-// (`.gitmodules:1-3`, `src/ncnn/` is empty, pinned SHA unknown) and the
-// reference ships no tests or golden vectors, so this restatement follows the
-// *published* ncnn layer semantics and is pinned only against (a) an
-// independent PyTorch-CPU execution of the same graphs (tests/test_oracle_vs_torch.py)
-// and (b) self-generated fixtures under tests/golden/.
+// PARITY UNPINNED for the layer arithmetic in this file: Tencent/ncnn is an
+// un-vendored submodule of the reference (`.gitmodules:1-3`, `src/ncnn/` is
+// empty, pinned SHA unknown) and the reference ships no tests or golden
+// vectors, so this restatement follows the *published* ncnn layer semantics
+// and is pinned only against (a) an independent PyTorch-CPU execution of the
+// same graphs (tests/test_oracle_vs_torch.py) and (b) self-generated fixtures
+// under tests/golden/.  (The ORCHESTRATION around these layers and rife.Warp
+// are pinned by the reference's own compiled code: oracle/refbuild/,
+// tests/test_ref_build.py.)
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
 // anything in this directory.

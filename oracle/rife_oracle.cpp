@@ -1,4 +1,7 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see ncnn_graph.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see ncnn_graph.h header).
+// PINNED since round 4: tests/test_ref_build.py holds every function of this file bit for bit against the reference's OWN src/rife.cpp + src/warp.cpp,
+// compiled unmodified against an ncnn look-alike (oracle/refbuild/ -> oracle/_ref/libref_rife.so), in all families and modes.  What stays
+// "parity unpinned" is the arithmetic of the ncnn built-in layers underneath (ncnn_graph.cpp, conv_cpu.cpp), which both sides share.
 //
 // CPU restatement of the reference's `-g -1` path:
 //   RIFE::load            reference src/rife.cpp:127-379  (only what the CPU path needs)
