@@ -364,7 +364,7 @@ def main():
     prof1, fps1 = None, None
     if not args.no_extra and nstreams > 1:
         saved = streams[:]
-        del streams[1:]
+        streams[:] = [torch.cuda.Stream()]                  # ONE ordinary stream: the kernel alone on the WHOLE chip (also when the timed region partitions the CUs)
         for i in range(2):
             step(i)
         sh.barrier(dist, torch.cuda.synchronize)
