@@ -242,20 +242,23 @@ def test_malformed_param_files_are_refused_not_fatal(modeldirs, tmp_path):
 
 
 def test_pmc_tables_reads_the_committed_summaries(tmp_path):
-    """tools/pmc_tables.py on the per-kernel PMC summaries kept in profiles/r3: the derived files are complete and the dominant
-    kernel's traffic is what bench.py reports as roofline.traffic."""
+    """tools/pmc_tables.py on the per-kernel PMC summaries kept in profiles/r4, for every bench workload: the derived files are complete and the
+    dominant kernel's traffic is what bench.py falls back to for roofline.traffic when it cannot measure it live."""
     import json, shutil
     from tools import pmc_tables
-    src = tmp_path / "src"; src.mkdir()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for short, first in pmc_tables.PASSES.items():
-        shutil.copy(os.path.join(root, "profiles", "r3", "pmc_all_kernels_4k_%s.txt" % short), src / ("pmc_%s_all.txt" % first))
-    dst = tmp_path / "dst"
-    pmc_tables.main(str(src), str(dst))
-    j = json.load(open(dst / "pmc_4k.json"))
-    committed = json.load(open(os.path.join(root, "profiles", "r3", "pmc_4k.json")))
-    assert j["hbm_bytes_per_launch"] == committed["hbm_bytes_per_launch"] > 2.6e8       # >= the 267.5 MB the layer stores
-    table = open(dst / "bandwidth_kernels_4k.txt").read()
-    assert "conv_rs_kernel" in table and "k_flow_update" in table
-    derived = [l for l in open(dst / "pmc_trunk_kernels_4k.txt") if "matrix pipe busy" in l]
-    assert len(derived) == 2
+    for wl, dom, floor in (("4k", "conv_rs_kernel", 2.6e8), ("1080p", "conv_rs_kernel", 6.6e7), ("v23_1080p", "conv_h2_kernel<3, 9, 0>", 5e7), ("4k_tta", "conv_rs_kernel", 2.6e8)):
+        src = tmp_path / ("src_" + wl); src.mkdir()
+        sfx = "" if wl == "4k" else "_" + wl
+        for short, first in pmc_tables.PASSES.items():
+            shutil.copy(os.path.join(root, "profiles", "r4", "pmc_all_kernels_%s_%s.txt" % (wl, short)), src / ("pmc_%s%s_all.txt" % (first, sfx)))
+        dst = tmp_path / ("dst_" + wl)
+        pmc_tables.main(str(src), str(dst), 1 if wl == "4k_tta" else 3, wl)
+        j = json.load(open(dst / ("pmc_%s.json" % wl)))
+        committed = json.load(open(os.path.join(root, "profiles", "r4", "pmc_%s.json" % wl)))
+        assert j["hbm_bytes_per_launch"] == committed["hbm_bytes_per_launch"] > floor and dom in j["kernel"]      # at least what the layer stores
+        assert committed["source"].startswith("profiles/r4/")
+        table = open(dst / ("bandwidth_kernels_%s.txt" % wl)).read()
+        assert dom.split("<")[0] in table
+        derived = [l for l in open(dst / ("pmc_trunk_kernels_%s.txt" % wl)) if "matrix pipe busy" in l]
+        assert len(derived) >= 2
