@@ -871,6 +871,7 @@ struct Profiler {
 struct Ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    int cu_budget = 0;                                                // > 0: `stream` owns this many compute units only (pool partition, RIFE_HIP_POOL_PARTS)
     std::mutex use;                                                   // rife_hip_process_device: one caller at a time per stream workspace
     int w = 0, h = 0, wp = 0, hp = 0;
     uint8_t *d_in0 = nullptr, *d_in1 = nullptr, *d_out = nullptr;   // staging for the host-buffer entry point
@@ -2372,9 +2373,20 @@ static int lease_ctx(const rife_hip* E, std::unique_ptr<Ctx>& c, int w, int h) {
     }
     if (!c) {
         c.reset(new Ctx);
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
+        // RIFE_HIP_POOL_PARTS=n (A/B; default 1): the pool's streams own 1 / n of the compute units each (CU index mod n), like rife_hip_stream_create
+        static const int parts = []() { const char* e = getenv("RIFE_HIP_POOL_PARTS"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 16 ? v : 1; }();
+        static std::atomic<int> next{0};
+        if (parts > 1) {
+            const int ncu = device_cus(true), part = next++ % parts;
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            int mine = 0;
+            for (int cu = 0; cu < ncu; cu++) if (cu % parts == part) { mask[cu / 32] |= 1u << (cu % 32); mine++; }
+            if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipExtStreamCreateWithCUMask failed");
+            c->cu_budget = mine;
+        } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
         c->own_stream = true;
     }
+    tl_cu_budget = c->cu_budget;                                         // the caller enqueues on this workspace's stream next
     return E->v4 ? ensure_ctx(*c, w, h) : E->v1 ? ensure_ctx_v1(*c, w, h, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1)
                                                 : ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1, E->v3);
 }
