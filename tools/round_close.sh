@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: a round's closing call - the full GPU suite and smoke() on the final commit (into gpurun_out/profile_<tag>/)
-TAG=${1:-r3}
+TAG=${1:-r4}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT
 OUT=gpurun_out/profile_$TAG; mkdir -p $OUT
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee $OUT/pytest_gpu.txt
