@@ -2460,7 +2460,8 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     if ((rc = check_device(E->gpuid))) return rc;
     // three workers = three pairs in flight: tools/host_path_bench2.py, 4K, 48 pairs: process() from 1 / 2 / 3 / 4 caller threads
     // 192 / 341 / 389 / 365 frames/s from pageable frames (resident frames: 395), 244 / 307 / 349 / 344 from page-locked ones
-    const int K = std::min(n, 3);
+    static const int batch_workers = []() { const char* e = getenv("RIFE_HIP_BATCH_WORKERS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? v : 0; }();      // A/B
+    const int K = std::min(n, batch_workers ? batch_workers : 4);      // round 4: four workers (measured against 3 / 5 / 6 / 8: 4K 439 vs 426 / 426 / 431 / 446, 1080p 1,334 vs 1,251 / 1,367 / 1,443 / 1,398 pageable; page-locked best at 4)
     // A host frame that serves several pairs of the batch (consecutive pairs of a sequence share one) crosses PCIe once: it becomes a
     // resident frame on first use and is released after its last (stream mode, below).  Batches without shared frames run as before.
     struct Shared { std::mutex mu; rife_hip_frame_t* f = nullptr; int left = 0; };
@@ -2508,7 +2509,7 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
             }
             if (pend >= 0) singles.push_back(pend);
         }
-        const int KG = std::min<int>(3, (int)grp.size() + (singles.empty() ? 0 : 1));      // three workers x two pairs in flight
+        const int KG = std::min<int>(batch_workers ? batch_workers : 4, (int)grp.size() + (singles.empty() ? 0 : 1));      // four workers x two pairs in flight
         std::vector<int> grc(std::max(KG, 1), 0);
         std::vector<std::string> gerr(std::max(KG, 1));
         const size_t nbytes = (size_t)w * h * 3;
