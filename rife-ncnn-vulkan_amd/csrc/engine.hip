@@ -2759,7 +2759,7 @@ static int rife_hip_process_device_batch_impl(const rife_hip_t* E, int n, const 
         const bool copy = i < n && (timestep[i] == 0.f || timestep[i] == 1.f);
         if (i < n && copy) {
             Ctx* c = lease();
-            if (!c) { rc = RIFE_HIP_EHIP; break; }
+            if (!c) { rc = fail(RIFE_HIP_EHIP, "rife_hip_process_device_batch: no workspace (" + g_err + ")"); break; }
             if (hipMemcpyAsync(d_out[i], timestep[i] == 0.f ? d_in0[i] : d_in1[i], nbytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "copy failed");
             continue;
         }
@@ -2767,7 +2767,7 @@ static int rife_hip_process_device_batch_impl(const rife_hip_t* E, int n, const 
         if (pend < 0) break;
         if (i < n) {            // group (pend, i)
             Ctx* a = lease(); Ctx* b = a ? lease() : nullptr;
-            if (!a || !b) { rc = RIFE_HIP_EHIP; break; }
+            if (!a || !b) { rc = fail(RIFE_HIP_EHIP, "rife_hip_process_device_batch: no workspace (" + g_err + ")"); break; }
             Ctx* g2[2] = {a, b};
             const uint8_t* p0[2] = {(const uint8_t*)d_in0[pend], (const uint8_t*)d_in0[i]};
             const uint8_t* p1[2] = {(const uint8_t*)d_in1[pend], (const uint8_t*)d_in1[i]};
@@ -2777,7 +2777,7 @@ static int rife_hip_process_device_batch_impl(const rife_hip_t* E, int n, const 
             pend = -1;
         } else {                // the odd pair left over
             Ctx* c = lease();
-            if (!c) { rc = RIFE_HIP_EHIP; break; }
+            if (!c) { rc = fail(RIFE_HIP_EHIP, "rife_hip_process_device_batch: no workspace (" + g_err + ")"); break; }
             rc = run_v4_replay(*E, *c, (const uint8_t*)d_in0[pend], (const uint8_t*)d_in1[pend], timestep[pend], (uint8_t*)d_out[pend]);
             pend = -1;
         }
