@@ -465,8 +465,9 @@ def dry_run(args, rank, world):
 
 
 def cpu_baseline(modeldir, family, pixels, passes, size=None):
-    """The reference's `-g -1` path cannot be built here (ncnn/Vulkan absent), so the CPU leg is the oracle
-    (kind "port"), timed on a bounded sample (>= 10 s of wall time on the host's cores): plain pairs of the same model at
+    """The reference's `-g -1` BINARY cannot be built here (ncnn/Vulkan absent), so the CPU leg is the oracle
+    (kind "port"; `reference_build` next to it = the reference's own src/rife.cpp + warp.cpp compiled against the ncnn look-alike of
+    oracle/refbuild/, whose convolutions are the port's: same speed, it is there to show that), timed on a bounded sample (>= 10 s of wall time on the host's cores): plain pairs of the same model at
     the workload's own frame size (1920x1080 for the TTA workload; the result is then scaled by the pixel ratio and the
     x16 passes of -x -z: the work is linear in both)."""
     from oracle import pyoracle
@@ -488,6 +489,19 @@ def cpu_baseline(modeldir, family, pixels, passes, size=None):
     res = {"value": round(1.0 / (per_pair * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port",
            "sample": "%d plain %s pair(s) at %dx%d in %.2f s with %d OpenMP threads; scaled by x%.3g (pixels x TTA passes, work is linear in both)"
                      % (n, family, w, h, dt, cores, 1.0 / scale)}
+    try:                                                             # the reference build (oracle/_ref; prebuilt on the GPU box): one pair, same frames, same threads
+        from oracle import pyref
+        if pyref.available():
+            rr = pyref.RefRIFE(rife_v2=family.startswith("rife-v2"), rife_v4=family.startswith("rife-v4"), num_threads=cores)
+            rr.load(modeldir)
+            t2 = time.perf_counter()
+            out_ref = rr.process(a, b, 0.5)
+            dtr = time.perf_counter() - t2
+            res["reference_build"] = {"value": round(1.0 / (dtr * scale), 5), "unit": "frames/s", "cores": cores,
+                                      "same_bytes_as_the_port": bool(w % 32 != 0 or np.array_equal(out_ref, o.process(a, b, 0.5))),
+                                      "sample": "1 pair at %dx%d in %.2f s: /root/reference/src/rife.cpp + warp.cpp compiled unmodified (oracle/refbuild), layer arithmetic = the port's" % (w, h, dtr)}
+    except Exception as e:
+        res["reference_build"] = {"error": str(e)[:200]}
     # secondary, labelled proxy: the same graph through PyTorch-CPU (oneDNN convolutions) as a stand-in for the optimised
     # x86 kernels of the reference's ncnn CPU path, which the naive direct convolutions of the oracle do not represent
     if family.startswith("rife-v4"):
