@@ -39,6 +39,8 @@ def trunk_conv(x, w, b, stride=1, padding=0):
     if s == "hi":
         return REAL_CONV(hi, w, b, stride=stride, padding=padding)
     lo = x - hi
+    if s.startswith("wino"):
+        return wino_conv(hi + lo.half().float(), w, b, int(s[4:] or 3))
     if s == "rs_fp8":
         # conv_rs_kernel's fp8 form (block 3 only, 64 channels): the tensor between the layers is {hi f16, e4m3(lo * 2^9)}, so the skip
         # connection sees hi + lo_q too; the lo product runs on e4m3(w * 2^kw), kw = the largest power of two that keeps max |w| <= 448
@@ -69,6 +71,38 @@ def trunk_conv(x, w, b, stride=1, padding=0):
         ws = 2.0 ** np.floor(np.log2((448.0 if dt == torch.float8_e4m3fn else 57344.0) / max(wmax, 1e-30)))     # one power-of-two scale per layer
         w_q = q8(w, dt, ws) if "w8" in s else w
     return REAL_CONV(hi, w, b, stride=stride, padding=padding) + REAL_CONV(lo_q, w_q, None, stride=stride, padding=padding)
+
+
+_G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float32)
+_BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+_AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+
+
+def wino_conv(x, w, b, nprod):
+    """Winograd F(2x2, 3x3) on the split-f16 matrix pipe (round 4 study, DESIGN (f)-0): 3x3 pad-1 stride-1 convolution of x (the S16 tensor's value hi + lo).
+    Transformed weights U = G g G^T and transformed input tiles V = B^T d B are fp32 and are each split into f16 hi + lo; the element-wise GEMMs
+    over the input channels run as nprod products with fp32 accumulation: 2 = Uhi Vhi + Uhi Vlo (weights rounded to f16), 3 = + Ulo Vhi, 4 = + Ulo Vlo.
+    Matrix instructions per output pixel: 16 / 4 x nprod against 9 x 2 for the direct split-f16 form."""
+    C, H, W = x.shape[-3], x.shape[-2], x.shape[-1]
+    xb = x.reshape(1, C, H, W)
+    Hp, Wp = (H + 1) // 2 * 2, (W + 1) // 2 * 2
+    xp = F.pad(xb, (1, 1 + Wp - W, 1, 1 + Hp - H))
+    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                         # [1, C, th, tw, 4, 4]
+    V = torch.einsum("ij,bcthjk,lk->bcthil", _BT, d, _BT)          # B^T d B
+    U = torch.einsum("ij,ocjk,lk->ocil", _G, w, _G)                # G g G^T
+    Uh = U.half().float(); Ul = (U - Uh).half().float()
+    Vh = V.half().float(); Vl = (V - Vh).half().float()
+    M = torch.einsum("ocil,bcthil->bothil", Uh, Vh) + torch.einsum("ocil,bcthil->bothil", Uh, Vl)
+    if nprod >= 3:
+        M = M + torch.einsum("ocil,bcthil->bothil", Ul, Vh)
+    if nprod >= 4:
+        M = M + torch.einsum("ocil,bcthil->bothil", Ul, Vl)
+    Y = torch.einsum("ij,bothjk,lk->bothil", _AT, M, _AT)          # [1, O, th, tw, 2, 2]
+    O, th, tw = Y.shape[1], Y.shape[2], Y.shape[3]
+    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(1, O, th * 2, tw * 2)[:, :, :H, :W]
+    if b is not None:
+        y = y + b.view(1, -1, 1, 1)
+    return y.reshape(x.shape[:-3] + (O, H, W))
 
 
 REAL_CONV = F.conv2d
