@@ -262,3 +262,27 @@ def test_pmc_tables_reads_the_committed_summaries(tmp_path):
         assert dom.split("<")[0] in table
         derived = [l for l in open(dst / ("pmc_trunk_kernels_%s.txt" % wl)) if "matrix pipe busy" in l]
         assert len(derived) >= 2
+
+
+def test_live_traffic_degrades_to_a_reason_without_rocprofv3(monkeypatch):
+    """bench.py measures roofline.traffic with rocprofv3 child passes; where the profiler is not usable it must come back with (None, reason),
+    never raise (the bench line then carries the committed figure, labelled)."""
+    import bench
+    monkeypatch.setenv("PATH", "/nonexistent")
+    tb, why = bench.live_traffic("4k", "rife-v4.6", timeout_s=5)
+    assert tb is None and "rocprofv3" in why
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_exercise_the_all_ranks_host_leg():
+    """`bench.py --gpus 2 --share-gpu`: the N-rank code paths on real HIP work (both ranks on device 0, gloo rendezvous): sharding, barriers, the
+    all-ranks host-buffer leg with NUMA pinning from sysfs.  A plumbing check - the line says so - not a scaling measurement."""
+    import json
+    r = _bench("--gpus", "2", "--share-gpu", "--workload", "1080p", "--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic", "--no-extra")
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and "TEST MODE" in d["config"]["parallelism"]
+    leg = d["extra"]["frames_per_s_host_buffers_all_ranks"]
+    assert leg["pageable"]["frames_per_s"] > 0 and leg["page_locked"]["frames_per_s"] > 0
+    assert abs(leg["pageable"]["host_device_GBps"] - leg["pageable"]["frames_per_s"] * 3 * 1920 * 1080 * 3 / 1e9) < 0.05
+    assert d["extra"]["numa"] is not None and d["extra"]["numa"]["pci"].count(":") == 2
