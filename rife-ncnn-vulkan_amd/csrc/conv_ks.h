@@ -303,7 +303,6 @@ void conv_ks_kernel(KsArgs a) {
                     const int y = y0 + it - 1;
                     const unsigned char* const sbuf = ldsb + K::LDS_STG;
                     unsigned char* const dst = tout + ((unsigned)((y + 1) * a.pitch + x0 + 1) * 32u + (unsigned)(lane * 16));
-#pragma unroll
                     for (int cc = j; cc < 2 * NB; cc += KS_NST) {        // chunk cc of the group = output block cc >> 1, half cc & 1
                         const int nn = cc >> 1, hh = cc & 1;
                         f32x4 s0, s1;
