@@ -132,10 +132,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="4k", choices=list(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=0, help="frame pairs in flight per GPU in the timed region; 0 = the workload's default: 3 for 4k (measured 466 vs 459 frames/s with 2, the reference's default of 2 proc threads per GPU, -j 1:2:2), "
-                    "one per chip partition where --cu-parts applies, 2 otherwise")
+    ap.add_argument("--streams", type=int, default=0, help="frame pairs in flight per GPU in the timed region; 0 = the workload's default: 4 where the chip is partitioned (--cu-parts; the reference's -j knob, src/main.cpp:849-866), "
+                    "2 otherwise (the reference's default, -j 1:2:2)")
     ap.add_argument("--cu-parts", type=int, default=-1, help="partition the compute units between the pairs in flight: every stream owns 1 / N of them (rife_hip_stream_create; "
-                    "include/rife_hip.h).  -1 = the workload's default: 4 for the 1080p workloads (rife-v4.6: measured 1,690 vs 1,450 - 1,590 frames/s; rife-v2.3: 478 vs 448 - 470), none for the 4K ones (no gain)")
+                    "include/rife_hip.h).  -1 = the workload's default: 4 for the 1080p workloads (rife-v4.6: measured 1,690 vs 1,450 - 1,590 frames/s; rife-v2.3: 478 vs 448 - 470), 2 for 4k (two pairs per half: 473 - 479 vs 465 - 469 from three ordinary streams, same call), none for 4k-tta")
     ap.add_argument("--no-extra", action="store_true", help="skip the second region (1 pair in flight, clean per-launch kernel timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive legs (rife_hip_process from pageable host buffers)")
@@ -221,8 +221,8 @@ def main():
         f = np.roll(base[i % 2], (2 * (i // 2), 5 * (i // 2)), axis=(0, 1))
         frames.append(torch.from_numpy(np.ascontiguousarray(f)).cuda())
     timesteps = [0.5, 0.125, 0.25, 0.7, 0.9]
-    cu_parts = args.cu_parts if args.cu_parts >= 0 else (4 if args.workload in ("1080p", "v23-1080p") else 0)
-    nstreams = args.streams if args.streams > 0 else (cu_parts if cu_parts > 1 else 3 if args.workload == "4k" else 2)
+    cu_parts = args.cu_parts if args.cu_parts >= 0 else (4 if args.workload in ("1080p", "v23-1080p") else 2 if args.workload == "4k" else 0)
+    nstreams = args.streams if args.streams > 0 else (4 if cu_parts > 1 else 2)
 
     class PartStream:                                        # a stream of rife_hip_stream_create, with torch.cuda.Stream's attribute
         def __init__(self, part, nparts):

@@ -68,7 +68,7 @@ int rife_hip_process_device(const rife_hip_t* r, const void* d_in0_rgb, const vo
  * compute units of its own: rife_hip_stream_create returns a hipStream_t restricted to the compute units i with i % nparts == part
  * (hipExtStreamCreateWithCUMask), and rife_hip_process_device on such a stream sizes its persistent kernels for that part.  Frames are the same
  * bytes on every stream.  nparts = 1: an ordinary stream.  Measured (1920x1080, resident frames): 4 parts x 1 caller each 1,690 frames/s against
- * 1,450 - 1,590 from 3 ordinary streams; no gain at 3840x2160.  Destroy with rife_hip_stream_destroy (after the work on it has finished), or
+ * 1,450 - 1,590 from 3 ordinary streams; 3840x2160: 2 parts x 2 callers each 473 - 479 against 465 - 469.  Destroy with rife_hip_stream_destroy (after the work on it has finished), or
  * let rife_hip_destroy do it. */
 int rife_hip_stream_create(const rife_hip_t* r, int part, int nparts, void** hip_stream);
 int rife_hip_stream_destroy(const rife_hip_t* r, void* hip_stream);
