@@ -40,7 +40,7 @@ def test_ref_library_is_the_reference_source_not_the_restatement():
 
 @pytest.mark.parametrize("fam", sorted(FLAGS))
 @pytest.mark.parametrize("mode", [dict(), dict(tta_temporal_mode=True)], ids=["plain", "z"])
-@pytest.mark.parametrize("size", [(128, 64), (100, 60)], ids=["128x64", "ragged100x60"])
+@pytest.mark.parametrize("size", [(128, 64), (100, 60), (101, 61)], ids=["128x64", "ragged100x60", "odd101x61"])      # 101 x 61: ncnn's 16-byte cstep alignment pads the 3-D Mats of the frame
 def test_plain_and_temporal_bit_identical(modeldirs, fam, mode, size):
     r, o = both(fam, modeldirs[fam], **mode)
     a, b = gen_frames.smooth_pair(size[0], size[1], 5)
