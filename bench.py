@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--no-numa-pin", action="store_true", help="do not restrict the rank to the CPUs of its GPU's NUMA node (read from /sys/class/drm/card*/device/numa_node)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST MODE for a 1-GPU box: all ranks use device 0 and rendezvous over gloo (RCCL refuses two ranks on one device); "
                     "exercises the N-rank code paths (sharding, barriers, the all-ranks host-buffer leg) on real HIP work.  The line is labelled and is not a scaling measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configs (extra.configs: 1080p, v23-1080p, 4k-tta) that the default call appends")
     ap.add_argument("--dry-run", action="store_true", help="CPU plumbing check (gloo): launcher, sharding, barrier, MAX over ranks, JSON; no HIP work")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -405,6 +406,15 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(modeldir, family, w * h, 16 if tta and tta_temporal else 1, (w, h))
         fps = world * args.steps / elapsed
+        # the default call certifies EVERY BASELINE config: short legs of the other three workloads, same stream policy as their --workload runs
+        configs = None
+        if args.workload == "4k" and world == 1 and not args.no_configs and not f32_mode:
+            configs = other_configs(amd, torch, sh, local, eng, base, None if args.no_cpu_baseline else cpu_baseline_small_frames())
+        boundary = None
+        if host:
+            kbest = max((k for k in host if isinstance(host[k], float)), key=lambda k: host[k])
+            boundary = {"value": host[kbest], "unit": "frames/s", "leg": kbest,
+                        "note": "best PCIe-inclusive figure of this run: host frames in, host frame out through RIFE::process / rife_hip_process_batch (the boundary the reference exposes); never `value`"}
         line = {
             "metric": "interpolated frames/sec (%s, %dx%d%s)" % (family, w, h, " -x -z" if tta else ""), "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -426,12 +436,113 @@ def main():
                       "frames_per_s_with_1_pair_in_flight": None if fps1 is None else round(fps1, 3), "kernel_ms_per_pair": round(all_ms / args.steps, 4), "conv_ms_per_pair": round(conv_ms / args.steps, 4),
                       "conv_tflops_overall": round(gflop_pair / max(conv_ms / args.steps, 1e-9), 2),
                       "frac_of_fused_hbm_roofline_e2e": None if roofline_ms is None else round(roofline_ms / (elapsed / args.steps * 1e3), 5),
-                      "per_class_ms_per_pair": {k: round(v["ms"] / args.steps, 4) for k, v in sorted((prof1 or prof).items(), key=lambda kv: -kv[1]["ms"])}},
+                      "per_class_ms_per_pair": {k: round(v["ms"] / args.steps, 4) for k, v in sorted((prof1 or prof).items(), key=lambda kv: -kv[1]["ms"])},
+                      "frames_per_s_process_boundary": boundary,
+                      "configs": configs},
         }
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# short legs of the other BASELINE configs, appended to the default call as extra.configs: (steps, warm-up, profiled steps)
+CONFIG_LEGS = {"1080p": (12, 3, 4), "v23-1080p": (12, 3, 4), "4k-tta": (3, 1, 1)}
+
+
+def leg_fps(torch, sh, eng, frames, w, h, nstreams, cu_parts, steps, warmup, local):
+    """One barrier-bracketed region of `steps` resident pairs, `nstreams` pairs in flight (one host thread per stream), the workload's stream
+    policy.  Returns (frames/s, the streams) - the same procedure as the main region, on one rank."""
+    import threading
+    timesteps = [0.5, 0.125, 0.25, 0.7, 0.9]
+    streams = [eng.stream_create(i % cu_parts, cu_parts) if cu_parts > 1 else torch.cuda.Stream().cuda_stream for i in range(nstreams)]
+    outs = [torch.empty((h, w, 3), dtype=torch.uint8, device="cuda") for _ in range(nstreams)]
+    nfr = len(frames)
+
+    def step(i):
+        s = i % nstreams
+        eng.process_device(frames[i % nfr].data_ptr(), frames[(i + 1) % nfr].data_ptr(), w, h, timesteps[i % len(timesteps)], outs[s].data_ptr(), streams[s])
+
+    def run(first, count):
+        def worker(s):
+            torch.cuda.set_device(local)
+            for i in range(first, first + count):
+                if i % nstreams == s:
+                    step(i)
+        th = [threading.Thread(target=worker, args=(s,)) for s in range(nstreams)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    run(0, nstreams)                                         # untimed set-up: workspaces, kernel attributes
+    for i in range(warmup):
+        step(i)
+    el = sh.timed_steps(lambda i: run(i, steps), 1, first_index=warmup, device_sync=torch.cuda.synchronize)
+    return steps / el, outs
+
+
+def other_configs(amd, torch, sh, local, eng46, base4k, oracle_small):
+    """extra.configs: {name: {value, ms_per_step, steps, roofline_frac, max_lsb, ...}} for BASELINE configs 3, 2 and 5 (the headline `value` stays config 4's).
+    max_lsb = the engine against the CPU oracle on a 256x160 smooth pair in the same mode (the full-size comparisons are the -m gpu tests and
+    profiles/*/parity_report.txt; the oracle needs seconds to minutes per full-size pair)."""
+    from tools import gen_frames, gen_models
+    res = {}
+    t_all = time.perf_counter()
+    small = gen_frames.smooth_pair(*SMALL_PAIR)
+    for name, (steps, warmup, psteps) in CONFIG_LEGS.items():
+        t0 = time.perf_counter()
+        try:
+            family, w, h, gflop_pair, roofline_ms, tta, tta_temporal = WORKLOADS[name]
+            v2, v4 = family.startswith("rife-v2"), family.startswith("rife-v4")
+            modeldir = gen_models.ensure(None, family)
+            if family == "rife-v4.6" and not tta:
+                eng = eng46
+            else:
+                eng = amd.RIFE(local, tta_mode=tta, tta_temporal_mode=tta_temporal, rife_v2=v2, rife_v4=v4)
+                eng.load(modeldir)
+            # parity first (small workspaces), then the timed legs at full size
+            max_lsb = None
+            if oracle_small is not None and name in oracle_small:
+                got = eng.process(small[0], small[1], 0.5)
+                max_lsb = int(np.abs(got.astype(np.int32) - oracle_small[name].astype(np.int32)).max())
+            if w == 3840:
+                pair = base4k
+            else:
+                try:
+                    pair = gen_frames.tiled_real_pair(w // 640)
+                except Exception:                                    # no PIL / fixture PNGs on this box
+                    pair = gen_frames.smooth_pair_native(w, h, 1000)
+            frames = []
+            for i in range(4):
+                f = np.roll(pair[i % 2], (2 * (i // 2), 5 * (i // 2)), axis=(0, 1))
+                frames.append(torch.from_numpy(np.ascontiguousarray(f)).cuda())
+            cu_parts = 0 if tta else 4
+            nstreams = 2 if tta else 4
+            fps, _ = leg_fps(torch, sh, eng, frames, w, h, nstreams, cu_parts, steps, warmup, local)
+            # dominant kernel of the leg: HIP events per launch, ONE pair in flight on the whole chip
+            st = torch.cuda.Stream().cuda_stream
+            out = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+            eng.process_device(frames[0].data_ptr(), frames[1].data_ptr(), w, h, 0.5, out.data_ptr(), st)
+            torch.cuda.synchronize()
+            eng.profile_enable(True)
+            for i in range(psteps):
+                eng.process_device(frames[i % 4].data_ptr(), frames[(i + 1) % 4].data_ptr(), w, h, 0.5, out.data_ptr(), st)
+            torch.cuda.synchronize()
+            prof = eng.profile_read()
+            eng.profile_enable(False)
+            roof = roofline_of(prof.get(DOMINANT[family][0], dict(ms=0.0, launches=0, flops=0.0)), family, w, h, False)
+            res[name] = {"metric": "interpolated frames/sec (%s, %dx%d%s)" % (family, w, h, " -x -z" if tta else ""), "value": round(fps, 3), "unit": "frames/s",
+                         "ms_per_step": round(1e3 / fps, 4), "steps": steps, "warmup": warmup, "pairs_in_flight": nstreams,
+                         "cu_partition": "none" if cu_parts <= 1 else "1 / %d of the compute units per stream" % cu_parts,
+                         "roofline_frac": None if roof is None else roof["frac"], "roofline_kernel": None if roof is None else roof["kernel"].split(" (")[0],
+                         "roofline_avg_launch_ms": None if roof is None else roof["avg_launch_ms"],
+                         "mfma_frac_issued": None if roof is None else roof["mfma_frac_issued"],
+                         "max_lsb": max_lsb, "max_lsb_on": "256x160 smooth pair vs the CPU oracle, same mode", "leg_seconds": round(time.perf_counter() - t0, 2)}
+            if eng is not eng46:
+                del eng
+            torch.cuda.synchronize()
+        except Exception as e:                                       # a failing leg must not take the headline line with it - but it must be visible
+            res[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    res["_seconds"] = round(time.perf_counter() - t_all, 2)
+    return res
 
 
 def dry_run(args, rank, world):
@@ -462,6 +573,28 @@ def dry_run(args, rank, world):
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+SMALL_PAIR = (256, 160, 77)       # w, h, seed of the smooth pair extra.configs' max_lsb is taken on
+
+
+def cpu_baseline_small_frames():
+    """Part of the cpu_baseline leg (the only place of bench.py that touches oracle/): the oracle's frames for the 256x160 smooth pair in the mode of
+    every extra.configs leg, so that each leg can state max_lsb of the engine against them."""
+    from oracle import pyoracle
+    from tools import gen_frames, gen_models
+    a, b = gen_frames.smooth_pair(*SMALL_PAIR)
+    out = {}
+    for name in CONFIG_LEGS:
+        family, _, _, _, _, tta, tta_temporal = WORKLOADS[name]
+        try:
+            o = pyoracle.OracleRIFE(tta_mode=tta, tta_temporal_mode=tta_temporal, rife_v2=family.startswith("rife-v2"), rife_v4=family.startswith("rife-v4"),
+                                    num_threads=min(len(os.sched_getaffinity(0)), 64))
+            o.load(gen_models.ensure(None, family))
+            out[name] = o.process(a, b, 0.5)
+        except Exception as e:
+            sys.stderr.write("bench.py: oracle frame for %s unavailable (%s)\n" % (name, e))
+    return out
 
 
 def cpu_baseline(modeldir, family, pixels, passes, size=None):
@@ -498,7 +631,8 @@ def cpu_baseline(modeldir, family, pixels, passes, size=None):
             out_ref = rr.process(a, b, 0.5)
             dtr = time.perf_counter() - t2
             res["reference_build"] = {"value": round(1.0 / (dtr * scale), 5), "unit": "frames/s", "cores": cores,
-                                      "same_bytes_as_the_port": bool(w % 32 != 0 or np.array_equal(out_ref, o.process(a, b, 0.5))),
+                                      "same_bytes_as_the_port": (bool(np.array_equal(out_ref, o.process(a, b, 0.5))) if w % 32 == 0 else
+                                                                 "not compared (ragged width: the reference's CPU crop quirk, SURVEY App. F-1; tests/test_ref_build.py compares the literal mode)"),
                                       "sample": "1 pair at %dx%d in %.2f s: /root/reference/src/rife.cpp + warp.cpp compiled unmodified (oracle/refbuild), layer arithmetic = the port's" % (w, h, dtr)}
     except Exception as e:
         res["reference_build"] = {"error": str(e)[:200]}

@@ -69,7 +69,11 @@ int rife_hip_process_device(const rife_hip_t* r, const void* d_in0_rgb, const vo
  * (hipExtStreamCreateWithCUMask), and rife_hip_process_device on such a stream sizes its persistent kernels for that part.  Frames are the same
  * bytes on every stream.  nparts = 1: an ordinary stream.  Measured (1920x1080, resident frames): 4 parts x 1 caller each 1,690 frames/s against
  * 1,450 - 1,590 from 3 ordinary streams; 3840x2160: 2 parts x 2 callers each 473 - 479 against 465 - 469.  Destroy with rife_hip_stream_destroy (after the work on it has finished), or
- * let rife_hip_destroy do it. */
+ * let rife_hip_destroy do it.
+ * Synchronisation semantics: hipExtStreamCreateWithCUMask takes no flags, so a stream with nparts > 1 is a BLOCKING stream - it synchronises implicitly
+ * with the legacy NULL stream (work enqueued on stream 0, plain hipMemcpy / hipMemset), while nparts = 1 returns a hipStreamNonBlocking stream.  Keep
+ * NULL-stream work out of the process while partition streams carry pairs, or the "independent" parts serialise behind it; the engine itself never
+ * enqueues on the NULL stream. */
 int rife_hip_stream_create(const rife_hip_t* r, int part, int nparts, void** hip_stream);
 int rife_hip_stream_destroy(const rife_hip_t* r, void* hip_stream);
 

@@ -4,6 +4,7 @@
 // bench-only: time the 8-wave trunk kernel on a synthetic (h x w x c) -> c layer; variant bits: 256 no stores,
 // 512 no global loads after chunk 1, 1024 no barriers (the last two compute garbage; timing ablations only)
 int rife_hip_bench_conv8(int gpuid, int c, int h, int w, int variant, int iters, float* ms_out) {
+    tl_cu_budget = 0;                                                    // bench hooks size their grids for the whole chip, whatever stream this thread used last
     int rc;
     if ((rc = check_device(gpuid))) return rc;
     if (c != 64) return fail(RIFE_HIP_EINVAL, "bench supports c = 64");
@@ -202,6 +203,7 @@ int rife_hip_bench_mfma_mix(int gpuid, int mix, int tiles, int iters, float* ms_
 // bench-only: ablations of the split-f16 trunk kernel (variant bits: 256 no stores, 512 no prefetch loads, 1024 no barriers,
 // 2048 no LDS staging writes after the first chunk; all but 0/256 compute garbage — timing only)
 int rife_hip_bench_h2b(int gpuid, int h, int w, int variant, int iters, float* ms_out) {
+    tl_cu_budget = 0;                                                    // bench hooks size their grids for the whole chip, whatever stream this thread used last
     int rc;
     if ((rc = check_device(gpuid))) return rc;
     const int c = 64;
@@ -277,6 +279,7 @@ int rife_hip_bench_h2b(int gpuid, int h, int w, int variant, int iters, float* m
 // bench-only: the persistent S16 trunk kernel (conv_t64.h) on an h x w tensor of random records, ping-pong between two tensors like
 // consecutive trunk layers; variant = ablation bits of conv_t64.h (0 = the product kernel); T64_STAMPS writes gpurun_out/t64_stamps.bin
 int rife_hip_bench_t64(int gpuid, int h, int w, int variant, int iters, float* ms_out) {
+    tl_cu_budget = 0;                                                    // bench hooks size their grids for the whole chip, whatever stream this thread used last
     int rc;
     if ((rc = check_device(gpuid))) return rc;
     std::vector<float> wts((size_t)64 * 64 * 9), bias(64, 0.f);
@@ -470,6 +473,7 @@ static int bench_ks_cfg(int gpuid, int h, int w, int variant, int iters, int div
 }
 }  // extern "C++"
 int rife_hip_bench_ks(int gpuid, int C, int h, int w, int variant, int iters, int div, float* ms_out, long long* stamps_out, int* nwg_out) {
+    tl_cu_budget = 0;                                                    // bench hooks size their grids for the whole chip, whatever stream this thread used last
     int rc;
     if ((rc = check_device(gpuid))) return rc;
     if (C == 128) return bench_ks_cfg<128, 2, 2>(gpuid, h, w, variant, iters, div, ms_out, stamps_out, nwg_out);
@@ -478,6 +482,7 @@ int rife_hip_bench_ks(int gpuid, int C, int h, int w, int variant, int iters, in
 }
 
 int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms_out, long long* stats) {
+    tl_cu_budget = 0;                                                    // bench hooks size their grids for the whole chip, whatever stream this thread used last
     int rc;
     if ((rc = check_device(gpuid))) return rc;
     if ((h + 1) / 2 < RS_MIN_PAIRS) return fail(RIFE_HIP_EINVAL, "conv_rs needs at least 7 rows");
@@ -803,6 +808,7 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
 
 // bench-only: tail_rs_kernel (tail_rs.h) on a wp x hp frame with random trunk / flows / weights, variant = TRS_* ablation bits
 int rife_hip_bench_tail_rs(int gpuid, int wp, int hp, int variant, int iters, float* ms_out) {
+    tl_cu_budget = 0;                                                    // bench hooks size their grids for the whole chip, whatever stream this thread used last
     int rc;
     if ((rc = check_device(gpuid))) return rc;
     const size_t P = (size_t)wp * hp;
@@ -864,6 +870,7 @@ int rife_hip_bench_tail_rs(int gpuid, int wp, int hp, int variant, int iters, fl
 // bench-only: stem_rs_kernel (stem_rs.h) on a wp x hp frame with random frames / flows / weights, variant = SRS_* ablation bits | 0x100 * g
 // (g > 0: g workgroups per CU instead of two)
 int rife_hip_bench_stem_rs(int gpuid, int wp, int hp, int variant, int iters, float* ms_out, long long* stamps_out) {
+    tl_cu_budget = 0;                                                    // bench hooks size their grids for the whole chip, whatever stream this thread used last
     int rc;
     if ((rc = check_device(gpuid))) return rc;
     const size_t P = (size_t)wp * hp;
@@ -944,6 +951,7 @@ int rife_hip_bench_stem_rs(int gpuid, int wp, int hp, int variant, int iters, fl
 
 // bench-only: ablations of stem0_fused_kernel<1,1> on a wp x hp frame (variant = ABL bits, see stem_fused.h)
 int rife_hip_bench_stemf(int gpuid, int wp, int hp, int variant, int iters, float* ms_out) {
+    tl_cu_budget = 0;                                                    // bench hooks size their grids for the whole chip, whatever stream this thread used last
     int rc;
     if ((rc = check_device(gpuid))) return rc;
     const size_t P = (size_t)wp * hp;

@@ -2737,61 +2737,78 @@ static int rife_hip_process_device_batch_impl(const rife_hip_t* E, int n, const 
     }
     hipStream_t user = (hipStream_t)hip_stream;
     const size_t nbytes = (size_t)w * h * 3;
-    hipEvent_t fork = nullptr;
+    // the fork event goes back to the pool on EVERY exit path (re-recorded by its next user; waits already enqueued keep their own snapshot of it)
+    struct ForkLease {
+        const rife_hip_t* E; hipEvent_t ev = nullptr;
+        ~ForkLease() { if (ev) { std::lock_guard<std::mutex> g(E->mu); E->batch_fork.push_back(ev); } }
+    } fk{E};
     {
         std::lock_guard<std::mutex> g(E->mu);
-        if (!E->batch_fork.empty()) { fork = E->batch_fork.back(); E->batch_fork.pop_back(); }
+        if (!E->batch_fork.empty()) { fk.ev = E->batch_fork.back(); E->batch_fork.pop_back(); }
     }
-    if (!fork) HIPCHK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    if (!fk.ev) HIPCHK(hipEventCreateWithFlags(&fk.ev, hipEventDisableTiming));
+    hipEvent_t fork = fk.ev;
     if (user) HIPCHK(hipEventRecord(fork, user));      // NULL = "the engine's own streams": nothing to order against, the call synchronises before it returns
+    // At most MAXG groups (2 MAXG workspaces) are in flight however many pairs the call carries: further groups re-use them round-robin - work on a
+    // workspace's stream executes in order, so a re-used workspace simply queues behind its previous pair (device memory stays O(1) in n).
+    constexpr int MAXG = 4;
     std::vector<std::unique_ptr<Ctx>> cs;
+    std::unique_ptr<Ctx> copy_ctx;                       // timestep 0 / 1 with no caller stream: one internal stream for the D2D copies
+    size_t next_slot = 0;
+    auto lease_new = [&](std::unique_ptr<Ctx>& c) -> bool {
+        if (lease_ctx(E, c, w, h)) return false;
+        if (!c->ev_group && hipEventCreateWithFlags(&c->ev_group, hipEventDisableTiming) != hipSuccess) { release_ctx(E, c); return false; }
+        if (user && hipStreamWaitEvent(c->stream, fork, 0) != hipSuccess) { release_ctx(E, c); return false; }
+        return true;
+    };
     auto lease = [&]() -> Ctx* {
-        std::unique_ptr<Ctx> c;
-        if (lease_ctx(E, c, w, h)) return nullptr;
-        if (!c->ev_group && hipEventCreateWithFlags(&c->ev_group, hipEventDisableTiming) != hipSuccess) { release_ctx(E, c); return nullptr; }
-        if (user && hipStreamWaitEvent(c->stream, fork, 0) != hipSuccess) { release_ctx(E, c); return nullptr; }
-        cs.push_back(std::move(c));
-        return cs.back().get();
+        if (cs.size() < (size_t)(2 * MAXG)) {
+            std::unique_ptr<Ctx> c;
+            if (!lease_new(c)) return nullptr;
+            cs.push_back(std::move(c));
+            return cs.back().get();
+        }
+        Ctx* c = cs[next_slot++ % cs.size()].get();     // always taken in pairs from an even-sized pool: the two of a group are distinct
+        tl_cu_budget = c->cu_budget;
+        return c;
     };
     rc = 0;
     int pend = -1;
     for (int i = 0; i <= n && !rc; i++) {
         const bool copy = i < n && (timestep[i] == 0.f || timestep[i] == 1.f);
-        if (i < n && copy) {
-            Ctx* c = lease();
-            if (!c) { rc = fail(RIFE_HIP_EHIP, "rife_hip_process_device_batch: no workspace (" + g_err + ")"); break; }
-            if (hipMemcpyAsync(d_out[i], timestep[i] == 0.f ? d_in0[i] : d_in1[i], nbytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "copy failed");
+        if (i < n && copy) {             // rife.cpp:2470-2480: an input frame unchanged - a D2D copy, no workspace; on the caller's stream when there is one
+            hipStream_t cst = user;
+            if (!cst) {
+                if (!copy_ctx && !lease_new(copy_ctx)) { rc = fail(RIFE_HIP_EHIP, "rife_hip_process_device_batch: no workspace (" + g_err + ")"); break; }
+                cst = copy_ctx->stream;
+            }
+            if (hipMemcpyAsync(d_out[i], timestep[i] == 0.f ? d_in0[i] : d_in1[i], nbytes, hipMemcpyDeviceToDevice, cst) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "copy failed");
             continue;
         }
         if (i < n && pend < 0) { pend = i; continue; }
         if (pend < 0) break;
+        Ctx* a = lease(); Ctx* b = a ? lease() : nullptr;      // the odd pair left over takes (and leaves idle) the second workspace of its slot pair
+        if (!a || !b) { rc = fail(RIFE_HIP_EHIP, "rife_hip_process_device_batch: no workspace (" + g_err + ")"); break; }
         if (i < n) {            // group (pend, i)
-            Ctx* a = lease(); Ctx* b = a ? lease() : nullptr;
-            if (!a || !b) { rc = fail(RIFE_HIP_EHIP, "rife_hip_process_device_batch: no workspace (" + g_err + ")"); break; }
             Ctx* g2[2] = {a, b};
             const uint8_t* p0[2] = {(const uint8_t*)d_in0[pend], (const uint8_t*)d_in0[i]};
             const uint8_t* p1[2] = {(const uint8_t*)d_in1[pend], (const uint8_t*)d_in1[i]};
             const float ts[2] = {timestep[pend], timestep[i]};
             uint8_t* po[2] = {(uint8_t*)d_out[pend], (uint8_t*)d_out[i]};
             rc = run_v4_group(*E, g2, 2, p0, p1, ts, po);
-            pend = -1;
-        } else {                // the odd pair left over
-            Ctx* c = lease();
-            if (!c) { rc = fail(RIFE_HIP_EHIP, "rife_hip_process_device_batch: no workspace (" + g_err + ")"); break; }
-            rc = run_v4_replay(*E, *c, (const uint8_t*)d_in0[pend], (const uint8_t*)d_in1[pend], timestep[pend], (uint8_t*)d_out[pend]);
-            pend = -1;
+        } else {
+            tl_cu_budget = a->cu_budget;
+            rc = run_v4_replay(*E, *a, (const uint8_t*)d_in0[pend], (const uint8_t*)d_in1[pend], timestep[pend], (uint8_t*)d_out[pend]);
         }
+        pend = -1;
     }
     // join: the caller's stream continues after every internal stream (also after an error: nothing may still run on the frames when we return control of them)
+    if (copy_ctx) cs.push_back(std::move(copy_ctx));
     for (auto& c : cs) {
         if (!user) { if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(RIFE_HIP_EHIP, "stream sync failed"); }
         else if (hipEventRecord(c->ev_group, c->stream) != hipSuccess || hipStreamWaitEvent(user, c->ev_group, 0) != hipSuccess) { (void)hipStreamSynchronize(c->stream); if (!rc) rc = fail(RIFE_HIP_EHIP, "join failed"); }
     }
     for (auto& c : cs) release_ctx(E, c);
-    {
-        std::lock_guard<std::mutex> g(E->mu);
-        E->batch_fork.push_back(fork);      // re-recorded by its next user; the waits enqueued above keep their own snapshot of it
-    }
     return rc;
 }
 int rife_hip_process_device_batch(const rife_hip_t* E, int n, const void* const* d_in0, const void* const* d_in1, const float* timestep,
