@@ -44,6 +44,53 @@ int rife_hip_bench_conv8(int gpuid, int c, int h, int w, int variant, int iters,
     return rc;
 }
 
+// bench-only: ONE layer of the product schedule through launch_conv() on `nstreams` concurrent streams (own tensors per stream, shared weights),
+// `iters` launches per stream back to back: ms_out[0] = wall time per launch at saturation (elapsed / (iters * nstreams)), ms_out[1] = one stream alone.
+// kind 0: 3x3 stride 1 + PReLU, 1: 3x3 stride 2 + PReLU, 2: Deconvolution 4x4 s2 + PReLU.  in_ld = input pixel stride (>= cin padded to 16).
+int rife_hip_bench_layer(int gpuid, int cin, int cout, int h, int w, int kind, int in_ld, int nstreams, int iters, float* ms_out) {
+    tl_cu_budget = 0;
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    if (nstreams < 1 || nstreams > 16 || iters < 1) return fail(RIFE_HIP_EINVAL, "bad bench arguments");
+    const int kk = kind == 2 ? 16 : 9;
+    std::vector<float> wts((size_t)cin * cout * kk), bias(cout), slope(cout);
+    uint32_t lcg = 12345u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((int)(lcg >> 9) - (1 << 22)) / (float)(1 << 22); };   // [-1, 1)
+    const float ws = std::sqrt(2.0f / (float)(cin * 9));
+    for (auto& v : wts) v = (float)(_Float16)(rnd() * ws);
+    for (auto& v : bias) v = rnd() * 0.01f;
+    for (auto& v : slope) v = 0.25f + 0.25f * rnd();
+    ConvLayer L; L.cin = cin; L.cout = cout; L.stride = kind == 1 ? 2 : 1; L.deconv = kind == 2; L.epi = kind == 2 ? EPI_DECONV : EPI_STORE; L.cls = "bench";
+    if ((rc = upload_layer(L, wts.data(), bias.data(), slope.data(), 1.0f))) return rc;
+    const int ho = kind == 1 ? (h - 1) / 2 + 1 : kind == 2 ? 2 * h : h, wo = kind == 1 ? (w - 1) / 2 + 1 : kind == 2 ? 2 * w : w;
+    const size_t nin = (size_t)h * w * in_ld, nout = (size_t)ho * wo * cout;
+    std::vector<float> hx(nin);
+    for (auto& v : hx) v = rnd();
+    std::vector<float*> xs(nstreams, nullptr), ys(nstreams, nullptr);
+    std::vector<hipStream_t> st(nstreams, nullptr);
+    for (int s = 0; s < nstreams; s++) {
+        HIPCHK(hipMalloc(&xs[s], nin * 4)); HIPCHK(hipMalloc(&ys[s], nout * 4));
+        HIPCHK(hipMemcpy(xs[s], hx.data(), nin * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking));
+    }
+    auto region = [&](int ns, float& per_launch) -> int {
+        for (int s = 0; s < ns; s++)
+            for (int i = 0; i < 2; i++) if ((rc = launch_conv(L, {xs[s], in_ld, 0}, h, w, {ys[s], cout, 0}, nullptr, st[s]))) return rc;
+        HIPCHK(hipDeviceSynchronize());
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iters; i++)
+            for (int s = 0; s < ns; s++) if ((rc = launch_conv(L, {xs[s], in_ld, 0}, h, w, {ys[s], cout, 0}, nullptr, st[s]))) return rc;
+        HIPCHK(hipDeviceSynchronize());
+        per_launch = (float)(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / ((double)iters * ns));
+        return 0;
+    };
+    rc = region(nstreams, ms_out[0]);
+    if (!rc) rc = region(1, ms_out[1]);
+    for (int s = 0; s < nstreams; s++) { (void)hipFree(xs[s]); (void)hipFree(ys[s]); (void)hipStreamDestroy(st[s]); }
+    free_layer(L);
+    return rc;
+}
+
 // hardware probe: does v_mfma_f32_32x32x16_f16 keep f16 subnormal inputs?  out[0] = sum over k of a_k*b_k with
 // a_k = 2^-20 (f16 subnormal), b_k = 1  -> 16 * 2^-20 = 1.52587890625e-05 if preserved, 0 if flushed.
 __global__ void k_probe_f16_denorm(float* out) {

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -26,6 +27,7 @@
 #include "../../include/rife_hip.h"
 #include "../../include/rife_hip_test.h"      // the parity taps and single-kernel entry points this library also exports
 #include "conv_mfma.h"
+#include "conv_img.h"
 #include "elementwise.h"
 #include "elementwise_v2.h"
 #include "stem_fused.h"
@@ -76,6 +78,7 @@ struct ConvLayer {
     unsigned char* d_t64 = nullptr;
     unsigned char* d_row = nullptr;      // 96 channels: the conv_row image next to the conv_t64 one (small grids)
     uint16_t* d_whp = nullptr;
+    uint16_t* d_wimg = nullptr;           // 3 -> 32 stride-2 layer on the RGBX u8 frame (conv_img.h): f16 [K-step 3][k half 2][32][8]
     double flops_per_pixel = 0;           // algorithmic: 2 * MAC per GEMM-M pixel
     std::string cls;                      // profile class
     int tag = 0;                          // distinct kernel symbol for the profiled layer class
@@ -90,6 +93,8 @@ static void free_layer(ConvLayer& L) {
     if (L.d_t64) (void)hipFree(L.d_t64);
     if (L.d_row) (void)hipFree(L.d_row);
     if (L.d_whp) (void)hipFree(L.d_whp);
+    if (L.d_wimg) (void)hipFree(L.d_wimg);
+    L.d_wimg = nullptr;
     L.d_w = L.d_bias = L.d_slope = L.d_w8 = nullptr; L.d_wh = nullptr; L.d_t64 = nullptr; L.d_row = nullptr; L.d_whp = nullptr;
 }
 
@@ -308,15 +313,35 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             L.nchunksh = 1;
         }
     }
-    if (!L.deconv && L.stride == 2 && L.epi == EPI_STORE && L.cin % 16 == 0 && L.cin >= 16) {      // stem-1 class: split-f16 stride-2 kernel
+    if (!L.deconv && L.stride == 2 && L.cin == 3 && L.cout == 32) {      // ContextNet's first convolution, read straight from the RGBX u8 frame (conv_img.h)
+        bool exact = true;
+        for (size_t i = 0; i < (size_t)L.cin * L.cout * 9 && exact; i++) exact = (float)(_Float16)w_orig[i] == w_orig[i];
+        if (exact) {
+            std::vector<uint16_t> pk(3 * 2 * 32 * 8, 0);
+            for (int j = 0; j < 3; j++)
+                for (int hh = 0; hh < 2; hh++)
+                    for (int oc = 0; oc < 32; oc++)
+                        for (int e = 0; e < 8; e++) {
+                            const int t = 4 * j + 2 * hh + (e >> 2), c = e & 3;
+                            if (t < 9 && c < 3) pk[((size_t)(j * 2 + hh) * 32 + oc) * 8 + e] = f2h(w_orig[((size_t)oc * 3 + c) * 9 + t]);
+                        }
+            HIPCHK(hipMalloc(&L.d_wimg, pk.size() * 2));
+            HIPCHK(hipMemcpy(L.d_wimg, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+        }
+    }
+    // stem-1 class: split-f16 stride-2 kernel.  cin = 10 (rife-v2.x / v3.x: the first convolution of IFNet blocks 1.. and of the FusionNet, whose 10-channel
+    // input is assembled as NHWC16 with six zero channels, elementwise_v2.h) rides the same kernel as one zero-padded 16-channel chunk instead of the fp32
+    // matrix path (round 5: 125 -> us for the 1920x1088 -> 48-channel layer)
+    static const bool stem16 = []() { const char* e = getenv("RIFE_HIP_V2_STEM16"); return !(e && e[0] == '0'); }();
+    if (!L.deconv && L.stride == 2 && L.epi == EPI_STORE && ((L.cin % 16 == 0 && L.cin >= 16) || (L.cin == 10 && stem16))) {
         bool exact = true;
         for (size_t i = 0; i < (size_t)L.cin * L.cout * 9 && exact; i++) exact = (float)(_Float16)w_orig[i] == w_orig[i];
         if (exact) {
             std::vector<uint16_t> ph = pack_weights_h2(L, w_orig, 9);
             HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
             HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
-            L.nchunksh = L.cin / 16;
-            if (L.want_s16out && L.cout % (L.NS * 32) == 0) {
+            L.nchunksh = (L.cin + 15) / 16;
+            if (L.want_s16out && L.cin % 16 == 0 && L.cout % (L.NS * 32) == 0) {
                 std::vector<uint16_t> pp = pack_weights_h2_perm(L, w_orig);
                 HIPCHK(hipMalloc(&L.d_whp, pp.size() * 2));
                 HIPCHK(hipMemcpy(L.d_whp, pp.data(), pp.size() * 2, hipMemcpyHostToDevice));
@@ -412,7 +437,8 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         const long wg2 = (long)a.tiles_x * ((a.Ho + 7) / 8) * a.nz;
         MS = wg2 >= 384 ? 2 : 1;
     }
-    if (L.nchunksh > 0 && !L.deconv && L.stride == 2 && L.cin >= 16 && g_trunk_h2 && g_s2_h2 && res == nullptr) {
+    if (L.nchunksh > 0 && !L.deconv && L.stride == 2 && (L.cin >= 16 || L.cin == 10) && g_trunk_h2 && g_s2_h2 && res == nullptr) {
+        if (x.ld - x.coff < 16 * L.nchunksh) return fail(RIFE_HIP_EINVAL, "conv input view is not padded to whole 16-channel chunks");
         a.ntiles_xy = a.tiles_x * ((a.Ho + 3) / 4);
         a.nchunks = L.nchunksh;
         a.wpk = reinterpret_cast<const float*>(L.d_wh);
@@ -530,7 +556,9 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         // 4-row tiles (4 waves, three workgroups per CU) for layers whose 8-row tiles would occupy only part of the chip: twice the
         // workgroups, half the latency of each (below 400 8-row workgroups: round-1 A/B)
         constexpr int rows4_max = 400;
-        const bool rows4 = g_h2b && (L.NS == 2 || L.NS == 3) && nsplit == 1 && nb < rows4_max;
+        static const int ns3_rows4 = []() { const char* e = getenv("RIFE_HIP_NS3_ROWS4"); return e ? atoi(e) : 0; }();      // A/B (round 5)
+        static const int rows4_lim = []() { const char* e = getenv("RIFE_HIP_ROWS4_MAX"); return e ? atoi(e) : rows4_max; }();
+        const bool rows4 = g_h2b && (L.NS == 2 || L.NS == 3) && nsplit == 1 && (nb < rows4_lim || (L.NS == 3 && ns3_rows4));
         if (rows4) {
             constexpr int l4_9 = convh2b_lds_bytes<2, 9, 4>(), l4_10 = convh2b_lds_bytes<2, 10, 4>();
             constexpr int l43_9 = convh2b_lds_bytes<3, 9, 4>(), l43_10 = convh2b_lds_bytes<3, 10, 4>();      // 96-wide N-tiles: 63 KB, two workgroups per CU
@@ -994,6 +1022,7 @@ struct rife_hip {
     struct V2Block { ConvLayer stem0, stem1, conv[6], head; int c = 0, scale = 1; } fblk[4];
     // rife-v3.x: same ContextNet / FusionNet, IFNet of 3 blocks (scales 4, 2, 1; 160 channels; trunk = 3 x [conv, conv, + skip])
     bool v3 = false;
+    bool prof_fine = false;                                              // RIFE_HIP_PROFILE_FINE=1: per-layer profile classes (load_v2)
     int n_fblk = 4;
     // v1 family (rife, rife-HD, rife-UHD, rife-anime): executed layer by layer from the .param (graph_exec.h)
     bool v1 = false;
@@ -1705,7 +1734,7 @@ static int run_v2_ifnet(const rife_hip& E, Ctx& c, IMG img0, IMG img1, int wp, i
         const rife_hip::V2Block& B = E.fblk[b];
         const int s = B.scale, Hb = hp / s, Wb = wp / s;
         {
-            Timed t(E.prof, "v2_assemble", 0, st);
+            Timed t(E.prof, E.prof_fine ? "fb" + std::to_string(b) + "_assemble" : std::string("v2_assemble"), 0, st);
             dim3 g = grid2d(Wb, Hb);
             if (b == 0 && s == 8) hipLaunchKernelGGL((k2_assemble0<8, IMG>), g, dim3(256), 0, st, img0, img1, c.X, wp, hp);
             else if (b == 0) hipLaunchKernelGGL((k2_assemble0<4, IMG>), g, dim3(256), 0, st, img0, img1, c.X, wp, hp);
@@ -1790,20 +1819,31 @@ static int run_v2_synth(const rife_hip& E, Ctx& c, const uint32_t* img0, const u
     const int wh = wp / 2, hh = hp / 2;
     // ---- ContextNet twice (contextnet.param): (img0, flow[0:2]) -> "3".."6", (img1, flow[2:4]) -> "7".."10",
     //      each warped level written straight into its slice of the FusionNet concat buffers ----
+    static const bool img_env = []() { const char* e = getenv("RIFE_HIP_CTX0_IMG"); return !(e && e[0] == '0'); }();      // A/B (round 5)
+    const bool ctx0_img = E.ctxc[0].d_wimg != nullptr && g_trunk_h2 && img_env;      // RIFE_HIP_TRUNK=f32 keeps the fp32 matrix path
     float* cat_buf[4] = {c.B1, c.B2, c.B3, c.B4};
     const int cat_ld[4] = {128, 256, 512, 1024}, cat_off[4] = {64, 128, 256, 512}, lvl_c[4] = {32, 64, 128, 256};
     for (int im = 0; im < 2; im++) {
         {
             Timed t(E.prof, "v2_ctx_misc", 0, st);
             const size_t P = (size_t)wp * hp;
-            hipLaunchKernelGGL(k2_image_nhwc8, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, im ? img1 : img0, c.I8, P);
+            if (!ctx0_img) hipLaunchKernelGGL(k2_image_nhwc8, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, im ? img1 : img0, c.I8, P);
             hipLaunchKernelGGL(k2_flow_half<true>, grid2d(wh / 2, hh / 2), dim3(256), 0, st, reinterpret_cast<const float*>(acc), im * 2, c.fl[0], wh, hh);
             for (int l = 1; l < 4; l++)
                 hipLaunchKernelGGL(k2_flow_half<false>, grid2d((wh >> l) / 2, (hh >> l) / 2), dim3(256), 0, st, reinterpret_cast<const float*>(c.fl[l - 1]), 0, c.fl[l],
                                    wh >> l, hh >> l);
             HIPCHK(hipGetLastError());
         }
-        if ((rc = conv_t(E, E.ctxc[0], {c.I8, 8, 0}, hp, wp, {c.ca, 32, 0}, st))) return rc;
+        if (ctx0_img) {
+            const ConvLayer& L0 = E.ctxc[0];
+            Timed t(E.prof, L0.cls, L0.flops_per_pixel * (hp / 2) * (wp / 2), st);
+            ImgConvArgs ia;
+            ia.img = im ? img1 : img0; ia.out = c.ca; ia.wpk = L0.d_wimg; ia.bias = L0.d_bias; ia.slope = L0.d_slope;
+            ia.wp = wp; ia.hp = hp; ia.Wo = wp / 2; ia.Ho = hp / 2; ia.tiles_x = (ia.Wo + 31) / 32; ia.ntiles = ia.tiles_x * ia.Ho;
+            const int nwg = std::min((ia.ntiles + 3) / 4, 8 * device_cus(true));
+            hipLaunchKernelGGL(conv_img_s2_kernel, dim3(nwg), dim3(256), 0, st, ia);
+            HIPCHK(hipGetLastError());
+        } else if ((rc = conv_t(E, E.ctxc[0], {c.I8, 8, 0}, hp, wp, {c.ca, 32, 0}, st))) return rc;
         if ((rc = conv_t(E, E.ctxc[1], {c.ca, 32, 0}, hp / 2, wp / 2, {c.cb, 32, 0}, st))) return rc;
         if ((rc = conv_t(E, E.ctxc[2], {c.cb, 32, 0}, hp / 2, wp / 2, {c.cc, 32, 0}, st))) return rc;
         if ((rc = conv_t(E, E.ctxc[3], {c.cc, 32, 0}, hp / 4, wp / 4, {c.feat[0], 32, 0}, st))) return rc;
@@ -1813,7 +1853,7 @@ static int run_v2_synth(const rife_hip& E, Ctx& c, const uint32_t* img0, const u
             if ((rc = conv_t(E, E.ctxc[3 + 2 * l], {c.ctmp[l - 1], lvl_c[l], 0}, Hl / 2, Wl / 2, {c.feat[l], lvl_c[l], 0}, st))) return rc;
         }
         {
-            Timed t(E.prof, "v2_ctx_misc", 0, st);
+            Timed t(E.prof, E.prof_fine ? "ctx_warps" : "v2_ctx_misc", 0, st);
             for (int l = 0; l < 4; l++) {
                 const int Hl = hp >> (l + 2), Wl = wp >> (l + 2), nq = lvl_c[l] / 4, ppb = 256 / nq;
                 hipLaunchKernelGGL(k2_warp_nhwc, dim3((Wl + ppb - 1) / ppb, Hl), dim3(256), 0, st, c.feat[l], lvl_c[l], c.fl[l], cat_buf[l], cat_ld[l],
@@ -1824,7 +1864,7 @@ static int run_v2_synth(const rife_hip& E, Ctx& c, const uint32_t* img0, const u
     }
     // ---- FusionNet (fusionnet.param) ----
     {
-        Timed t(E.prof, "v2_assemble", 0, st);
+        Timed t(E.prof, E.prof_fine ? "fus_assemble" : "v2_assemble", 0, st);
         hipLaunchKernelGGL((k2_assemble<1, ImgU8>), grid2d(wp, hp), dim3(256), 0, st, ImgU8{img0}, ImgU8{img1}, acc, c.X, wp, hp);
         HIPCHK(hipGetLastError());
     }
@@ -2152,7 +2192,13 @@ static int load_v2(rife_hip* E, const std::string& dir) {
     if (!mc.load_bin(dir + "/contextnet.bin")) return fail(RIFE_HIP_EIO, mc.error);
     if (!mu.load_bin(dir + "/fusionnet.bin")) return fail(RIFE_HIP_EIO, mu.error);
     int rc;
-    auto take = [&](std::vector<const NcnnLayer*>& wl, size_t& k, ConvLayer& L, int cin, int cout, int stride, bool deconv, int epi, const char* cls) -> int {
+    // RIFE_HIP_PROFILE_FINE=1: one profile class per layer position (fb<b>_stem0 / _stem1 / _trunk / _head, ctx<i>, fus<i>) instead of the coarse classes
+    // bench.py reports - what tools/part_profile.py reads on a CU-masked stream, where rocprofv3 cannot follow (its queue interception drops the mask)
+    const bool fine = []() { const char* e = getenv("RIFE_HIP_PROFILE_FINE"); return e && e[0] == '1'; }();
+    E->prof_fine = fine;
+    std::string fine_name;
+    auto take = [&](std::vector<const NcnnLayer*>& wl, size_t& k, ConvLayer& L, int cin, int cout, int stride, bool deconv, int epi, const char* cls0) -> int {
+        const char* cls = fine && !fine_name.empty() ? fine_name.c_str() : cls0;
         if (k >= wl.size()) return fail(RIFE_HIP_EMODEL, "weight stream ended early");
         const NcnnLayer* nl = wl[k++];
         const int kk = deconv ? 16 : 9;
@@ -2175,10 +2221,15 @@ static int load_v2(rife_hip* E, const std::string& dir) {
         for (int b = 0; b < E->n_fblk; b++) {
             rife_hip::V2Block& B = E->fblk[b];
             B.c = C[b]; B.scale = SC[b];
+            const std::string fb = "fb" + std::to_string(b);
+            fine_name = fb + "_stem0";
             if ((rc = take(wl, k, B.stem0, b == 0 ? 6 : 10, C[b] / 2, 2, false, EPI_STORE, "v2_flow_stem"))) return rc;
+            fine_name = fb + "_stem1";
             if ((rc = take(wl, k, B.stem1, C[b] / 2, C[b], 2, false, EPI_STORE, "v2_flow_stem"))) return rc;
+            fine_name = fb + "_trunk";
             for (int i = 0; i < 6; i++)
                 if ((rc = take(wl, k, B.conv[i], C[b], C[b], 1, false, EPI_STORE, b == 0 ? "v2_flow_trunk_b0" : b == 1 ? "v2_flow_trunk_b1" : b == 2 ? "v2_flow_trunk_b2" : "v2_flow_trunk_b3"))) return rc;
+            fine_name = fb + "_head";
             if ((rc = take(wl, k, B.head, C[b], 4, 2, true, EPI_DECONV, "v2_flow_head"))) return rc;
         }
         if (k != wl.size()) return fail(RIFE_HIP_EMODEL, "flownet.bin has extra weighted layers");
@@ -2187,19 +2238,26 @@ static int load_v2(rife_hip* E, const std::string& dir) {
         std::vector<const NcnnLayer*> wl = mc.weighted(); size_t k = 0;
         static const int CI[10] = {3, 32, 32, 32, 32, 64, 64, 128, 128, 256}, CO[10] = {32, 32, 32, 32, 64, 64, 128, 128, 256, 256};
         static const int ST[10] = {2, 1, 2, 1, 2, 1, 2, 1, 2, 1};
-        for (int i = 0; i < 10; i++)
+        for (int i = 0; i < 10; i++) {
+            fine_name = "ctx" + std::to_string(i);
             if ((rc = take(wl, k, E->ctxc[i], CI[i], CO[i], ST[i], false, EPI_STORE, "v2_context"))) return rc;
+        }
         if (k != wl.size()) return fail(RIFE_HIP_EMODEL, "contextnet.bin has extra weighted layers");
     }
     {
         std::vector<const NcnnLayer*> wl = mu.weighted(); size_t k = 0;
         static const int CI[10] = {10, 32, 32, 64, 128, 128, 256, 256, 512, 512}, CO[10] = {32, 32, 64, 64, 128, 128, 256, 256, 512, 512};
         static const int ST[10] = {2, 1, 2, 1, 2, 1, 2, 1, 2, 1};
-        for (int i = 0; i < 10; i++)
+        for (int i = 0; i < 10; i++) {
+            fine_name = "fus" + std::to_string(i);
             if ((rc = take(wl, k, E->fus[i], CI[i], CO[i], ST[i], false, EPI_STORE, "v2_fusion_down"))) return rc;
+        }
         static const int UI[4] = {1024, 512, 256, 128}, UO[4] = {256, 128, 64, 32};
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++) {
+            fine_name = "fus" + std::to_string(10 + i);
             if ((rc = take(wl, k, E->fus[10 + i], UI[i], UO[i], 2, true, EPI_DECONV, "v2_fusion_up"))) return rc;
+        }
+        fine_name = "fus14";
         if ((rc = take(wl, k, E->fus[14], 32, 4, 2, true, EPI_DECONV_SIG, "v2_fusion_head"))) return rc;
         if (k != wl.size()) return fail(RIFE_HIP_EMODEL, "fusionnet.bin has extra weighted layers");
     }
