@@ -69,12 +69,10 @@ __global__ void k2_assemble0(IMG img0, IMG img1, float* __restrict__ X, int wp, 
 // IFNet blocks 1..3 and FusionNet input (flownet.param:27-37, 58-68, 90-99; fusionnet.param:14-23):
 //   Ff = 2*Interp(x2)(acc);  x = Interp(1/S)(Concat(warp(img0, Ff.xy), warp(img1, Ff.zw), Ff))  -> NHWC16 (10 + 6 zero)
 // FSCALE (rife-v3.x, flownet.param:44-46, 83-85): the flow channels are additionally multiplied by 1/S after the resize
-template <int S, typename IMG, bool FSCALE = false>
-__global__ void k2_assemble(IMG img0, IMG img1, const float4* __restrict__ acc, float* __restrict__ X, int wp, int hp) {
-    const int Wb = wp / S, Hb = hp / S;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= Wb || y >= Hb) return;
-    float o[10];
+// one pixel (x, y) of that block input at 1/S resolution: o[0..5] = the two warped frames, o[6..9] = the flow (shared by k2_assemble and the
+// fused stem kernel of stem_fused_v2.h, so that both run the same arithmetic)
+template <int S, typename IMG, bool FSCALE>
+__device__ __forceinline__ void assemble2_pixel(const IMG& img0, const IMG& img1, const float4* __restrict__ acc, int wp, int hp, int x, int y, float (&o)[10]) {
     if (S == 1) {
         const float4 f = flow_up2x2(acc, x, y, wp / 2, hp / 2);
         const float3 w0 = warp_img(img0, x, y, f.x, f.y, wp, hp);
@@ -99,6 +97,15 @@ __global__ void k2_assemble(IMG img0, IMG img1, const float4* __restrict__ acc, 
             for (int c = 6; c < 10; c++) o[c] = o[c] * (1.0f / (float)S);
         }
     }
+}
+
+template <int S, typename IMG, bool FSCALE = false>
+__global__ void k2_assemble(IMG img0, IMG img1, const float4* __restrict__ acc, float* __restrict__ X, int wp, int hp) {
+    const int Wb = wp / S, Hb = hp / S;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= Wb || y >= Hb) return;
+    float o[10];
+    assemble2_pixel<S, IMG, FSCALE>(img0, img1, acc, wp, hp, x, y, o);
     float4* dst = reinterpret_cast<float4*>(X + ((size_t)y * Wb + x) * 16);
     dst[0] = make_float4(o[0], o[1], o[2], o[3]);
     dst[1] = make_float4(o[4], o[5], o[6], o[7]);

@@ -24,20 +24,31 @@
 #include <thread>
 #include <vector>
 
+// Three builds of these sources (csrc/Makefile): librife_hip.so = the PRODUCT (exports include/rife_hip.h, nothing else, one schedule);
+// librife_hip_test.so (-DRIFE_HIP_TEST_BUILD) = + the parity taps / single-kernel entry points of include/rife_hip_test.h and the kernel-selection
+// switches the kernel-vs-kernel tests flip; librife_hip_bench.so (-DRIFE_HIP_BENCH_BUILD) = + csrc/bench_hooks.h.
+#if defined(RIFE_HIP_BENCH_BUILD) && !defined(RIFE_HIP_TEST_BUILD)
+#define RIFE_HIP_TEST_BUILD 1
+#endif
 #include "../../include/rife_hip.h"
-#include "../../include/rife_hip_test.h"      // the parity taps and single-kernel entry points this library also exports
+#ifdef RIFE_HIP_TEST_BUILD
+#include "../../include/rife_hip_test.h"      // the parity taps and single-kernel entry points the test build also exports
+#endif
 #include "conv_mfma.h"
 #include "conv_img.h"
 #include "elementwise.h"
 #include "elementwise_v2.h"
 #include "stem_fused.h"
+#include "stem_fused_v2.h"
 #include "stem_rs.h"
 #include "tail_rs.h"
 #include "head_h2.h"
 #include "conv_t64.h"
 #include "conv_row.h"
 #include "conv_rs.h"
-#include "conv_ks.h"
+#ifdef RIFE_HIP_TEST_BUILD
+#include "conv_ks.h"      // round-4 K-split trunk kernel: opt-in (RIFE_HIP_KS), measured slower with pairs in flight; not compiled into the product
+#endif
 #include "graph_kernels.h"
 #include "model_hashes.h"
 #include "ncnn_model.h"
@@ -49,6 +60,19 @@ namespace rife {
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return -code; }
+
+// Kernel-selection and A/B switches (RIFE_HIP_T64 / RS / KS / STEM_RS / TAIL_RS / FUSE_FLOW / ...): read only by the TEST build (librife_hip_test.so, the same sources
+// with -DRIFE_HIP_TEST_BUILD, which also exports include/rife_hip_test.h) and the bench build (librife_hip_bench.so).  The PRODUCT ignores them: it runs one schedule,
+// and the only environment variables it reads are RIFE_HIP_TRUNK=f32 (fp32 matrix path), RIFE_HIP_GRAPH=1 (hipGraph replay), RIFE_HIP_BATCH_WORKERS (process_batch
+// worker threads) and RIFE_HIP_PROFILE_FINE=1 (per-layer profile classes).
+static inline const char* ab_getenv(const char* name) {
+#ifdef RIFE_HIP_TEST_BUILD
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
@@ -332,7 +356,7 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
     // stem-1 class: split-f16 stride-2 kernel.  cin = 10 (rife-v2.x / v3.x: the first convolution of IFNet blocks 1.. and of the FusionNet, whose 10-channel
     // input is assembled as NHWC16 with six zero channels, elementwise_v2.h) rides the same kernel as one zero-padded 16-channel chunk instead of the fp32
     // matrix path (round 5: 125 -> us for the 1920x1088 -> 48-channel layer)
-    static const bool stem16 = []() { const char* e = getenv("RIFE_HIP_V2_STEM16"); return !(e && e[0] == '0'); }();
+    static const bool stem16 = []() { const char* e = ab_getenv("RIFE_HIP_V2_STEM16"); return !(e && e[0] == '0'); }();
     if (!L.deconv && L.stride == 2 && L.epi == EPI_STORE && ((L.cin % 16 == 0 && L.cin >= 16) || (L.cin == 10 && stem16))) {
         bool exact = true;
         for (size_t i = 0; i < (size_t)L.cin * L.cout * 9 && exact; i++) exact = (float)(_Float16)w_orig[i] == w_orig[i];
@@ -556,8 +580,8 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         // 4-row tiles (4 waves, three workgroups per CU) for layers whose 8-row tiles would occupy only part of the chip: twice the
         // workgroups, half the latency of each (below 400 8-row workgroups: round-1 A/B)
         constexpr int rows4_max = 400;
-        static const int ns3_rows4 = []() { const char* e = getenv("RIFE_HIP_NS3_ROWS4"); return e ? atoi(e) : 0; }();      // A/B (round 5)
-        static const int rows4_lim = []() { const char* e = getenv("RIFE_HIP_ROWS4_MAX"); return e ? atoi(e) : rows4_max; }();
+        static const int ns3_rows4 = []() { const char* e = ab_getenv("RIFE_HIP_NS3_ROWS4"); return e ? atoi(e) : 0; }();      // A/B (round 5)
+        static const int rows4_lim = []() { const char* e = ab_getenv("RIFE_HIP_ROWS4_MAX"); return e ? atoi(e) : rows4_max; }();
         const bool rows4 = g_h2b && (L.NS == 2 || L.NS == 3) && nsplit == 1 && (nb < rows4_lim || (L.NS == 3 && ns3_rows4));
         if (rows4) {
             constexpr int l4_9 = convh2b_lds_bytes<2, 9, 4>(), l4_10 = convh2b_lds_bytes<2, 10, 4>();
@@ -693,7 +717,7 @@ static int device_cus(bool physical = false) {
 // first rows of a layer's input were written more than a cache-full of traffic ago by the time they are read).
 // RIFE_HIP_T64_LW=1: the 96-channel trunk with two loader waves (conv_t64.h, template parameter LW).  Off by default: measured equal or 2 % slower
 // (4K, same call: trunk_b2 0.401 vs 0.392 - 0.396 ms per pair) - unlike in conv_rs_kernel, whose consumers also lose the weight stream and the stores
-static const bool g_t64_loader_waves = []() { const char* e = getenv("RIFE_HIP_T64_LW"); return e && e[0] == '1'; }();
+static const bool g_t64_loader_waves = []() { const char* e = ab_getenv("RIFE_HIP_T64_LW"); return e && e[0] == '1'; }();
 static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool reverse = false) {
     if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_t64 image");
     const int NS = t64_ns(L.cout);
@@ -730,7 +754,7 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
 
 // the same 64 -> 64 layer on the row-streaming kernel (conv_rs.h): one workgroup per CU, specialised waves.  descend: walk every
 // workgroup's range bottom-up; consecutive layers alternate so that a layer starts on the rows its predecessor wrote last.
-static const bool g_rs_split = []() { const char* e = getenv("RIFE_HIP_RS_SPLIT"); return e && e[0] == '1'; }();      // A/B: epilogue shared by all four io waves (conv_rs.h, SPLIT)
+static const bool g_rs_split = []() { const char* e = ab_getenv("RIFE_HIP_RS_SPLIT"); return e && e[0] == '1'; }();      // A/B: epilogue shared by all four io waves (conv_rs.h, SPLIT)
 static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool descend = false) {
     if (!L.d_t64 || L.cout != 64) return fail(RIFE_HIP_EINVAL, "layer has no 64-channel conv_t64 image");
     if ((H + 1) / 2 < RS_MIN_PAIRS) return fail(RIFE_HIP_EINVAL, "conv_rs needs at least " + std::to_string(2 * RS_MIN_PAIRS - 1) + " rows");
@@ -797,6 +821,7 @@ static int launch_row(const ConvLayer& L, const unsigned char* in, unsigned char
     return 0;
 }
 
+#ifdef RIFE_HIP_TEST_BUILD
 // the same coarse-block layers on the weight-stationary K-split kernel (conv_ks.h; round 4): C = 128 (block 1) and C = 96 (block 2).
 // RIFE_HIP_KS (create time) = bit mask: 1 = 128 channels, 2 = 96 channels where conv_row served them (small grids), 4 = 96 channels at every
 // size (instead of conv_t64), 0 = conv_row / conv_t64 as in round 3 (A/B, tests/test_gpu_ks.py).
@@ -816,7 +841,7 @@ static int launch_ks_cfg(const unsigned char* img, const KsArgs& a0, int tiles_x
     a.img = img;
     // ranges per N group: one workgroup per CU (150 KB of LDS), all resident at once also when gy pairs share the launch; a multiple of the
     // strip count where possible, so that no range crosses a strip (a crossing costs a pipeline drain and refill)
-    static const int div = []() { const char* e = getenv("RIFE_HIP_KS_DIV"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();      // A/B: part of the chip only
+    static const int div = []() { const char* e = ab_getenv("RIFE_HIP_KS_DIV"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();      // A/B: part of the chip only
     int G = std::max(1, device_cus() / (K::NG * gy * div));
     G = std::min(G, a.nunits);
     if (G >= tiles_x) G = G / tiles_x * tiles_x;
@@ -841,6 +866,12 @@ static int launch_ks(const ConvLayer& L, const unsigned char* in, unsigned char*
     if (L.cout == 96) return launch_ks_cfg<96, 3, 2>(rimg, a, G.tiles_x, gy, st);
     return fail(RIFE_HIP_EINVAL, "conv_ks serves 96 and 128 channels");
 }
+#else      // product: no conv_ks
+static inline bool ks_serves(int, int) { return false; }
+static inline int launch_ks(const ConvLayer&, const unsigned char*, unsigned char*, int, int, hipStream_t, int = 0, const unsigned char* const* = nullptr, unsigned char* const* = nullptr) {
+    return fail(RIFE_HIP_ENOSYS, "conv_ks is not part of the product build");
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // profiler (rife_hip_profile_*): HIP events on the launch stream around every kernel
@@ -1723,6 +1754,47 @@ static int conv_t(const rife_hip& E, const ConvLayer& L, TensorView x, int H, in
     return launch_conv(L, x, H, W, y, nullptr, st);
 }
 
+// stem2_fused_kernel (stem_fused_v2.h): block-input assembly at scale S (1 or 2) fused into the 10 -> cout stride-2 convolution that consumes it.
+// RIFE_HIP_V2_FUSED_STEM=0 (A/B): the unfused pair k2_assemble + conv_h2s2_kernel
+static const bool g_v2_fused_stem = []() { const char* e = ab_getenv("RIFE_HIP_V2_FUSED_STEM"); return !(e && e[0] == '0'); }();
+static bool stem2_fusable(const ConvLayer& L, int S, int wp, int hp) {
+    static const bool dbg = ab_getenv("RIFE_HIP_DEBUG_V2") != nullptr;
+    if (dbg) fprintf(stderr, "stem2_fusable: env %d trunk_h2 %d S %d d_wh %p cin %d nchunksh %d stride %d deconv %d cout %d wp %d hp %d\n", (int)g_v2_fused_stem, (int)g_trunk_h2, S,
+                     (void*)L.d_wh, L.cin, L.nchunksh, L.stride, (int)L.deconv, L.cout, wp, hp);
+    return g_v2_fused_stem && g_trunk_h2 && (S == 1 || S == 2) && L.d_wh && L.cin == 10 && L.nchunksh == 1 && L.stride == 2 && !L.deconv && L.cout <= 128 && L.cout % 4 == 0 &&
+           (wp / S) % 2 == 0 && (hp / S) % 2 == 0;
+}
+template <int S, typename IMG, bool FSCALE>
+static int launch_stem2_cfg(const Stem2Args<IMG>& a, int nwg, hipStream_t st) {
+    auto kfn = stem2_fused_kernel<S, IMG, FSCALE>;
+    {
+        static std::mutex mu; static std::map<int, bool> done;
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(mu);
+        if (!done[dev]) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, stem2_lds_bytes(4)));
+            done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), stem2_lds_bytes(a.nsub), st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("stem2_fused launch: ") + hipGetErrorString(e));
+    return 0;
+}
+template <typename IMG>
+static int launch_stem2_fused(const rife_hip& E, const ConvLayer& L, int S, bool fscale, IMG img0, IMG img1, const float4* acc, int wp, int hp, float* out, int out_ld,
+                              hipStream_t st) {
+    Stem2Args<IMG> a;
+    a.img0 = img0; a.img1 = img1; a.acc = acc; a.wpk = reinterpret_cast<const unsigned char*>(L.d_wh); a.bias = L.d_bias; a.slope = L.d_slope; a.out = out;
+    a.wp = wp; a.hp = hp; a.Ho = hp / S / 2; a.Wo = wp / S / 2; a.out_ld = out_ld; a.Cout = L.cout; a.tiles_x = (a.Wo + 31) / 32;
+    a.NS = L.NS; a.nsub = (L.cout + 31) / 32;
+    const int nwg = a.tiles_x * ((a.Ho + 3) / 4);
+    Timed t(E.prof, L.cls, L.flops_per_pixel * a.Ho * a.Wo, st);
+    if (S == 1) return launch_stem2_cfg<1, IMG, false>(a, nwg, st);
+    if (fscale) return launch_stem2_cfg<2, IMG, true>(a, nwg, st);
+    return launch_stem2_cfg<2, IMG, false>(a, nwg, st);
+}
+
 // IFNet of rife-v2.x on frames of wp x hp (flownet.param): 4 blocks at scales 8,4,2,1; the flow is accumulated at
 // half of that resolution into `acc` (float4 per pixel).
 template <typename IMG>
@@ -1733,7 +1805,10 @@ static int run_v2_ifnet(const rife_hip& E, Ctx& c, IMG img0, IMG img1, int wp, i
     for (int b = 0; b < E.n_fblk; b++) {
         const rife_hip::V2Block& B = E.fblk[b];
         const int s = B.scale, Hb = hp / s, Wb = wp / s;
-        {
+        const bool fused_stem = b > 0 && stem2_fusable(B.stem0, s, wp, hp);
+        if (fused_stem) {
+            if ((rc = launch_stem2_fused(E, B.stem0, s, E.v3 && s == 2, img0, img1, acc, wp, hp, c.S1, B.c / 2, st))) return rc;
+        } else {
             Timed t(E.prof, E.prof_fine ? "fb" + std::to_string(b) + "_assemble" : std::string("v2_assemble"), 0, st);
             dim3 g = grid2d(Wb, Hb);
             if (b == 0 && s == 8) hipLaunchKernelGGL((k2_assemble0<8, IMG>), g, dim3(256), 0, st, img0, img1, c.X, wp, hp);
@@ -1744,7 +1819,7 @@ static int run_v2_ifnet(const rife_hip& E, Ctx& c, IMG img0, IMG img1, int wp, i
             else hipLaunchKernelGGL((k2_assemble<1, IMG>), g, dim3(256), 0, st, img0, img1, acc, c.X, wp, hp);   // v3: x 1.0 (Mul_139) is the identity
             HIPCHK(hipGetLastError());
         }
-        if ((rc = conv_t(E, B.stem0, {c.X, b == 0 ? 8 : 16, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, st))) return rc;
+        if (!fused_stem && (rc = conv_t(E, B.stem0, {c.X, b == 0 ? 8 : 16, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, st))) return rc;
         if ((rc = conv_t(E, B.stem1, {c.S1, B.c / 2, 0}, Hb / 2, Wb / 2, {c.T0, B.c, 0}, st))) return rc;
         float* cur = c.T0;
         const int Ht = Hb / 4, Wt = Wb / 4;
@@ -1819,7 +1894,7 @@ static int run_v2_synth(const rife_hip& E, Ctx& c, const uint32_t* img0, const u
     const int wh = wp / 2, hh = hp / 2;
     // ---- ContextNet twice (contextnet.param): (img0, flow[0:2]) -> "3".."6", (img1, flow[2:4]) -> "7".."10",
     //      each warped level written straight into its slice of the FusionNet concat buffers ----
-    static const bool img_env = []() { const char* e = getenv("RIFE_HIP_CTX0_IMG"); return !(e && e[0] == '0'); }();      // A/B (round 5)
+    static const bool img_env = []() { const char* e = ab_getenv("RIFE_HIP_CTX0_IMG"); return !(e && e[0] == '0'); }();      // A/B (round 5)
     const bool ctx0_img = E.ctxc[0].d_wimg != nullptr && g_trunk_h2 && img_env;      // RIFE_HIP_TRUNK=f32 keeps the fp32 matrix path
     float* cat_buf[4] = {c.B1, c.B2, c.B3, c.B4};
     const int cat_ld[4] = {128, 256, 512, 1024}, cat_off[4] = {64, 128, 256, 512}, lvl_c[4] = {32, 64, 128, 256};
@@ -1863,7 +1938,8 @@ static int run_v2_synth(const rife_hip& E, Ctx& c, const uint32_t* img0, const u
         }
     }
     // ---- FusionNet (fusionnet.param) ----
-    {
+    const bool fused_f0 = stem2_fusable(E.fus[0], 1, wp, hp);
+    if (!fused_f0) {
         Timed t(E.prof, E.prof_fine ? "fus_assemble" : "v2_assemble", 0, st);
         hipLaunchKernelGGL((k2_assemble<1, ImgU8>), grid2d(wp, hp), dim3(256), 0, st, ImgU8{img0}, ImgU8{img1}, acc, c.X, wp, hp);
         HIPCHK(hipGetLastError());
@@ -1873,7 +1949,8 @@ static int run_v2_synth(const rife_hip& E, Ctx& c, const uint32_t* img0, const u
         hipLaunchKernelGGL(k2_copy_view, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, sld, soff, dst, dld, doff, C, npix);
     };
     const ConvLayer* F = E.fus;
-    if ((rc = conv_t(E, F[0], {c.X, 16, 0}, hp, wp, {c.e0a, 32, 0}, st))) return rc;
+    if (fused_f0) { if ((rc = launch_stem2_fused(E, F[0], 1, false, ImgU8{img0}, ImgU8{img1}, acc, wp, hp, c.e0a, 32, st))) return rc; }
+    else if ((rc = conv_t(E, F[0], {c.X, 16, 0}, hp, wp, {c.e0a, 32, 0}, st))) return rc;
     if ((rc = conv_t(E, F[1], {c.e0a, 32, 0}, hp / 2, wp / 2, {c.e0b, 32, 0}, st))) return rc;
     if ((rc = conv_t(E, F[2], {c.e0b, 32, 0}, hp / 2, wp / 2, {c.e0c, 64, 0}, st))) return rc;
     if ((rc = conv_t(E, F[3], {c.e0c, 64, 0}, hp / 4, wp / 4, {c.B1, 128, 0}, st))) return rc;            // s0 -> B1[0:64]
@@ -2294,13 +2371,13 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     E->num_threads = num_threads; E->v2 = rife_v2; E->v4 = rife_v4;
     E->frame_pool = std::make_shared<FramePool>();
     E->frame_pool->gpuid = gpuid;
-    { const char* e = getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
-    { const char* e = getenv("RIFE_HIP_RS"); E->rs = !(e && e[0] == '0'); }
-    { const char* e = getenv("RIFE_HIP_KS"); if (e && e[0] >= '0' && e[0] <= '9') E->ks_mask = atoi(e); }
-    { const char* e = getenv("RIFE_HIP_STEM_RS"); E->stem_rs = !(e && e[0] == '0'); }
-    { const char* e = getenv("RIFE_HIP_TTA_CONSENSUS"); E->tta_consensus = !(e && e[0] == '0'); }
-    { const char* e = getenv("RIFE_HIP_TAIL_RS"); E->tail_rs = !(e && e[0] == '0'); E->tail_rs_always = e && e[0] == '2'; }
-    { const char* e = getenv("RIFE_HIP_FUSE_FLOW"); E->fuse_flow = e && e[0] == '1'; if (E->fuse_flow) g_fuse_flow_buffers = true; }
+    { const char* e = ab_getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
+    { const char* e = ab_getenv("RIFE_HIP_RS"); E->rs = !(e && e[0] == '0'); }
+    { const char* e = ab_getenv("RIFE_HIP_KS"); if (e && e[0] >= '0' && e[0] <= '9') E->ks_mask = atoi(e); }
+    { const char* e = ab_getenv("RIFE_HIP_STEM_RS"); E->stem_rs = !(e && e[0] == '0'); }
+    { const char* e = ab_getenv("RIFE_HIP_TTA_CONSENSUS"); E->tta_consensus = !(e && e[0] == '0'); }
+    { const char* e = ab_getenv("RIFE_HIP_TAIL_RS"); E->tail_rs = !(e && e[0] == '0'); E->tail_rs_always = e && e[0] == '2'; }
+    { const char* e = ab_getenv("RIFE_HIP_FUSE_FLOW"); E->fuse_flow = e && e[0] == '1'; if (E->fuse_flow) g_fuse_flow_buffers = true; }
     return E;
 }
 
@@ -2432,7 +2509,7 @@ static int lease_ctx(const rife_hip* E, std::unique_ptr<Ctx>& c, int w, int h) {
     if (!c) {
         c.reset(new Ctx);
         // RIFE_HIP_POOL_PARTS=n (A/B; default 1): the pool's streams own 1 / n of the compute units each (CU index mod n), like rife_hip_stream_create
-        static const int parts = []() { const char* e = getenv("RIFE_HIP_POOL_PARTS"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 16 ? v : 1; }();
+        static const int parts = []() { const char* e = ab_getenv("RIFE_HIP_POOL_PARTS"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 16 ? v : 1; }();
         static std::atomic<int> next{0};
         if (parts > 1) {
             const int ncu = device_cus(true), part = next++ % parts;
@@ -2552,7 +2629,7 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     // timestep 0 / 1 copies and every other model family take the per-pair path below.
     // (only where the coarse grids leave CUs idle - block 0 on the row kernel, frames up to ~1080p: at 3840x2160 a coarse layer of ONE pair already
     // fills the chip, measured 405 - 413 frames/s in groups against 400 - 425 per pair; RIFE_HIP_BATCH_GROUPS=1 / 0 forces / forbids the path)
-    const char* genv = getenv("RIFE_HIP_BATCH_GROUPS");
+    const char* genv = ab_getenv("RIFE_HIP_BATCH_GROUPS");
     const int Ht0 = (h + 31) / 32, Wt0 = (w + 31) / 32;
     const bool small_grid = ((Wt0 + 31) / 32) * Ht0 <= device_cus(true) * 5 / 8;      // MI355X: 160 workgroups, block 0 on the row kernel (block_on_row_kernel)
     const bool groups = E->v4 && !E->v40 && !E->v1 && !E->tta && !E->tta_temporal && E->t64 && n >= 2 && (genv ? genv[0] != '0' : small_grid);
@@ -2964,6 +3041,7 @@ int rife_hip_profile_read(rife_hip_t* E, char* names, size_t names_cap, double* 
     return n;
 }
 
+#ifdef RIFE_HIP_TEST_BUILD      // ======== include/rife_hip_test.h: test and bench builds only ========
 // ---- stage tap: flow{fi} with optional injection of flow0..flow{n_inject-1} (rife.cpp:2653-2669) -------------
 int rife_hip_v4_extract_flow(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, int fi,
                              const float* const* inject, int n_inject, float* out6chw) {
@@ -3227,6 +3305,8 @@ int rife_hip_v4_process_injected(const rife_hip_t* E, const uint8_t* in0, const 
     catch (const std::exception& e) { return fail(RIFE_HIP_EINVAL, std::string("v4_process_injected: ") + e.what()); }
 }
 
+#endif  // RIFE_HIP_TEST_BUILD
+
 static int rife_hip_graph_check_impl(const char* base) {
     if (!base) return fail(RIFE_HIP_EINVAL, "null argument");
     GraphNet n;
@@ -3238,6 +3318,7 @@ int rife_hip_graph_check(const char* base) {      // nothing may throw across th
     catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_graph_check: unknown exception"); }
 }
 
+#ifdef RIFE_HIP_TEST_BUILD      // ======== include/rife_hip_test.h (continued) ========
 int rife_hip_v4_flow_dims(const rife_hip_t* E, int w, int h, int fi, int* channels, int* fh, int* fw) {
     if (!E || !E->loaded || !E->v4) return fail(RIFE_HIP_EINVAL, "flow blobs exist for a loaded rife-v4 family engine only");
     if (fi < 0 || fi > 3 || w <= 0 || h <= 0 || !channels || !fh || !fw) return fail(RIFE_HIP_EINVAL, "bad argument");
@@ -3310,6 +3391,8 @@ int rife_hip_op_warp(int gpuid, const float* image, const float* flow, int c, in
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("op_warp: ") + hipGetErrorString(e));
     return 0;
 }
+
+#endif  // RIFE_HIP_TEST_BUILD
 
 #ifdef RIFE_HIP_BENCH_BUILD
 #include "bench_hooks.h"      // bench-only / probe entry points and ablation instantiations: librife_hip_bench.so (tools/*.py), never the product

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Command line of the reference (`rife-ncnn-vulkan`, src/main.cpp:102-121, 442-917) on top of the HIP engine.
 
-    cli.py -0 in0.png -1 in1.png -o out.png [options]
-    cli.py -i indir -o outdir [options]
+    tests/cli_harness.py -0 in0.png -1 in1.png -o out.png [options]
+    tests/cli_harness.py -i indir -o outdir [options]
 
 Same flags, defaults, validation and frame/timestep schedule as the reference; the three-stage pipeline
 (load -> proc -> save, bounded queues of 8, `-j load:proc[,proc..]:save`, one RIFE replica per `-g` id,

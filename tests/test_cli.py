@@ -7,7 +7,7 @@ import pytest
 
 from conftest import ROOT
 
-cli = importlib.import_module("rife-ncnn-vulkan_amd.cli")
+import cli_harness as cli      # tests/cli_harness.py: the Python restatement of the command-line contract (the product CLI is rife-hip, csrc/main.cpp)
 
 
 def test_schedule_default_doubles_frame_count():
@@ -79,7 +79,7 @@ def test_cli_file_mode(modeldirs, tmp_path):
 
 
 # ---- the C++ command line (rife-ncnn-vulkan_amd/rife-hip, csrc/main.cpp) ----
-RIFE_HIP = os.path.join(ROOT, "rife-ncnn-vulkan_amd", "rife-hip")
+RIFE_HIP = os.environ.get("RIFE_HIP_BIN") or os.path.join(ROOT, "rife-ncnn-vulkan_amd", "rife-hip")      # RIFE_HIP_BIN: the sanitizer builds (tools/sanitize_run.sh)
 
 
 def run_cpp(args):

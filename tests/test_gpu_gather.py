@@ -23,7 +23,7 @@ from oracle import pyoracle
 from tools import gen_frames
 
 pytestmark = pytest.mark.gpu
-amd = importlib.import_module("rife-ncnn-vulkan_amd")
+amd = importlib.import_module("rife-ncnn-vulkan_amd").test_build()      # librife_hip_test.so: parity taps, single-kernel entry points and kernel-selection switches (include/rife_hip_test.h)
 
 
 @pytest.fixture(scope="module")

@@ -11,7 +11,7 @@ import pytest
 from oracle import pyoracle
 
 pytestmark = pytest.mark.gpu
-amd = importlib.import_module("rife-ncnn-vulkan_amd")
+amd = importlib.import_module("rife-ncnn-vulkan_amd").test_build()      # librife_hip_test.so: parity taps, single-kernel entry points and kernel-selection switches (include/rife_hip_test.h)
 
 
 def conv_tol(x, w):

@@ -17,7 +17,7 @@ from tools import gen_frames
 from test_gpu_gather import injected_flows
 
 pytestmark = pytest.mark.gpu
-amd = importlib.import_module("rife-ncnn-vulkan_amd")
+amd = importlib.import_module("rife-ncnn-vulkan_amd").test_build()      # librife_hip_test.so: parity taps, single-kernel entry points and kernel-selection switches (include/rife_hip_test.h)
 
 
 def _engine(d, on):

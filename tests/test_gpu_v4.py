@@ -12,6 +12,7 @@ from tools import gen_frames
 
 pytestmark = pytest.mark.gpu
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
+amd_t = amd.test_build()      # librife_hip_test.so: the same sources + the parity taps and kernel-selection switches (include/rife_hip_test.h)
 
 
 @pytest.fixture(scope="module")
@@ -25,6 +26,18 @@ def engines(modeldirs):
     return g, o
 
 
+@pytest.fixture(scope="module")
+def tap_engines(modeldirs):
+    """The test build of the engine (stage taps, RIFE_HIP_* switches) next to the oracle; the frame-parity tests below run the PRODUCT library."""
+    d = modeldirs["rife-v4.6"]
+    g = amd_t.RIFE(0, rife_v4=True)
+    g.load(d)
+    o = pyoracle.OracleRIFE(rife_v4=True)
+    o.set_gpu_crop(1)
+    o.load(d)
+    return g, o
+
+
 def lsb_report(a, b):
     d = np.abs(a.astype(np.int32) - b.astype(np.int32))
     mse = float((d.astype(np.float64) ** 2).mean())
@@ -33,8 +46,8 @@ def lsb_report(a, b):
 
 
 @pytest.mark.parametrize("w,h", [(64, 64), (160, 96)])
-def test_stage_flows_match_oracle(engines, w, h):
-    g, o = engines
+def test_stage_flows_match_oracle(tap_engines, w, h):
+    g, o = tap_engines
     a, b = gen_frames.smooth_pair(w, h, 21)
     for fi in range(4):
         got = g.v4_extract_flow(a, b, 0.5, fi)
@@ -43,9 +56,9 @@ def test_stage_flows_match_oracle(engines, w, h):
         assert np.abs(got - want).max() < 1e-3, fi
 
 
-def test_flow_injection_matches_oracle(engines):
+def test_flow_injection_matches_oracle(tap_engines):
     """The Extractor inject/extract contract TTA relies on (rife.cpp:2653-2669)."""
-    g, o = engines
+    g, o = tap_engines
     a, b = gen_frames.smooth_pair(96, 64, 22)
     rng = np.random.default_rng(1)
     inj = [(rng.standard_normal((6, 64 // s, 96 // s)) * 0.3).astype(np.float32) for s in (8, 4, 2)]
@@ -189,12 +202,13 @@ def test_process_batch_equals_single_calls(engines):
 
 
 @pytest.mark.parametrize("w,h,n", [(160, 96, 9), (640, 360, 7), (1920, 1080, 6)])
-def test_process_batch_lockstep_groups_equal_single_calls(engines, w, h, n):
+def test_process_batch_lockstep_groups_equal_single_calls(engines, tap_engines, w, h, n):
     """The lockstep-group path of rife_hip_process_batch (pairs of pairs; the coarse blocks' trunk layers are one launch for both, gridDim.y = 2;
     SURVEY 8f-2) against n single calls: identical bytes, with shared frames (a sequence), an odd pair left over and timestep 0 / 1 copies in the mix,
     and against the per-pair path of the same call (RIFE_HIP_BATCH_GROUPS=0)."""
     import os
     g, _ = engines
+    gt, _ = tap_engines      # RIFE_HIP_BATCH_GROUPS is a switch of the test build
     frames = [gen_frames.smooth_pair(w, h, 500 + i)[i & 1] for i in range(n + 1)]
     ts = [(0.5, 0.25, 0.0, 0.7, 1.0, 0.125, 0.9, 0.3, 0.6)[i % 9] for i in range(n)]
     want = [g.process(frames[i], frames[i + 1], ts[i]) for i in range(n)]
@@ -203,7 +217,7 @@ def test_process_batch_lockstep_groups_equal_single_calls(engines, w, h, n):
         assert np.array_equal(got[i], want[i]), (i, ts[i])
     os.environ["RIFE_HIP_BATCH_GROUPS"] = "0"
     try:
-        got0 = g.process_batch(frames[:n], frames[1:n + 1], ts)
+        got0 = gt.process_batch(frames[:n], frames[1:n + 1], ts)
     finally:
         del os.environ["RIFE_HIP_BATCH_GROUPS"]
     for i in range(n):
@@ -241,7 +255,7 @@ def test_device_frames_at_odd_addresses_equal_aligned_ones(engines):
         assert np.array_equal(o, want)
 
 
-def test_4k_pass_is_run_to_run_stable(engines):
+def test_4k_pass_is_run_to_run_stable(engines, tap_engines):
     """The same 3840x2160 pair four times through one engine: identical frames and identical block-1 / block-3 flows (the first stages that
     go through the fused stem kernels and the fused tail)."""
     g, _ = engines
@@ -249,8 +263,9 @@ def test_4k_pass_is_run_to_run_stable(engines):
     outs = [g.process(a, b, 0.5) for _ in range(4)]
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
+    gt, _ = tap_engines
     for fi in (1, 3):
-        fl = [g.v4_extract_flow(a, b, 0.5, fi) for _ in range(3)]
+        fl = [gt.v4_extract_flow(a, b, 0.5, fi) for _ in range(3)]
         for f in fl[1:]:
             assert np.array_equal(f, fl[0]), fi
 
@@ -262,9 +277,9 @@ def test_fused_tta_consensus_is_bit_identical_to_the_two_kernels(modeldirs, w, h
     Reference src/rife.cpp:3477-3512, 3515-3821."""
     a, b = gen_frames.smooth_pair(w, h, 77)
     monkeypatch.setenv("RIFE_HIP_TTA_CONSENSUS", "0")
-    g0 = amd.RIFE(0, tta_mode=True, tta_temporal_mode=True, rife_v4=True); g0.load(modeldirs["rife-v4.6"])
+    g0 = amd_t.RIFE(0, tta_mode=True, tta_temporal_mode=True, rife_v4=True); g0.load(modeldirs["rife-v4.6"])
     monkeypatch.delenv("RIFE_HIP_TTA_CONSENSUS")
-    g1 = amd.RIFE(0, tta_mode=True, tta_temporal_mode=True, rife_v4=True); g1.load(modeldirs["rife-v4.6"])
+    g1 = amd.RIFE(0, tta_mode=True, tta_temporal_mode=True, rife_v4=True); g1.load(modeldirs["rife-v4.6"])      # the product (fused consensus)
     for t in (0.5, 0.3):
         x0, x1 = g0.process(a, b, t), g1.process(a, b, t)
         assert np.array_equal(x0, x1), "%d bytes differ" % int((x0 != x1).sum())

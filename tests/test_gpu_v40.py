@@ -10,6 +10,7 @@ from tools import gen_frames
 
 pytestmark = pytest.mark.gpu
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
+amd_t = amd.test_build()      # stage taps live in the test build (include/rife_hip_test.h)
 
 
 @pytest.fixture(scope="module")
@@ -20,14 +21,22 @@ def engines(modeldirs):
     return g, o
 
 
+@pytest.fixture(scope="module")
+def tap_engines(modeldirs):
+    d = modeldirs["rife-v4"]
+    g = amd_t.RIFE(0, rife_v4=True); g.load(d)
+    o = pyoracle.OracleRIFE(rife_v4=True); o.set_gpu_crop(1); o.load(d)
+    return g, o
+
+
 def report(a, b):
     d = np.abs(a.astype(np.int32) - b.astype(np.int32))
     return int(d.max()), float((d == 0).mean())
 
 
 @pytest.mark.parametrize("w,h", [(64, 64), (160, 96)])
-def test_v40_stage_flows_match_oracle(engines, w, h):
-    g, o = engines
+def test_v40_stage_flows_match_oracle(tap_engines, w, h):
+    g, o = tap_engines
     a, b = gen_frames.smooth_pair(w, h, 41)
     for fi in range(4):
         got = g.v4_extract_flow(a, b, 0.5, fi)
@@ -36,8 +45,8 @@ def test_v40_stage_flows_match_oracle(engines, w, h):
         assert np.abs(got - want).max() < 1e-3, fi
 
 
-def test_v40_flow_injection_matches_oracle(engines):
-    g, o = engines
+def test_v40_flow_injection_matches_oracle(tap_engines):
+    g, o = tap_engines
     a, b = gen_frames.smooth_pair(96, 64, 42)
     rng = np.random.default_rng(2)
     inj = [(rng.standard_normal((5, 64 // s, 96 // s)) * 0.3).astype(np.float32) for s in (16, 8, 4)]

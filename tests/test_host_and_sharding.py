@@ -15,21 +15,56 @@ from conftest import REFERENCE, ROOT
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
 
 
-def test_c_abi_exports_every_declared_symbol():
-    # the product header and the test-surface header (stage taps, single-kernel entry points) together declare everything the library exports
+def _exports(path):
+    nm = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(set(re.findall(r"\b(rife_hip_[A-Za-z0-9_]+)$", nm, flags=re.M)))
+
+
+def test_product_library_exports_exactly_the_product_header():
+    """librife_hip.so == include/rife_hip.h, both directions: no parity tap, single-kernel entry point, bench / probe / ablation hook rides in the product."""
     hdr = open(os.path.join(ROOT, "include", "rife_hip.h")).read()
-    test_hdr = open(os.path.join(ROOT, "include", "rife_hip_test.h")).read()
-    assert "rife_hip_test.h" not in hdr and not re.search(r"rife_hip_(op_|v4_tap|v4_process_injected|v4_extract_flow)", hdr)
-    declared = sorted(set(re.findall(r"\b(rife_hip_[a-z0-9_]+)\s*\(", hdr + test_hdr)))
+    assert "rife_hip_test.h" not in hdr and not re.search(r"rife_hip_(op_|v4_)", hdr)
+    declared = sorted(set(re.findall(r"\b(rife_hip_[a-z0-9_]+)\s*\(", hdr)))
     assert declared == sorted(amd.C_ABI_SYMBOLS)
-    L = ctypes.CDLL(amd.LIB_PATH)
+    product = os.path.join(ROOT, "rife-ncnn-vulkan_amd", "librife_hip.so")
+    L = ctypes.CDLL(product)
     for s in declared:
         assert hasattr(L, s), s
-    # ... and nothing else: no bench / probe / ablation entry point may ride in the product library
-    nm = subprocess.run(["nm", "-D", "--defined-only", amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = sorted(set(re.findall(r"\b(rife_hip_[A-Za-z0-9_]+)$", nm, flags=re.M)))
+    exported = _exports(product)
     assert exported == declared, sorted(set(exported) ^ set(declared))
     assert "bench" not in " ".join(exported) and "probe" not in " ".join(exported)
+
+
+def test_test_build_exports_exactly_both_headers():
+    """librife_hip_test.so (same sources, -DRIFE_HIP_TEST_BUILD) == include/rife_hip.h + include/rife_hip_test.h."""
+    hdr = open(os.path.join(ROOT, "include", "rife_hip.h")).read()
+    test_hdr = open(os.path.join(ROOT, "include", "rife_hip_test.h")).read()
+    only_test = sorted(set(re.findall(r"\b(rife_hip_[a-z0-9_]+)\s*\(", test_hdr)))
+    assert only_test == sorted(amd.TEST_ABI_SYMBOLS)
+    declared = sorted(set(re.findall(r"\b(rife_hip_[a-z0-9_]+)\s*\(", hdr + test_hdr)))
+    exported = _exports(amd.TEST_LIB_PATH)
+    assert exported == declared, sorted(set(exported) ^ set(declared))
+
+
+def test_product_ignores_the_kernel_selection_switches():
+    """The A/B and kernel-selection environment switches are compiled out of the product: every getenv of the library sources outside ab_getenv() (which
+    returns null unless RIFE_HIP_TEST_BUILD is defined) names one of the four documented product variables, and the product binary holds neither the
+    long switch names nor the opt-in K-split kernel."""
+    csrc = os.path.join(ROOT, "rife-ncnn-vulkan_amd", "csrc")
+    allowed = {"RIFE_HIP_TRUNK", "RIFE_HIP_GRAPH", "RIFE_HIP_BATCH_WORKERS", "RIFE_HIP_PROFILE_FINE"}
+    for f in os.listdir(csrc):
+        if not f.endswith((".h", ".hip")) or f in ("bench_hooks.h", "jpeg_codec.h", "ncnn_mat.h", "rife.h"):      # bench_hooks.h: bench build only; the others belong to the shim / CLI
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        for m in re.finditer(r"(?<![A-Za-z_])getenv\(\s*\"?([A-Za-z0-9_]*)", src):
+            if m.group(1) == "name" and "ab_getenv" in src[max(0, m.start() - 400):m.start()]:
+                continue                                  # the body of ab_getenv itself, under #ifdef RIFE_HIP_TEST_BUILD
+            assert m.group(1) in allowed, (f, m.group(0))
+    blob = open(os.path.join(ROOT, "rife-ncnn-vulkan_amd", "librife_hip.so"), "rb").read()
+    for name in (b"RIFE_HIP_FUSE_FLOW", b"RIFE_HIP_POOL_PARTS", b"RIFE_HIP_BATCH_GROUPS", b"RIFE_HIP_TTA_CONSENSUS", b"RIFE_HIP_V2_FUSED_STEM", b"conv_ks_kernel"):
+        assert name not in blob, name
+    test_blob = open(amd.TEST_LIB_PATH, "rb").read()
+    assert b"RIFE_HIP_FUSE_FLOW" in test_blob and b"conv_ks_kernel" in test_blob
 
 
 def test_no_cpu_fallback_without_a_device():
@@ -38,6 +73,8 @@ def test_no_cpu_fallback_without_a_device():
         pytest.skip("a GPU is present")
     with pytest.raises(amd.RifeError):
         amd.RIFE(0, rife_v4=True)
+    with pytest.raises(amd.RifeError):
+        amd.test_build().RIFE(0, rife_v4=True)
     with pytest.raises(amd.RifeError):
         amd.op_warp(np.zeros((3, 4, 4), np.float32), np.zeros((2, 4, 4), np.float32))
 

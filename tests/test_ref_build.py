@@ -112,3 +112,30 @@ def test_real_contextnet_families_bit_identical(fam):
     g = gen_models.GRAPH_FAMILY[fam]
     r, o = both(g, gen_models.ensure_realctx(fam))
     assert np.array_equal(r.process(a, b, 0.5), o.process(a, b, 0.5))
+
+
+def test_uhd_on_a_half_size_that_is_not_a_multiple_of_32_breaks_the_reference_itself(modeldirs):
+    """`-u` where the padded frame's half size is not a multiple of 32 (96 x 64 -> 48 x 32; 1280 x 720 -> 640 x 368 is the same case): the HIP engine
+    refuses these with RIFE_HIP_EINVAL (tests/test_gpu_v2.py::test_v23_uhd_rejects_unsupported_size).  This is NOT an input the reference handles: its own
+    compiled src/rife.cpp (process_cpu, 1256-1290 / GPU twin 928-945) feeds the IFNet a 48 x 32 frame, and with ncnn's shape rules (Interp: int(w * scale);
+    Convolution 3 x 3 s2 p1: (w - 1) / 2 + 1; Deconvolution 4 x 4 s2 p1: 2 w; models/rife-v2.3/flownet.param:7-27) block 0 runs 48 x 32 -> Interp 1/8: 6 x 4 ->
+    3 x 2 -> 2 x 1 -> Deconvolution: 4 x 2 -> Interp x8: 32 x 16 -> Interp x2: 64 x 32, against warped frames of 48 x 32 (the chain only round-trips when
+    the IFNet input is a multiple of 32), so
+    Concat_57 (flownet.param:35) receives blobs of different sizes.  ncnn's Concat does not check: its CPU kernel copies each bottom blob's whole cstep *
+    channels floats into a top blob sized for the first one (a heap overflow of 2,048 floats here), the Vulkan shader reads the larger blob on the smaller
+    grid (misaligned garbage).  The reference build on the shape-checking look-alike fails the extraction, src/rife.cpp ignores the return value
+    (`ex.extract("flow", flow)`) and walks an empty Mat: it does not survive.  Run in a child process because of that."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from oracle import pyref\n"
+        "from tools import gen_frames\n"
+        "r = pyref.RefRIFE(num_threads=2, uhd_mode=True, rife_v2=True); r.load(%r)\n"
+        "a, b = gen_frames.smooth_pair(96, 64, 3)\n"
+        "out = r.process(a, b, 0.5)\n"
+        "print('SURVIVED', out.shape)\n") % (__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), modeldirs["rife-v2.3"])
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "Concat" in p.stderr and "64x32 vs 48x32" in p.stderr, p.stderr[-400:]          # the mis-sized blobs of flownet.param:35
+    assert p.returncode != 0 and "SURVIVED" not in p.stdout, (p.returncode, p.stdout[-200:])
+    # ... while a size whose half IS a multiple of 32 goes through the same code bit-identically (test_uhd_mode_bit_identical above: 128 x 64)
