@@ -65,6 +65,15 @@ static int fail(int code, const std::string& msg) { g_err = msg; return -code; }
 // with -DRIFE_HIP_TEST_BUILD, which also exports include/rife_hip_test.h) and the bench build (librife_hip_bench.so).  The PRODUCT ignores them: it runs one schedule,
 // and the only environment variables it reads are RIFE_HIP_TRUNK=f32 (fp32 matrix path), RIFE_HIP_GRAPH=1 (hipGraph replay), RIFE_HIP_BATCH_WORKERS (process_batch
 // worker threads) and RIFE_HIP_PROFILE_FINE=1 (per-layer profile classes).
+// Values of the switches are parsed by these NAMED helpers, never by immediately-invoked lambdas in static initialisers.  Round 5 found why: hipcc numbers the
+// closure types of namespace-scope lambdas per `namespace rife { }` block, and this file re-opens the namespace four times, so the initialiser lambda of
+// g_use_graph (first of its block) carried the mangled name of g_trunk_h2's (first of the first block) and the linker-visible internal symbol of the one was
+// the code of the other: _GLOBAL__sub_I_engine.hip read RIFE_HIP_TRUNK into g_use_graph (hipGraph replay silently ON for every plain v4 pass <= 1080p since the
+// second block appeared, RIFE_HIP_GRAPH itself never read) and RIFE_HIP_T64_LW into g_v2_fused_stem (objdump of the static initialiser; profiles/r5/README.md).
+static inline bool env_on(const char* e) { return e && e[0] == '1'; }               // default off, "=1" switches on
+static inline bool env_not_off(const char* e) { return !(e && e[0] == '0'); }       // default on, "=0" switches off
+static inline bool env_is(const char* e, const char* value) { return e && std::strcmp(e, value) == 0; }
+static inline int env_int(const char* e, int dflt, int lo, int hi) { if (!e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
 static inline const char* ab_getenv(const char* name) {
 #ifdef RIFE_HIP_TEST_BUILD
     return getenv(name);
@@ -356,7 +365,7 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
     // stem-1 class: split-f16 stride-2 kernel.  cin = 10 (rife-v2.x / v3.x: the first convolution of IFNet blocks 1.. and of the FusionNet, whose 10-channel
     // input is assembled as NHWC16 with six zero channels, elementwise_v2.h) rides the same kernel as one zero-padded 16-channel chunk instead of the fp32
     // matrix path (round 5: 125 -> us for the 1920x1088 -> 48-channel layer)
-    static const bool stem16 = []() { const char* e = ab_getenv("RIFE_HIP_V2_STEM16"); return !(e && e[0] == '0'); }();
+    static const bool stem16 = env_not_off(ab_getenv("RIFE_HIP_V2_STEM16"));
     if (!L.deconv && L.stride == 2 && L.epi == EPI_STORE && ((L.cin % 16 == 0 && L.cin >= 16) || (L.cin == 10 && stem16))) {
         bool exact = true;
         for (size_t i = 0; i < (size_t)L.cin * L.cout * 9 && exact; i++) exact = (float)(_Float16)w_orig[i] == w_orig[i];
@@ -435,7 +444,7 @@ static float* splitk_workspace(hipStream_t st, size_t floats) {
 // numerics fallback, and bench.py's fp32 reference mode.  The round-1 A/B switches with a settled winner (fused stem, split-f16
 // heads and stride-2 stems, split-K for tiny grids, fused tail, two-workgroup trunk kernel, 8-wave fp32 kernel, 96-wide N tiles,
 // 4-row tiles below 400 workgroups) are constants now; the measurements behind them are in DESIGN.md and profiles/r1.
-static const bool g_trunk_h2 = []() { const char* e = getenv("RIFE_HIP_TRUNK"); return !(e && std::strcmp(e, "f32") == 0); }();
+static const bool g_trunk_h2 = !env_is(getenv("RIFE_HIP_TRUNK"), "f32");
 static constexpr bool g_fuse_stem = true, g_head_h2 = true, g_s2_h2 = true, g_splitk = true, g_fuse_tail = true, g_h2b = true, g_use_conv8 = true;
 
 // x: NHWC input (H x W), y: output; for deconv layers y has 2H x 2W pixels (or the 4H x 4W flow tensor with EPI_DECONV_PS).
@@ -580,8 +589,8 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         // 4-row tiles (4 waves, three workgroups per CU) for layers whose 8-row tiles would occupy only part of the chip: twice the
         // workgroups, half the latency of each (below 400 8-row workgroups: round-1 A/B)
         constexpr int rows4_max = 400;
-        static const int ns3_rows4 = []() { const char* e = ab_getenv("RIFE_HIP_NS3_ROWS4"); return e ? atoi(e) : 0; }();      // A/B (round 5)
-        static const int rows4_lim = []() { const char* e = ab_getenv("RIFE_HIP_ROWS4_MAX"); return e ? atoi(e) : rows4_max; }();
+        static const int ns3_rows4 = env_int(ab_getenv("RIFE_HIP_NS3_ROWS4"), 0, INT_MIN, INT_MAX);      // A/B (round 5)
+        static const int rows4_lim = env_int(ab_getenv("RIFE_HIP_ROWS4_MAX"), rows4_max, INT_MIN, INT_MAX);
         const bool rows4 = g_h2b && (L.NS == 2 || L.NS == 3) && nsplit == 1 && (nb < rows4_lim || (L.NS == 3 && ns3_rows4));
         if (rows4) {
             constexpr int l4_9 = convh2b_lds_bytes<2, 9, 4>(), l4_10 = convh2b_lds_bytes<2, 10, 4>();
@@ -717,7 +726,7 @@ static int device_cus(bool physical = false) {
 // first rows of a layer's input were written more than a cache-full of traffic ago by the time they are read).
 // RIFE_HIP_T64_LW=1: the 96-channel trunk with two loader waves (conv_t64.h, template parameter LW).  Off by default: measured equal or 2 % slower
 // (4K, same call: trunk_b2 0.401 vs 0.392 - 0.396 ms per pair) - unlike in conv_rs_kernel, whose consumers also lose the weight stream and the stores
-static const bool g_t64_loader_waves = []() { const char* e = ab_getenv("RIFE_HIP_T64_LW"); return e && e[0] == '1'; }();
+static const bool g_t64_loader_waves = env_on(ab_getenv("RIFE_HIP_T64_LW"));
 static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool reverse = false) {
     if (!L.d_t64) return fail(RIFE_HIP_EINVAL, "layer has no conv_t64 image");
     const int NS = t64_ns(L.cout);
@@ -754,7 +763,7 @@ static int launch_t64(const ConvLayer& L, const unsigned char* in, unsigned char
 
 // the same 64 -> 64 layer on the row-streaming kernel (conv_rs.h): one workgroup per CU, specialised waves.  descend: walk every
 // workgroup's range bottom-up; consecutive layers alternate so that a layer starts on the rows its predecessor wrote last.
-static const bool g_rs_split = []() { const char* e = ab_getenv("RIFE_HIP_RS_SPLIT"); return e && e[0] == '1'; }();      // A/B: epilogue shared by all four io waves (conv_rs.h, SPLIT)
+static const bool g_rs_split = env_on(ab_getenv("RIFE_HIP_RS_SPLIT"));      // A/B: epilogue shared by all four io waves (conv_rs.h, SPLIT)
 static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool descend = false) {
     if (!L.d_t64 || L.cout != 64) return fail(RIFE_HIP_EINVAL, "layer has no 64-channel conv_t64 image");
     if ((H + 1) / 2 < RS_MIN_PAIRS) return fail(RIFE_HIP_EINVAL, "conv_rs needs at least " + std::to_string(2 * RS_MIN_PAIRS - 1) + " rows");
@@ -841,7 +850,7 @@ static int launch_ks_cfg(const unsigned char* img, const KsArgs& a0, int tiles_x
     a.img = img;
     // ranges per N group: one workgroup per CU (150 KB of LDS), all resident at once also when gy pairs share the launch; a multiple of the
     // strip count where possible, so that no range crosses a strip (a crossing costs a pipeline drain and refill)
-    static const int div = []() { const char* e = ab_getenv("RIFE_HIP_KS_DIV"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();      // A/B: part of the chip only
+    static const int div = env_int(ab_getenv("RIFE_HIP_KS_DIV"), 1, 1, 8);      // A/B: part of the chip only
     int G = std::max(1, device_cus() / (K::NG * gy * div));
     G = std::min(G, a.nunits);
     if (G >= tiles_x) G = G / tiles_x * tiles_x;
@@ -1556,7 +1565,7 @@ static int run_v4_group(const rife_hip& E, Ctx* const* cs, int G, const uint8_t*
 // (tools/graph_bench.py, profiler off): 1080p 1.116 vs 1.119 ms per pair, 720p 0.782 vs 0.782, 360p 0.673 vs 0.674 - no gain: the
 // chain of ~50 dependent kernels (fill / drain of each launch), not host launch overhead, sets the floor, and a replayed graph
 // executes the same chain.  Kept off by default; the profiler (events around every launch) bypasses it.
-static const bool g_use_graph = []() { const char* e = getenv("RIFE_HIP_GRAPH"); return e && e[0] == '1'; }();
+static const bool g_use_graph = env_on(getenv("RIFE_HIP_GRAPH"));
 
 static int run_v4_replay(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t* d_in1, float timestep, uint8_t* d_out) {
     const bool eligible = g_use_graph && !E.prof.on && c.d_ts && (size_t)c.wp * c.hp <= (size_t)1920 * 1088;
@@ -1756,7 +1765,7 @@ static int conv_t(const rife_hip& E, const ConvLayer& L, TensorView x, int H, in
 
 // stem2_fused_kernel (stem_fused_v2.h): block-input assembly at scale S (1 or 2) fused into the 10 -> cout stride-2 convolution that consumes it.
 // RIFE_HIP_V2_FUSED_STEM=0 (A/B): the unfused pair k2_assemble + conv_h2s2_kernel
-static const bool g_v2_fused_stem = []() { const char* e = ab_getenv("RIFE_HIP_V2_FUSED_STEM"); return !(e && e[0] == '0'); }();
+static const bool g_v2_fused_stem = env_not_off(ab_getenv("RIFE_HIP_V2_FUSED_STEM"));
 static bool stem2_fusable(const ConvLayer& L, int S, int wp, int hp) {
     static const bool dbg = ab_getenv("RIFE_HIP_DEBUG_V2") != nullptr;
     if (dbg) fprintf(stderr, "stem2_fusable: env %d trunk_h2 %d S %d d_wh %p cin %d nchunksh %d stride %d deconv %d cout %d wp %d hp %d\n", (int)g_v2_fused_stem, (int)g_trunk_h2, S,
@@ -1894,7 +1903,7 @@ static int run_v2_synth(const rife_hip& E, Ctx& c, const uint32_t* img0, const u
     const int wh = wp / 2, hh = hp / 2;
     // ---- ContextNet twice (contextnet.param): (img0, flow[0:2]) -> "3".."6", (img1, flow[2:4]) -> "7".."10",
     //      each warped level written straight into its slice of the FusionNet concat buffers ----
-    static const bool img_env = []() { const char* e = ab_getenv("RIFE_HIP_CTX0_IMG"); return !(e && e[0] == '0'); }();      // A/B (round 5)
+    static const bool img_env = env_not_off(ab_getenv("RIFE_HIP_CTX0_IMG"));      // A/B (round 5)
     const bool ctx0_img = E.ctxc[0].d_wimg != nullptr && g_trunk_h2 && img_env;      // RIFE_HIP_TRUNK=f32 keeps the fp32 matrix path
     float* cat_buf[4] = {c.B1, c.B2, c.B3, c.B4};
     const int cat_ld[4] = {128, 256, 512, 1024}, cat_off[4] = {64, 128, 256, 512}, lvl_c[4] = {32, 64, 128, 256};
@@ -2271,7 +2280,7 @@ static int load_v2(rife_hip* E, const std::string& dir) {
     int rc;
     // RIFE_HIP_PROFILE_FINE=1: one profile class per layer position (fb<b>_stem0 / _stem1 / _trunk / _head, ctx<i>, fus<i>) instead of the coarse classes
     // bench.py reports - what tools/part_profile.py reads on a CU-masked stream, where rocprofv3 cannot follow (its queue interception drops the mask)
-    const bool fine = []() { const char* e = getenv("RIFE_HIP_PROFILE_FINE"); return e && e[0] == '1'; }();
+    const bool fine = env_on(getenv("RIFE_HIP_PROFILE_FINE"));
     E->prof_fine = fine;
     std::string fine_name;
     auto take = [&](std::vector<const NcnnLayer*>& wl, size_t& k, ConvLayer& L, int cin, int cout, int stride, bool deconv, int epi, const char* cls0) -> int {
@@ -2509,7 +2518,7 @@ static int lease_ctx(const rife_hip* E, std::unique_ptr<Ctx>& c, int w, int h) {
     if (!c) {
         c.reset(new Ctx);
         // RIFE_HIP_POOL_PARTS=n (A/B; default 1): the pool's streams own 1 / n of the compute units each (CU index mod n), like rife_hip_stream_create
-        static const int parts = []() { const char* e = ab_getenv("RIFE_HIP_POOL_PARTS"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 16 ? v : 1; }();
+        static const int parts = env_int(ab_getenv("RIFE_HIP_POOL_PARTS"), 1, 1, 16);
         static std::atomic<int> next{0};
         if (parts > 1) {
             const int ncu = device_cus(true), part = next++ % parts;
@@ -2595,7 +2604,7 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     if ((rc = check_device(E->gpuid))) return rc;
     // three workers = three pairs in flight: tools/host_path_bench2.py, 4K, 48 pairs: process() from 1 / 2 / 3 / 4 caller threads
     // 192 / 341 / 389 / 365 frames/s from pageable frames (resident frames: 395), 244 / 307 / 349 / 344 from page-locked ones
-    static const int batch_workers = []() { const char* e = getenv("RIFE_HIP_BATCH_WORKERS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? v : 0; }();      // A/B
+    static const int batch_workers = env_int(getenv("RIFE_HIP_BATCH_WORKERS"), 0, 1, 16);      // A/B
     const int K = std::min(n, batch_workers ? batch_workers : 4);      // round 4: four workers (measured against 3 / 5 / 6 / 8: 4K 439 vs 426 / 426 / 431 / 446, 1080p 1,334 vs 1,251 / 1,367 / 1,443 / 1,398 pageable; page-locked best at 4)
     // A host frame that serves several pairs of the batch (consecutive pairs of a sequence share one) crosses PCIe once: it becomes a
     // resident frame on first use and is released after its last (stream mode, below).  Batches without shared frames run as before.

@@ -661,10 +661,15 @@ int main(int argc, char** argv) {
             toproc.put(std::move(t));
         }
     };
+    std::vector<std::atomic<int>> replica_tasks(rife.size());               // tasks every replica took off the shared queue (timing line; tests/test_cli.py)
+    for (auto& n : replica_tasks) n = 0;
     auto proc = [&](RIFE* r) {
+        size_t me = 0;
+        while (me < rife.size() && rife[me] != r) me++;
         for (;;) {
             Task t = toproc.get();
             if (t.id == -233) return;                                          // end marker, like the reference
+            replica_tasks[me]++;
             if (t.timestep == 0.f || t.timestep == 1.f) t.out = (t.timestep == 0.f ? t.fr0 : t.fr1)->px;      // rife.cpp:2470-2480: an input frame, unchanged
             else {
                 const rife_hip_frame* d0 = t.fr0->on(r);
@@ -699,6 +704,7 @@ int main(int argc, char** argv) {
         const auto tp2 = std::chrono::steady_clock::now();
         const double a = std::chrono::duration<double>(tp1 - tp0).count(), b = std::chrono::duration<double>(tp2 - tp1).count();
         fprintf(stderr, "timing: devices + model load %.3f s, pipeline %.3f s for %zu frames = %.1f frames/s\n", a, b, tasks.size(), tasks.size() / b);
+        for (size_t d = 0; d < rife.size(); d++) fprintf(stderr, "timing: replica %zu (gpu %d) took %d task(s)\n", d, gpuid[d], replica_tasks[d].load());
     }
     cache.clear();                                                             // resident frames go before their engines
     for (RIFE* r : rife) delete r;

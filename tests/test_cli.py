@@ -145,18 +145,25 @@ def test_cpp_cli_two_replicas_on_one_device_equal_one(modeldirs, tmp_path):
         Image.fromarray(gen_frames.smooth_pair(160, 96, 20 + i)[0]).save(ind / ("%03d.png" % i))
     model = modeldirs["rife-v4.6"]
     outs = {}
-    for name, extra in (("one", ["-g", "0", "-j", "1:2:2"]), ("two", ["-g", "0,0", "-j", "1:2,2:2"])):
-        outd = tmp_path / name; outd.mkdir()
-        rc, err = run_cpp(["-i", str(ind), "-o", str(outd), "-m", model, "-n", "13"] + extra)
-        assert rc == 0, err
-        outs[name] = outd
+    import re
+    os.environ["RIFE_HIP_CLI_TIMING"] = "1"                    # the summary lines on stderr carry the number of tasks every replica took
+    try:
+        for name, extra in (("one", ["-g", "0", "-j", "1:2:2"]), ("two", ["-g", "0,0", "-j", "1:2,2:2"])):
+            outd = tmp_path / name; outd.mkdir()
+            rc, err = run_cpp(["-i", str(ind), "-o", str(outd), "-m", model, "-n", "29"] + extra)
+            assert rc == 0, err
+            outs[name] = outd
+            took = [int(x) for x in re.findall(r"timing: replica \d+ \(gpu 0\) took (\d+) task", err)]
+            assert len(took) == (2 if name == "two" else 1) and sum(took) == 29 and min(took) >= 1, err      # both replicas worked (src/main.cpp:849-866)
+    finally:
+        del os.environ["RIFE_HIP_CLI_TIMING"]
     names = sorted(os.listdir(outs["one"]))
-    assert names == ["%08d.png" % i for i in range(1, 14)] and sorted(os.listdir(outs["two"])) == names
+    assert names == ["%08d.png" % i for i in range(1, 30)] and sorted(os.listdir(outs["two"])) == names
     for n in names:
         a = np.asarray(Image.open(outs["one"] / n).convert("RGB")); b = np.asarray(Image.open(outs["two"] / n).convert("RGB"))
         assert np.array_equal(a, b), n
     outp = tmp_path / "py"; outp.mkdir()
-    assert cli.main(["-i", str(ind), "-o", str(outp), "-m", model, "-n", "13", "-g", "0,0", "-j", "1:2,2:2"]) == 0
+    assert cli.main(["-i", str(ind), "-o", str(outp), "-m", model, "-n", "29", "-g", "0,0", "-j", "1:2,2:2"]) == 0
     for n in names:
         assert np.array_equal(np.asarray(Image.open(outp / n).convert("RGB")), np.asarray(Image.open(outs["one"] / n).convert("RGB"))), n
 
