@@ -20,6 +20,8 @@ struct ImgConvArgs {
     const float* bias;        // [32]
     const float* slope;       // [32]
     int wp, hp, Wo, Ho, tiles_x, ntiles;
+    const uint32_t* img1 = nullptr;      // gridDim.y = 2: the second frame / output of the launch (the two ContextNet passes)
+    float* out1 = nullptr;
 };
 
 __global__ __launch_bounds__(256) void conv_img_s2_kernel(ImgConvArgs a) {
@@ -28,6 +30,8 @@ __global__ __launch_bounds__(256) void conv_img_s2_kernel(ImgConvArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int h = lane >> 5, li = lane & 31;
     float* const tl = tlb + wv * 32 * ROWF;
+    const uint32_t* const timg = blockIdx.y ? a.img1 : a.img;
+    float* const tout = blockIdx.y ? a.out1 : a.out;
     f16x8 wA[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) wA[j] = *reinterpret_cast<const f16x8*>(a.wpk + ((j * 2 + h) * 32 + li) * 8);
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_img_s2_kernel(ImgConvArgs a) {
                 const int dy = t / 3, dx = t - 3 * dy;
                 const int iy = 2 * oy + dy - 1, ix = 2 * ox + dx - 1;
                 const bool ok = t < 9 && iy >= 0 && iy < a.hp && ix >= 0 && ix < a.wp;
-                px[j][tt] = ok ? a.img[(size_t)iy * a.wp + ix] : 0u;
+                px[j][tt] = ok ? timg[(size_t)iy * a.wp + ix] : 0u;
             }
         f32x16 acc;
 #pragma unroll
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_img_s2_kernel(ImgConvArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
         const int pl = lane >> 3, chunk = lane & 7;           // 8 lanes (16-byte chunks) per pixel, 8 pixels per store instruction
-        float* const orow = a.out + ((size_t)oy * a.Wo + ox0) * 32 + chunk * 4;
+        float* const orow = tout + ((size_t)oy * a.Wo + ox0) * 32 + chunk * 4;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int p = j * 8 + pl;

@@ -73,6 +73,10 @@ struct ConvArgs {
     // conv_h2s2_kernel<NS, true> writes one, head_h2_kernel<EPI, true> reads one.
     int s16_pitch = 0;
     unsigned s16_plane = 0;
+    // two tensors through one launch (gridDim.y = 2; conv_h2b_kernel, conv_h2s2_kernel): the workgroups with blockIdx.y = 1 read in1 and write out1 (same geometry,
+    // strides and weights) - the two ContextNet passes of rife-v2.x (contextnet.param run on (img0, flow01) and (img1, flow10), src/rife.cpp:1027-1060)
+    const float* in1 = nullptr;
+    float* out1 = nullptr;
 };
 
 template <int STRIDE, int MS, int KS = 3> struct ConvGeom {
@@ -439,6 +443,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int half = lane >> 5, li = lane & 31;
+    const float* const tin = blockIdx.y ? a.in1 : a.in;                // gridDim.y = 2: the second tensor pair of the launch
+    float* const tout = blockIdx.y ? a.out1 : a.out;
     int L;
     {
         const int n = gridDim.x, b = blockIdx.x;
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define H2_ISSUE(RIN, RW, CH)                                                                               \
     {                                                                                                       \
         _Pragma("unroll") for (int k = 0; k < NIN; k++)                                                     \
-            RIN[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC);                           \
+            RIN[k] = *reinterpret_cast<const f32x4*>(tin + goff[k] + (CH) * CC);                           \
         _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                    \
             const int idx = tid + k * 512;                                                                  \
             RW[k] = wsrc[(size_t)(CH) * W_16 + ((W_16 % 512 == 0 || idx < W_16) ? idx : 0)];                \
@@ -577,13 +583,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k];
             if (via_lds) *reinterpret_cast<f32x4*>(tl + li * ROWF + n * 32 + 8 * q + 4 * half) = v;
-            else if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
+            else if (ok) *reinterpret_cast<f32x4*>(tout + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
         }
     }
     if (via_lds) {
         // 8 lanes per pixel and 32-channel sub-tile: every store instruction writes eight full 128-byte segments
         const int pl = lane >> 3, chunk = lane & 7;
-        float* const orow = a.out + ((size_t)oy * a.Wo + ox0) * a.out_ld + a.out_coff;
+        float* const orow = tout + ((size_t)oy * a.Wo + ox0) * a.out_ld + a.out_coff;
 #pragma unroll
         for (int n = 0; n < NS; n++)
 #pragma unroll
@@ -622,6 +628,8 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
+    const float* const tin = blockIdx.y ? a.in1 : a.in;                // gridDim.y = 2: the second tensor pair of the launch
+    float* const tout = blockIdx.y ? a.out1 : a.out;
     // bench-only RIFE_ABL(TAG & 32768): wave 0 of every workgroup records the shader clock at its phase boundaries into a.partial
     // ([workgroup][16] 64-bit slots: 0 start, 8 index math done, 9 first loads issued, 10 first chunk in LDS, 1 prologue barrier passed,
     // 2..5 one per chunk, 6 epilogue barrier passed, 7 tile in LDS, 13 stores issued, 14 stores done, 15 HW_ID | XCC_ID << 32)
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
     // (tools/h2b_phase_trace.py: chunks 0..2 took 4.3 / 3.2 / 2.5 us against 1.6 us for the last one, which waits for nothing)
     f32x4 rinA[NIN], rinB[NIN], rw[NW];
 #define H2B_ISSUE_IN(CH, RIN)                                                                               \
-    _Pragma("unroll") for (int k = 0; k < NIN; k++) RIN[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC);
+    _Pragma("unroll") for (int k = 0; k < NIN; k++) RIN[k] = *reinterpret_cast<const f32x4*>(tin + goff[k] + (CH) * CC);
 #define H2B_ISSUE_W(CH)                                                                                     \
     _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                        \
         const int idx = tid + k * NTHR;                                                                      \
@@ -789,8 +797,8 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k];
             if (via_lds) *reinterpret_cast<f32x4*>(tl + li * ROWF + n * 32 + 8 * q + 4 * half) = v;
-            else if RIFE_ABL(TAG & 256) { if (v[0] == 123.456f) a.out[0] = v[1]; }   // ablation: keep alive, (almost) never store
-            else if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
+            else if RIFE_ABL(TAG & 256) { if (v[0] == 123.456f) tout[0] = v[1]; }   // ablation: keep alive, (almost) never store
+            else if (ok) *reinterpret_cast<f32x4*>(tout + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
         }
     }
     H2B_STAMP(7)
@@ -798,7 +806,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
         constexpr int LPP = NT / 4;                            // lanes (16-byte chunks) per pixel
         constexpr int PPI = 64 / LPP;                          // pixels per store instruction
         const int pl = lane / LPP, chunk = lane - pl * LPP;
-        float* const orow = a.out + ((size_t)oy * a.Wo + ox0) * a.out_ld + a.out_coff + chunk * 4;
+        float* const orow = tout + ((size_t)oy * a.Wo + ox0) * a.out_ld + a.out_coff + chunk * 4;
 #pragma unroll
         for (int j = 0; j < 32 / PPI; j++) {
             const int px = j * PPI + pl;
@@ -856,6 +864,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int half = lane >> 5, li = lane & 31;
+    const float* const tin = blockIdx.y ? a.in1 : a.in;                // gridDim.y = 2: the second tensor pair of the launch
+    float* const tout = blockIdx.y ? a.out1 : a.out;
     int L;
     {
         const int n = gridDim.x, b = blockIdx.x;
@@ -884,7 +894,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 rin[NIN], rw[NW];
 #define S2_ISSUE(CH)                                                                                        \
     {                                                                                                       \
-        _Pragma("unroll") for (int k = 0; k < NIN; k++) rin[k] = *reinterpret_cast<const f32x4*>(a.in + goff[k] + (CH) * CC); \
+        _Pragma("unroll") for (int k = 0; k < NIN; k++) rin[k] = *reinterpret_cast<const f32x4*>(tin + goff[k] + (CH) * CC); \
         _Pragma("unroll") for (int k = 0; k < NW; k++) {                                                    \
             const int idx = tid + k * 256;                                                                  \
             rw[k] = wsrc[(size_t)(CH) * W_16 + ((W_16 % 256 == 0 || idx < W_16) ? idx : 0)];                \
@@ -954,7 +964,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int oy = oy0 + wv, ox = ox0 + li;
     const bool pok = oy < a.Ho && ox < a.Wo;
     if (S16OUT) {
-        unsigned char* const o = reinterpret_cast<unsigned char*>(a.out) + ((size_t)(2 * half + 4 * NS * ntile) * a.s16_plane + ((size_t)(oy + 1) * a.s16_pitch + ox + 1) * 32);
+        unsigned char* const o = reinterpret_cast<unsigned char*>(tout) + ((size_t)(2 * half + 4 * NS * ntile) * a.s16_plane + ((size_t)(oy + 1) * a.s16_pitch + ox + 1) * 32);
 #pragma unroll
         for (int n = 0; n < NS; n++) {
             float v[16];
@@ -983,7 +993,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             f32x4 v;
 #pragma unroll
             for (int k = 0; k < 4; k++) { v[k] = acc[n][4 * q + k] + b4[k]; v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k]; }
-            if (ok) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
+            if (ok) *reinterpret_cast<f32x4*>(tout + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
         }
     }
 }

@@ -45,6 +45,7 @@
 #include "head_h2.h"
 #include "conv_t64.h"
 #include "conv_row.h"
+#include "conv_rowf.h"
 #include "conv_rs.h"
 #ifdef RIFE_HIP_TEST_BUILD
 #include "conv_ks.h"      // round-4 K-split trunk kernel: opt-in (RIFE_HIP_KS), measured slower with pairs in flight; not compiled into the product
@@ -110,6 +111,8 @@ struct ConvLayer {
     bool want_t64 = false, want_s16out = false;
     unsigned char* d_t64 = nullptr;
     unsigned char* d_row = nullptr;      // 96 channels: the conv_row image next to the conv_t64 one (small grids)
+    bool want_rowf = false;
+    unsigned char* d_rowf = nullptr;     // rife-v2.x wide small-grid trunk layers (256 / 384 channels): weight image of conv_rowf_kernel (conv_rowf.h)
     uint16_t* d_whp = nullptr;
     uint16_t* d_wimg = nullptr;           // 3 -> 32 stride-2 layer on the RGBX u8 frame (conv_img.h): f16 [K-step 3][k half 2][32][8]
     double flops_per_pixel = 0;           // algorithmic: 2 * MAC per GEMM-M pixel
@@ -125,6 +128,8 @@ static void free_layer(ConvLayer& L) {
     if (L.d_wh) (void)hipFree(L.d_wh);
     if (L.d_t64) (void)hipFree(L.d_t64);
     if (L.d_row) (void)hipFree(L.d_row);
+    if (L.d_rowf) (void)hipFree(L.d_rowf);
+    L.d_rowf = nullptr;
     if (L.d_whp) (void)hipFree(L.d_whp);
     if (L.d_wimg) (void)hipFree(L.d_wimg);
     L.d_wimg = nullptr;
@@ -242,7 +247,7 @@ static std::vector<uint16_t> pack_weights_h2_perm(const ConvLayer& L, const floa
 // permuted by s16_row_channel() (every chunk is one contiguous LDS-DMA source), then that N-tile's bias[NT] and slope[NT] as fp32.
 static int t64_ns(int C) { return C == 96 ? 3 : 2; }
 // NSf > 0 forces the N-tile width (conv_row_kernel: NSf = 1, one 32-channel output block per wave)
-static std::vector<unsigned char> pack_t64_image(const float* w, const float* bias, float slope, int C = 64, int NSf = 0) {
+static std::vector<unsigned char> pack_t64_image(const float* w, const float* bias, float slope, int C = 64, int NSf = 0, const float* slopes = nullptr) {
     const int NS = NSf > 0 ? NSf : t64_ns(C), NT = 32 * NS, nnt = C / NT, nch = C / 16;
     const size_t stride = t64_img_nt(NS, nch);
     std::vector<unsigned char> img(stride * nnt, 0);
@@ -257,7 +262,7 @@ static std::vector<unsigned char> pack_t64_image(const float* w, const float* bi
                             wh[((((size_t)c * 9 + t) * 2 + kh) * NT + row) * 8 + e] = f2h(w[((size_t)oc * C + ic) * 9 + t]);
                         }
         float* bs = reinterpret_cast<float*>(img.data() + nt * stride + (size_t)nch * t64_wch(NS));
-        for (int i = 0; i < NT; i++) { bs[i] = bias ? bias[nt * NT + i] : 0.f; bs[NT + i] = slope; }
+        for (int i = 0; i < NT; i++) { bs[i] = bias ? bias[nt * NT + i] : 0.f; bs[NT + i] = slopes ? slopes[nt * NT + i] : slope; }
     }
     return img;
 }
@@ -396,6 +401,11 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
             HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
             L.nchunksh = L.cin / 16;
+            if (L.want_rowf && !L.skip && L.cin == L.cout && (L.cout == 128 || L.cout == 256 || L.cout == 384)) {
+                std::vector<unsigned char> img = pack_t64_image(w_orig, bias, uniform_slope, L.cout, 1, slope);
+                HIPCHK(hipMalloc(&L.d_rowf, img.size()));
+                HIPCHK(hipMemcpy(L.d_rowf, img.data(), img.size(), hipMemcpyHostToDevice));
+            }
             if (L.want_t64 && L.skip && L.cin == L.cout && (L.cout == 64 || L.cout == 96 || L.cout == 128 || L.cout == 192) && !slope) {
                 std::vector<unsigned char> img = pack_t64_image(w_orig, bias, uniform_slope, L.cout, L.cout >= 128 ? 1 : 0);
                 HIPCHK(hipMalloc(&L.d_t64, img.size()));
@@ -450,8 +460,11 @@ static constexpr bool g_fuse_stem = true, g_head_h2 = true, g_s2_h2 = true, g_sp
 // x: NHWC input (H x W), y: output; for deconv layers y has 2H x 2W pixels (or the 4H x 4W flow tensor with EPI_DECONV_PS).
 // s16_pitch > 0: the stride-2 stem writes / the head reads an S16 tensor (conv_t64.h) of that row pitch instead of NHWC fp32
 static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorView y, const TensorView* res, hipStream_t st, const FinalArgs* fin = nullptr,
-                       int s16_pitch = 0, unsigned s16_plane = 0) {
+                       int s16_pitch = 0, unsigned s16_plane = 0, const float* in1 = nullptr, float* out1 = nullptr) {
+    // in1 / out1: a second tensor pair of the same geometry through the same launch (gridDim.y = 2; the stride-2 and stride-1 split-f16 kernels and conv_rowf)
     ConvArgs a;
+    a.in1 = in1; a.out1 = out1;
+    const unsigned gy = in1 ? 2 : 1;
     a.s16_pitch = s16_pitch; a.s16_plane = s16_plane;
     a.in = x.p; a.in_ld = x.ld; a.in_coff = x.coff; a.H = H; a.W = W;
     a.out = y.p; a.out_ld = y.ld; a.out_coff = y.coff;
@@ -492,18 +505,19 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         if (s16_pitch > 0) {
             if ((L.NS != 2 && L.NS != 3) || !L.d_whp) return fail(RIFE_HIP_EINVAL, "no S16 variant of this stride-2 layer");
             a.wpk = reinterpret_cast<const float*>(L.d_whp);
-            if (L.NS == 2) hipLaunchKernelGGL((conv_h2s2_kernel<2, true>), dim3(nb), dim3(256), ls2, st, a);
-            else hipLaunchKernelGGL((conv_h2s2_kernel<3, true>), dim3(nb), dim3(256), ls3, st, a);
+            if (L.NS == 2) hipLaunchKernelGGL((conv_h2s2_kernel<2, true>), dim3(nb, gy), dim3(256), ls2, st, a);
+            else hipLaunchKernelGGL((conv_h2s2_kernel<3, true>), dim3(nb, gy), dim3(256), ls3, st, a);
         }
-        else if (L.NS == 1) hipLaunchKernelGGL(conv_h2s2_kernel<1>, dim3(nb), dim3(256), ls1, st, a);
-        else if (L.NS == 2) hipLaunchKernelGGL(conv_h2s2_kernel<2>, dim3(nb), dim3(256), ls2, st, a);
-        else hipLaunchKernelGGL(conv_h2s2_kernel<3>, dim3(nb), dim3(256), ls3, st, a);
+        else if (L.NS == 1) hipLaunchKernelGGL(conv_h2s2_kernel<1>, dim3(nb, gy), dim3(256), ls1, st, a);
+        else if (L.NS == 2) hipLaunchKernelGGL(conv_h2s2_kernel<2>, dim3(nb, gy), dim3(256), ls2, st, a);
+        else hipLaunchKernelGGL(conv_h2s2_kernel<3>, dim3(nb, gy), dim3(256), ls3, st, a);
         hipError_t eh = hipGetLastError();
         if (eh != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_h2s2 launch: ") + hipGetErrorString(eh));
         return 0;
     }
     if (fin && !(L.nchunksh > 0 && L.deconv && g_trunk_h2 && g_head_h2)) return fail(RIFE_HIP_EINVAL, "fused tail needs the split-f16 head kernel");
     if (L.nchunksh > 0 && L.deconv && g_trunk_h2 && g_head_h2) {
+        if (in1) return fail(RIFE_HIP_EINVAL, "no two-tensor form of the head kernel");
         a.ntiles_xy = a.tiles_x * ((a.Ho + 7) / 8);
         a.nchunks = L.nchunksh;
         a.nz = (L.cout + 31) / 32;
@@ -526,14 +540,28 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         if (L.epi == EPI_DECONV_PS && (L.cout != 24 || y.ld != 8 || y.coff != 0))
             return fail(RIFE_HIP_EINVAL, "the PixelShuffle head kernel writes the 6-channel flow tensor [4H][4W][8] only");
         if (s16_pitch > 0 && L.epi != EPI_DECONV_PS) return fail(RIFE_HIP_EINVAL, "no S16 variant of this head");
-        if (s16_pitch > 0 && fin) hipLaunchKernelGGL((head_h2_kernel<EPI_FINAL, true>), dim3(nb), dim3(512), headh2_lds_bytes(), st, a, *fin);
-        else if (s16_pitch > 0) hipLaunchKernelGGL((head_h2_kernel<EPI_DECONV_PS, true>), dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
-        else if (fin && L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_FINAL>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, *fin);
-        else if (L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_PS>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
-        else if (L.epi == EPI_DECONV) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
-        else hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_SIG>, dim3(nb), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
+        if (s16_pitch > 0 && fin) hipLaunchKernelGGL((head_h2_kernel<EPI_FINAL, true>), dim3(nb, gy), dim3(512), headh2_lds_bytes(), st, a, *fin);
+        else if (s16_pitch > 0) hipLaunchKernelGGL((head_h2_kernel<EPI_DECONV_PS, true>), dim3(nb, gy), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
+        else if (fin && L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_FINAL>, dim3(nb, gy), dim3(512), headh2_lds_bytes(), st, a, *fin);
+        else if (L.epi == EPI_DECONV_PS) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_PS>, dim3(nb, gy), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
+        else if (L.epi == EPI_DECONV) hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV>, dim3(nb, gy), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
+        else hipLaunchKernelGGL(head_h2_kernel<EPI_DECONV_SIG>, dim3(nb, gy), dim3(512), headh2_lds_bytes(), st, a, FinalArgs{});
         hipError_t eh = hipGetLastError();
         if (eh != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("head_h2 launch: ") + hipGetErrorString(eh));
+        return 0;
+    }
+    // wide small-grid trunk layers of rife-v2.x (256 / 384 channels): one pass over K per workgroup (conv_rowf.h); RIFE_HIP_V2_ROWF=0 (A/B): the per-tile kernels
+    const int rowf_mask = env_int(ab_getenv("RIFE_HIP_V2_ROWF"), 3, 0, 7);      // bit 0: 256 channels, bit 1: 384, bit 2: 128 (A/B; read per call: test build only, null in the product)
+    const bool rowf_on = (L.cout == 256 && (rowf_mask & 1)) || (L.cout == 384 && (rowf_mask & 2)) || (L.cout == 128 && (rowf_mask & 4));
+    if (L.d_rowf && rowf_on && g_trunk_h2 && res == nullptr && !L.deconv && L.stride == 1 && s16_pitch == 0) {
+        RowfArgs r;
+        r.in = x.p; r.out = y.p; r.img = L.d_rowf; r.H = H; r.W = W; r.in_ld = x.ld; r.in_coff = x.coff; r.out_ld = y.ld; r.out_coff = y.coff;
+        r.tiles_x = (W + 31) / 32; r.in1 = in1; r.out1 = out1;
+        if (L.cout == 128) hipLaunchKernelGGL((conv_rowf_kernel<128, 4>), dim3(r.tiles_x * ((H + 3) / 4), gy), dim3(256), (rowf_lds_bytes<128, 4>()), st, r);
+        else if (L.cout == 256) hipLaunchKernelGGL((conv_rowf_kernel<256, 4>), dim3(r.tiles_x * ((H + 3) / 4), gy), dim3(512), (rowf_lds_bytes<256, 4>()), st, r);
+        else hipLaunchKernelGGL((conv_rowf_kernel<384, 2>), dim3(r.tiles_x * ((H + 1) / 2), gy), dim3(768), (rowf_lds_bytes<384, 2>()), st, r);
+        hipError_t er = hipGetLastError();
+        if (er != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_rowf launch: ") + hipGetErrorString(er));
         return 0;
     }
     // trunk layers: split-f16 matrix path (fp32-grade accuracy at 8x the fp32 MFMA rate) unless RIFE_HIP_TRUNK=f32
@@ -578,7 +606,7 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         // split-K only for layers with a handful of workgroups (<= 64, i.e. under a quarter of the CUs): measured +35 % on the
         // 1080p block-0 trunk (30 workgroups); above that the partial-sum traffic and the extra launch eat the gain
         int nsplit = 1;
-        if (g_splitk && g_h2b && L.NS == 2 && nb <= 64 && a.nchunks >= 4) nsplit = std::min(4, a.nchunks / 2);
+        if (g_splitk && g_h2b && L.NS == 2 && nb <= 64 && a.nchunks >= 4 && !in1) nsplit = std::min(4, a.nchunks / 2);
         int nbl = nb;
         if (nsplit > 1) {
             a.nsplit = nsplit; a.cpad = L.ntiles * L.NS * 32;
@@ -597,10 +625,10 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
             constexpr int l43_9 = convh2b_lds_bytes<3, 9, 4>(), l43_10 = convh2b_lds_bytes<3, 10, 4>();      // 96-wide N-tiles: 63 KB, two workgroups per CU
             a.ntiles_xy = a.tiles_x * ((a.Ho + 3) / 4);
             const int nb4 = a.ntiles_xy * a.nz;
-            if (L.NS == 3 && L.skip) hipLaunchKernelGGL((conv_h2b_kernel<3, 10, 0, 4>), dim3(nb4), dim3(256), l43_10, st, a);
-            else if (L.NS == 3) hipLaunchKernelGGL((conv_h2b_kernel<3, 9, 0, 4>), dim3(nb4), dim3(256), l43_9, st, a);
-            else if (L.skip) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 0, 4>), dim3(nb4), dim3(256), l4_10, st, a);
-            else hipLaunchKernelGGL((conv_h2b_kernel<2, 9, 0, 4>), dim3(nb4), dim3(256), l4_9, st, a);
+            if (L.NS == 3 && L.skip) hipLaunchKernelGGL((conv_h2b_kernel<3, 10, 0, 4>), dim3(nb4, gy), dim3(256), l43_10, st, a);
+            else if (L.NS == 3) hipLaunchKernelGGL((conv_h2b_kernel<3, 9, 0, 4>), dim3(nb4, gy), dim3(256), l43_9, st, a);
+            else if (L.skip) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 0, 4>), dim3(nb4, gy), dim3(256), l4_10, st, a);
+            else hipLaunchKernelGGL((conv_h2b_kernel<2, 9, 0, 4>), dim3(nb4, gy), dim3(256), l4_9, st, a);
             hipError_t e4 = hipGetLastError();
             if (e4 != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_h2b (4-row) launch: ") + hipGetErrorString(e4));
             return 0;
@@ -608,16 +636,16 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         const int nb_saved = nb; (void)nb_saved;
 #define nb nbl
         constexpr int lb110 = convh2b_lds_bytes<1, 10>();
-        if (L.NS == 1 && L.skip) hipLaunchKernelGGL((conv_h2b_kernel<1, 10, 0>), dim3(nb), dim3(512), lb110, st, a);
-        else if (L.NS == 1) hipLaunchKernelGGL((conv_h2b_kernel<1, 9, 0>), dim3(nb), dim3(512), lb19, st, a);
-        else if (g_h2b && L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 3>), dim3(nb), dim3(512), lb10, st, a);
-        else if (g_h2b && L.NS == 2 && L.skip) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 0>), dim3(nb), dim3(512), lb10, st, a);
-        else if (g_h2b && L.NS == 2) hipLaunchKernelGGL((conv_h2b_kernel<2, 9, 0>), dim3(nb), dim3(512), lb9, st, a);
-        else if (L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2_kernel<2, 10, 3>), dim3(nb), dim3(512), l210, st, a);
-        else if (L.NS == 2 && L.skip) hipLaunchKernelGGL((conv_h2_kernel<2, 10, 0>), dim3(nb), dim3(512), l210, st, a);
-        else if (L.NS == 2) hipLaunchKernelGGL((conv_h2_kernel<2, 9, 0>), dim3(nb), dim3(512), l29, st, a);
-        else if (L.skip) hipLaunchKernelGGL((conv_h2_kernel<3, 10, 0>), dim3(nb), dim3(512), l310, st, a);
-        else hipLaunchKernelGGL((conv_h2_kernel<3, 9, 0>), dim3(nb), dim3(512), l39, st, a);
+        if (L.NS == 1 && L.skip) hipLaunchKernelGGL((conv_h2b_kernel<1, 10, 0>), dim3(nb, gy), dim3(512), lb110, st, a);
+        else if (L.NS == 1) hipLaunchKernelGGL((conv_h2b_kernel<1, 9, 0>), dim3(nb, gy), dim3(512), lb19, st, a);
+        else if (g_h2b && L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 3>), dim3(nb, gy), dim3(512), lb10, st, a);
+        else if (g_h2b && L.NS == 2 && L.skip) hipLaunchKernelGGL((conv_h2b_kernel<2, 10, 0>), dim3(nb, gy), dim3(512), lb10, st, a);
+        else if (g_h2b && L.NS == 2) hipLaunchKernelGGL((conv_h2b_kernel<2, 9, 0>), dim3(nb, gy), dim3(512), lb9, st, a);
+        else if (L.NS == 2 && L.skip && L.tag == 3) hipLaunchKernelGGL((conv_h2_kernel<2, 10, 3>), dim3(nb, gy), dim3(512), l210, st, a);
+        else if (L.NS == 2 && L.skip) hipLaunchKernelGGL((conv_h2_kernel<2, 10, 0>), dim3(nb, gy), dim3(512), l210, st, a);
+        else if (L.NS == 2) hipLaunchKernelGGL((conv_h2_kernel<2, 9, 0>), dim3(nb, gy), dim3(512), l29, st, a);
+        else if (L.skip) hipLaunchKernelGGL((conv_h2_kernel<3, 10, 0>), dim3(nb, gy), dim3(512), l310, st, a);
+        else hipLaunchKernelGGL((conv_h2_kernel<3, 9, 0>), dim3(nb, gy), dim3(512), l39, st, a);
 #undef nb
         hipError_t eh = hipGetLastError();
         if (eh != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_h2 launch: ") + hipGetErrorString(eh));
@@ -630,6 +658,7 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         }
         return 0;
     }
+    if (in1) return fail(RIFE_HIP_EINVAL, "no two-tensor form of this convolution kernel");
     // layers with >= 2 full waves of 8-row tiles take the double-buffered 8-wave kernel
     if (L.nchunks8 > 0 && g_use_conv8) {
         const long wg8 = (long)a.tiles_x * ((a.Ho + 7) / 8) * a.nz;
@@ -651,9 +680,9 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
                     done[dev] = true;
                 }
             }
-            if (L.NS == 2 && L.tag == 3) hipLaunchKernelGGL((conv_mfma8_kernel<2, 8, 4, 3>), dim3(nb), dim3(512), lds28, st, a);
-            else if (L.NS == 2) hipLaunchKernelGGL((conv_mfma8_kernel<2, 8, 4, 0>), dim3(nb), dim3(512), lds28, st, a);
-            else hipLaunchKernelGGL((conv_mfma8_kernel<3, 8, 2, 0>), dim3(nb), dim3(512), lds38, st, a);
+            if (L.NS == 2 && L.tag == 3) hipLaunchKernelGGL((conv_mfma8_kernel<2, 8, 4, 3>), dim3(nb, gy), dim3(512), lds28, st, a);
+            else if (L.NS == 2) hipLaunchKernelGGL((conv_mfma8_kernel<2, 8, 4, 0>), dim3(nb, gy), dim3(512), lds28, st, a);
+            else hipLaunchKernelGGL((conv_mfma8_kernel<3, 8, 2, 0>), dim3(nb, gy), dim3(512), lds38, st, a);
             hipError_t e8 = hipGetLastError();
             if (e8 != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv8 launch: ") + hipGetErrorString(e8));
             return 0;
@@ -963,6 +992,9 @@ struct Ctx {
     float4 *h0 = nullptr, *h1 = nullptr, *acc_s = nullptr;          // UHD: half-resolution fp32 frames and their (quarter-res) flow
     float *I8 = nullptr, *ca = nullptr, *cb = nullptr, *cc = nullptr, *feat[4] = {nullptr, nullptr, nullptr, nullptr}, *ctmp[3] = {nullptr, nullptr, nullptr};
     float2* fl[4] = {nullptr, nullptr, nullptr, nullptr};           // ContextNet flow pyramid
+    // the second ContextNet pass (img1, flow10): its own activations, so that both passes ride one launch per layer (gridDim.y = 2)
+    float *ca2 = nullptr, *cb2 = nullptr, *cc2 = nullptr, *feat2[4] = {nullptr, nullptr, nullptr, nullptr}, *ctmp2[3] = {nullptr, nullptr, nullptr};
+    float2* fl2[4] = {nullptr, nullptr, nullptr, nullptr};
     float *e0a = nullptr, *e0b = nullptr, *e0c = nullptr, *B1 = nullptr, *e1a = nullptr, *B2 = nullptr, *e2a = nullptr, *B3 = nullptr, *e3a = nullptr, *B4 = nullptr;
     float *U0 = nullptr, *U1 = nullptr, *U2 = nullptr, *U3 = nullptr;
     // rife-v2.x TTA: per orientation RGBX frames, half-res flows [direction][orientation], float outputs [direction][orientation]
@@ -1744,6 +1776,10 @@ static int ensure_ctx_v2(Ctx& c, int w, int h, bool uhd, int nori = 1, int ntemp
     A_(c.feat[0], P / 16 * 32) A_(c.feat[1], P / 64 * 64) A_(c.feat[2], P / 256 * 128) A_(c.feat[3], P / 1024 * 256)
     A_(c.ctmp[0], P / 64 * 64) A_(c.ctmp[1], P / 256 * 128) A_(c.ctmp[2], P / 1024 * 256)
     A_(c.fl[0], P / 16) A_(c.fl[1], P / 64) A_(c.fl[2], P / 256) A_(c.fl[3], P / 1024)
+    A_(c.ca2, P / 4 * 32) A_(c.cb2, P / 4 * 32) A_(c.cc2, P / 16 * 32)
+    A_(c.feat2[0], P / 16 * 32) A_(c.feat2[1], P / 64 * 64) A_(c.feat2[2], P / 256 * 128) A_(c.feat2[3], P / 1024 * 256)
+    A_(c.ctmp2[0], P / 64 * 64) A_(c.ctmp2[1], P / 256 * 128) A_(c.ctmp2[2], P / 1024 * 256)
+    A_(c.fl2[0], P / 16) A_(c.fl2[1], P / 64) A_(c.fl2[2], P / 256) A_(c.fl2[3], P / 1024)
     A_(c.e0a, P / 4 * 32) A_(c.e0b, P / 4 * 32) A_(c.e0c, P / 16 * 64) A_(c.B1, P / 16 * 128) A_(c.e1a, P / 64 * 128) A_(c.B2, P / 64 * 256)
     A_(c.e2a, P / 256 * 256) A_(c.B3, P / 256 * 512) A_(c.e3a, P / 1024 * 512) A_(c.B4, P / 1024 * 1024)
     A_(c.U0, P / 256 * 512) A_(c.U1, P / 64 * 256) A_(c.U2, P / 16 * 128) A_(c.U3, P / 4 * 32)
@@ -1757,10 +1793,10 @@ static int ensure_ctx_v2(Ctx& c, int w, int h, bool uhd, int nori = 1, int ntemp
     return 0;
 }
 
-static int conv_t(const rife_hip& E, const ConvLayer& L, TensorView x, int H, int W, TensorView y, hipStream_t st) {
+static int conv_t(const rife_hip& E, const ConvLayer& L, TensorView x, int H, int W, TensorView y, hipStream_t st, const float* in1 = nullptr, float* out1 = nullptr) {
     const int mo_h = L.deconv ? H : (H - 1) / L.stride + 1, mo_w = L.deconv ? W : (W - 1) / L.stride + 1;
-    Timed t(E.prof, L.cls, L.flops_per_pixel * mo_h * mo_w, st);
-    return launch_conv(L, x, H, W, y, nullptr, st);
+    Timed t(E.prof, L.cls, L.flops_per_pixel * mo_h * mo_w * (in1 ? 2 : 1), st);
+    return launch_conv(L, x, H, W, y, nullptr, st, nullptr, 0, 0, in1, out1);      // in1 / out1: a second tensor pair through the same launch
 }
 
 // stem2_fused_kernel (stem_fused_v2.h): block-input assembly at scale S (1 or 2) fused into the 10 -> cout stride-2 convolution that consumes it.
@@ -1907,6 +1943,52 @@ static int run_v2_synth(const rife_hip& E, Ctx& c, const uint32_t* img0, const u
     const bool ctx0_img = E.ctxc[0].d_wimg != nullptr && g_trunk_h2 && img_env;      // RIFE_HIP_TRUNK=f32 keeps the fp32 matrix path
     float* cat_buf[4] = {c.B1, c.B2, c.B3, c.B4};
     const int cat_ld[4] = {128, 256, 512, 1024}, cat_off[4] = {64, 128, 256, 512}, lvl_c[4] = {32, 64, 128, 256};
+    // both passes through ONE launch per layer (gridDim.y = 2: same weights, twice the workgroups - the deep levels are grids of 72 - 272 workgroups);
+    // RIFE_HIP_V2_CTX_BATCH=0 (A/B, test build): one pass after the other
+    static const bool ctx_batch_env = env_not_off(ab_getenv("RIFE_HIP_V2_CTX_BATCH"));
+    const bool ctx_batch = ctx0_img && ctx_batch_env;
+    if (ctx_batch) {
+        float2* const* flp[2] = {c.fl, c.fl2};
+        float* const* featp[2] = {c.feat, c.feat2};
+        {
+            Timed t(E.prof, "v2_ctx_misc", 0, st);
+            for (int im = 0; im < 2; im++) {
+                hipLaunchKernelGGL(k2_flow_half<true>, grid2d(wh / 2, hh / 2), dim3(256), 0, st, reinterpret_cast<const float*>(acc), im * 2, flp[im][0], wh, hh);
+                for (int l = 1; l < 4; l++)
+                    hipLaunchKernelGGL(k2_flow_half<false>, grid2d((wh >> l) / 2, (hh >> l) / 2), dim3(256), 0, st, reinterpret_cast<const float*>(flp[im][l - 1]), 0, flp[im][l],
+                                       wh >> l, hh >> l);
+            }
+            HIPCHK(hipGetLastError());
+        }
+        {
+            const ConvLayer& L0 = E.ctxc[0];
+            Timed t(E.prof, L0.cls, 2 * L0.flops_per_pixel * (hp / 2) * (wp / 2), st);
+            ImgConvArgs ia;
+            ia.img = img0; ia.out = c.ca; ia.img1 = img1; ia.out1 = c.ca2; ia.wpk = L0.d_wimg; ia.bias = L0.d_bias; ia.slope = L0.d_slope;
+            ia.wp = wp; ia.hp = hp; ia.Wo = wp / 2; ia.Ho = hp / 2; ia.tiles_x = (ia.Wo + 31) / 32; ia.ntiles = ia.tiles_x * ia.Ho;
+            const int nwg = std::min((ia.ntiles + 3) / 4, 4 * device_cus(true));
+            hipLaunchKernelGGL(conv_img_s2_kernel, dim3(nwg, 2), dim3(256), 0, st, ia);
+            HIPCHK(hipGetLastError());
+        }
+        if ((rc = conv_t(E, E.ctxc[1], {c.ca, 32, 0}, hp / 2, wp / 2, {c.cb, 32, 0}, st, c.ca2, c.cb2))) return rc;
+        if ((rc = conv_t(E, E.ctxc[2], {c.cb, 32, 0}, hp / 2, wp / 2, {c.cc, 32, 0}, st, c.cb2, c.cc2))) return rc;
+        if ((rc = conv_t(E, E.ctxc[3], {c.cc, 32, 0}, hp / 4, wp / 4, {c.feat[0], 32, 0}, st, c.cc2, c.feat2[0]))) return rc;
+        for (int l = 1; l < 4; l++) {
+            const int Hl = hp >> (l + 1), Wl = wp >> (l + 1);      // input resolution of this level's strided conv
+            if ((rc = conv_t(E, E.ctxc[2 + 2 * l], {c.feat[l - 1], lvl_c[l - 1], 0}, Hl, Wl, {c.ctmp[l - 1], lvl_c[l], 0}, st, c.feat2[l - 1], c.ctmp2[l - 1]))) return rc;
+            if ((rc = conv_t(E, E.ctxc[3 + 2 * l], {c.ctmp[l - 1], lvl_c[l], 0}, Hl / 2, Wl / 2, {c.feat[l], lvl_c[l], 0}, st, c.ctmp2[l - 1], c.feat2[l]))) return rc;
+        }
+        {
+            Timed t(E.prof, E.prof_fine ? "ctx_warps" : "v2_ctx_misc", 0, st);
+            for (int im = 0; im < 2; im++)
+                for (int l = 0; l < 4; l++) {
+                    const int Hl = hp >> (l + 2), Wl = wp >> (l + 2), nq = lvl_c[l] / 4, ppb = 256 / nq;
+                    hipLaunchKernelGGL(k2_warp_nhwc, dim3((Wl + ppb - 1) / ppb, Hl), dim3(256), 0, st, featp[im][l], lvl_c[l], flp[im][l], cat_buf[l], cat_ld[l],
+                                       cat_off[l] + im * lvl_c[l], Wl, Hl);
+                }
+            HIPCHK(hipGetLastError());
+        }
+    } else
     for (int im = 0; im < 2; im++) {
         {
             Timed t(E.prof, "v2_ctx_misc", 0, st);
@@ -2298,6 +2380,7 @@ static int load_v2(rife_hip* E, const std::string& dir) {
         }
         free_layer(L);
         L.cin = cin; L.cout = cout; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi; L.cls = cls; L.tag = 0;
+        L.want_rowf = !deconv && stride == 1 && cin == cout && (cout == 128 || cout == 256 || cout == 384);      // IFNet blocks 0 / 1, the 256-channel levels of the two pyramids
         return upload_layer(L, nl->weight.data(), nl->bias.data(), slope, 1.0f);
     };
     {
@@ -3343,6 +3426,7 @@ static int op_conv_common(int gpuid, const float* x, int c, int h, int w, const 
     if ((rc = check_device(gpuid))) return rc;
     ConvLayer L;
     L.cin = c; L.cout = outc; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi;
+    L.want_rowf = !deconv && stride == 1 && !residual && c == outc && (c == 128 || c == 256 || c == 384);      // like load_v2: 256 / 384 reach conv_rowf_kernel (128 with RIFE_HIP_V2_ROWF=7)
     if ((rc = upload_layer(L, weight, bias, slope, 1.0f))) { free_layer(L); return rc; }
     const int ho = deconv ? 2 * h : (h + 2 - 3) / stride + 1, wo = deconv ? 2 * w : (w + 2 - 3) / stride + 1;
     const int ldi = L.cin_p;
