@@ -77,6 +77,10 @@ struct ConvArgs {
     // strides and weights) - the two ContextNet passes of rife-v2.x (contextnet.param run on (img0, flow01) and (img1, flow10), src/rife.cpp:1027-1060)
     const float* in1 = nullptr;
     float* out1 = nullptr;
+    // second destination of the output (conv_h2b_kernel, direct-store epilogue): the U-Net skip connections of the rife-v2.x FusionNet - s0 / s1 / s2 are the input
+    // of the next encoder level AND a channel slice of a decoder concat buffer (fusionnet.param:53, 56, 59) - are written twice by the producer instead of copied
+    float* out2 = nullptr;
+    int out2_ld = 0, out2_coff = 0;
 };
 
 template <int STRIDE, int MS, int KS = 3> struct ConvGeom {
@@ -773,7 +777,7 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
     const int oy = oy0 + wv, ox = ox0 + li;
     const bool pok = oy < a.Ho && ox < a.Wo;
     constexpr int ROWF = NT + 4;                               // floats per pixel row of the transpose tile (odd number of 16-B slots)
-    const bool via_lds = a.nsplit == 1 && !RIFE_ABL(TAG & 256) && a.out_ld == NT && a.Cout == NT && a.nz == 1;
+    const bool via_lds = a.nsplit == 1 && !RIFE_ABL(TAG & 256) && a.out_ld == NT && a.Cout == NT && a.nz == 1 && a.out2 == nullptr;
     if (via_lds) __syncthreads();                              // every wave is done reading the staging buffers
     H2B_STAMP(6)
     float* const tl = reinterpret_cast<float*>(ldsb) + wv * 32 * ROWF;
@@ -798,7 +802,10 @@ __global__ __launch_bounds__(ROWS * 64) __attribute__((amdgpu_waves_per_eu(NS ==
             for (int k = 0; k < 4; k++) v[k] = v[k] < 0.f ? v[k] * s4[k] : v[k];
             if (via_lds) *reinterpret_cast<f32x4*>(tl + li * ROWF + n * 32 + 8 * q + 4 * half) = v;
             else if RIFE_ABL(TAG & 256) { if (v[0] == 123.456f) tout[0] = v[1]; }   // ablation: keep alive, (almost) never store
-            else if (ok) *reinterpret_cast<f32x4*>(tout + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
+            else if (ok) {
+                *reinterpret_cast<f32x4*>(tout + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff + c0) = v;
+                if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + ((size_t)oy * a.Wo + ox) * a.out2_ld + a.out2_coff + c0) = v;
+            }
         }
     }
     H2B_STAMP(7)

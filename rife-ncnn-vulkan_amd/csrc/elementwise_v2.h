@@ -185,6 +185,33 @@ __global__ void k2_warp_nhwc(const float* __restrict__ feat, int C, const float2
     *reinterpret_cast<float4*>(out + ((size_t)y * w + x) * out_ld + out_coff + c4 * 4) = o;
 }
 
+// the eight ContextNet warps of a pair (4 pyramid levels x 2 frames: contextnet.param:17, 26, 35, 42 run twice, src/rife.cpp:1027-1060) in ONE launch:
+// blockIdx.z = 4 * frame + level selects the tensors, the grid is sized for level 0 and the blocks beyond a level's extent leave at once.  Same arithmetic
+// as k2_warp_nhwc; 32 / 64 / 128 / 256 channels = 8 / 16 / 32 / 64 float4 lanes per pixel of a 256-thread block.
+struct WarpBatch {
+    const float* feat[8]; const float2* flow[8]; float* out[8];
+    int C[8], out_ld[8], out_coff[8], w[8], h[8];
+};
+__global__ void k2_warp_nhwc_batch(WarpBatch b) {
+    const int z = blockIdx.z;
+    const int C = b.C[z], w = b.w[z], h = b.h[z];
+    const int nq = C / 4, pix_per_block = 256 / nq;
+    const int x = blockIdx.x * pix_per_block + threadIdx.x / nq, y = blockIdx.y;
+    if (y >= h || x >= w) return;
+    const int c4 = threadIdx.x % nq;
+    const float* __restrict__ feat = b.feat[z];
+    const float2 f = b.flow[z][(size_t)y * w + x];
+    const WarpTaps t = warp_taps(x, y, f.x, f.y, w, h);
+    const float4 a = *reinterpret_cast<const float4*>(feat + (size_t)t.i00 * C + c4 * 4);
+    const float4 bb = *reinterpret_cast<const float4*>(feat + (size_t)t.i01 * C + c4 * 4);
+    const float4 c = *reinterpret_cast<const float4*>(feat + (size_t)t.i10 * C + c4 * 4);
+    const float4 d = *reinterpret_cast<const float4*>(feat + (size_t)t.i11 * C + c4 * 4);
+    float4 o;
+    o.x = warp_lerp(a.x, bb.x, c.x, d.x, t.alpha, t.beta); o.y = warp_lerp(a.y, bb.y, c.y, d.y, t.alpha, t.beta);
+    o.z = warp_lerp(a.z, bb.z, c.z, d.z, t.alpha, t.beta); o.w = warp_lerp(a.w, bb.w, c.w, d.w, t.alpha, t.beta);
+    *reinterpret_cast<float4*>(b.out[z] + ((size_t)y * w + x) * b.out_ld[z] + b.out_coff[z] + c4 * 4) = o;
+}
+
 // channel-slice copy between NHWC views (U-Net skip connections, fusionnet.param:53, 56, 59)
 __global__ void k2_copy_view(const float* __restrict__ src, int src_ld, int src_coff, float* __restrict__ dst, int dst_ld, int dst_coff, int C, size_t npix) {
     const int nq = C / 4;

@@ -45,7 +45,6 @@
 #include "head_h2.h"
 #include "conv_t64.h"
 #include "conv_row.h"
-#include "conv_rowf.h"
 #include "conv_rs.h"
 #ifdef RIFE_HIP_TEST_BUILD
 #include "conv_ks.h"      // round-4 K-split trunk kernel: opt-in (RIFE_HIP_KS), measured slower with pairs in flight; not compiled into the product
@@ -111,8 +110,6 @@ struct ConvLayer {
     bool want_t64 = false, want_s16out = false;
     unsigned char* d_t64 = nullptr;
     unsigned char* d_row = nullptr;      // 96 channels: the conv_row image next to the conv_t64 one (small grids)
-    bool want_rowf = false;
-    unsigned char* d_rowf = nullptr;     // rife-v2.x wide small-grid trunk layers (256 / 384 channels): weight image of conv_rowf_kernel (conv_rowf.h)
     uint16_t* d_whp = nullptr;
     uint16_t* d_wimg = nullptr;           // 3 -> 32 stride-2 layer on the RGBX u8 frame (conv_img.h): f16 [K-step 3][k half 2][32][8]
     double flops_per_pixel = 0;           // algorithmic: 2 * MAC per GEMM-M pixel
@@ -128,8 +125,6 @@ static void free_layer(ConvLayer& L) {
     if (L.d_wh) (void)hipFree(L.d_wh);
     if (L.d_t64) (void)hipFree(L.d_t64);
     if (L.d_row) (void)hipFree(L.d_row);
-    if (L.d_rowf) (void)hipFree(L.d_rowf);
-    L.d_rowf = nullptr;
     if (L.d_whp) (void)hipFree(L.d_whp);
     if (L.d_wimg) (void)hipFree(L.d_wimg);
     L.d_wimg = nullptr;
@@ -138,7 +133,7 @@ static void free_layer(ConvLayer& L) {
 
 // Choose the kernel configuration for a layer (see conv_mfma.h for the meaning of MS / NS / CC).
 static void configure(ConvLayer& L) {
-    const int NT = L.cout <= 32 ? 32 : (L.cout % 64 == 0 ? 64 : (L.cout % 96 == 0 ? 96 : 64));      // 96-wide N tiles beat 3 x 32 (round-1 A/B)
+    const int NT = L.cout <= 32 ? 32 : (L.cout % 64 == 0 ? 64 : (L.cout % 96 == 0 ? 96 : 64));      // 96-wide N tiles beat 3 x 32 (round-1 A/B); 192 = 3 x 64, not 2 x 96 (round-5 A/B)
     L.NS = NT / 32;
     L.ntiles = (L.cout + NT - 1) / NT;
     if (L.stride == 2) { L.MS = 1; L.CC = 8; }
@@ -401,11 +396,6 @@ static int upload_layer(ConvLayer& L, const float* w, const float* bias, const f
             HIPCHK(hipMalloc(&L.d_wh, ph.size() * 2));
             HIPCHK(hipMemcpy(L.d_wh, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
             L.nchunksh = L.cin / 16;
-            if (L.want_rowf && !L.skip && L.cin == L.cout && (L.cout == 128 || L.cout == 256 || L.cout == 384)) {
-                std::vector<unsigned char> img = pack_t64_image(w_orig, bias, uniform_slope, L.cout, 1, slope);
-                HIPCHK(hipMalloc(&L.d_rowf, img.size()));
-                HIPCHK(hipMemcpy(L.d_rowf, img.data(), img.size(), hipMemcpyHostToDevice));
-            }
             if (L.want_t64 && L.skip && L.cin == L.cout && (L.cout == 64 || L.cout == 96 || L.cout == 128 || L.cout == 192) && !slope) {
                 std::vector<unsigned char> img = pack_t64_image(w_orig, bias, uniform_slope, L.cout, L.cout >= 128 ? 1 : 0);
                 HIPCHK(hipMalloc(&L.d_t64, img.size()));
@@ -460,11 +450,15 @@ static constexpr bool g_fuse_stem = true, g_head_h2 = true, g_s2_h2 = true, g_sp
 // x: NHWC input (H x W), y: output; for deconv layers y has 2H x 2W pixels (or the 4H x 4W flow tensor with EPI_DECONV_PS).
 // s16_pitch > 0: the stride-2 stem writes / the head reads an S16 tensor (conv_t64.h) of that row pitch instead of NHWC fp32
 static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorView y, const TensorView* res, hipStream_t st, const FinalArgs* fin = nullptr,
-                       int s16_pitch = 0, unsigned s16_plane = 0, const float* in1 = nullptr, float* out1 = nullptr) {
-    // in1 / out1: a second tensor pair of the same geometry through the same launch (gridDim.y = 2; the stride-2 and stride-1 split-f16 kernels and conv_rowf)
+                       int s16_pitch = 0, unsigned s16_plane = 0, const float* in1 = nullptr, float* out1 = nullptr, const TensorView* y2 = nullptr) {
+    // in1 / out1: a second tensor pair of the same geometry through the same launch (gridDim.y = 2; the stride-2 and stride-1 split-f16 kernels)
     ConvArgs a;
     a.in1 = in1; a.out1 = out1;
     const unsigned gy = in1 ? 2 : 1;
+    // y2: the output goes to a second view as well (conv_h2b_kernel only: stride-1 split-f16 layers without split-K)
+    if (y2) { a.out2 = y2->p; a.out2_ld = y2->ld; a.out2_coff = y2->coff; }
+    if (y2 && !(L.nchunksh > 0 && L.stride == 1 && !L.deconv && g_trunk_h2 && res == nullptr && g_h2b && L.NS <= 2))
+        return fail(RIFE_HIP_EINVAL, "no two-destination form of this convolution kernel");
     a.s16_pitch = s16_pitch; a.s16_plane = s16_plane;
     a.in = x.p; a.in_ld = x.ld; a.in_coff = x.coff; a.H = H; a.W = W;
     a.out = y.p; a.out_ld = y.ld; a.out_coff = y.coff;
@@ -550,20 +544,6 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         if (eh != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("head_h2 launch: ") + hipGetErrorString(eh));
         return 0;
     }
-    // wide small-grid trunk layers of rife-v2.x (256 / 384 channels): one pass over K per workgroup (conv_rowf.h); RIFE_HIP_V2_ROWF=0 (A/B): the per-tile kernels
-    const int rowf_mask = env_int(ab_getenv("RIFE_HIP_V2_ROWF"), 3, 0, 7);      // bit 0: 256 channels, bit 1: 384, bit 2: 128 (A/B; read per call: test build only, null in the product)
-    const bool rowf_on = (L.cout == 256 && (rowf_mask & 1)) || (L.cout == 384 && (rowf_mask & 2)) || (L.cout == 128 && (rowf_mask & 4));
-    if (L.d_rowf && rowf_on && g_trunk_h2 && res == nullptr && !L.deconv && L.stride == 1 && s16_pitch == 0) {
-        RowfArgs r;
-        r.in = x.p; r.out = y.p; r.img = L.d_rowf; r.H = H; r.W = W; r.in_ld = x.ld; r.in_coff = x.coff; r.out_ld = y.ld; r.out_coff = y.coff;
-        r.tiles_x = (W + 31) / 32; r.in1 = in1; r.out1 = out1;
-        if (L.cout == 128) hipLaunchKernelGGL((conv_rowf_kernel<128, 4>), dim3(r.tiles_x * ((H + 3) / 4), gy), dim3(256), (rowf_lds_bytes<128, 4>()), st, r);
-        else if (L.cout == 256) hipLaunchKernelGGL((conv_rowf_kernel<256, 4>), dim3(r.tiles_x * ((H + 3) / 4), gy), dim3(512), (rowf_lds_bytes<256, 4>()), st, r);
-        else hipLaunchKernelGGL((conv_rowf_kernel<384, 2>), dim3(r.tiles_x * ((H + 1) / 2), gy), dim3(768), (rowf_lds_bytes<384, 2>()), st, r);
-        hipError_t er = hipGetLastError();
-        if (er != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_rowf launch: ") + hipGetErrorString(er));
-        return 0;
-    }
     // trunk layers: split-f16 matrix path (fp32-grade accuracy at 8x the fp32 MFMA rate) unless RIFE_HIP_TRUNK=f32
     if (L.nchunksh > 0 && L.stride == 1 && g_trunk_h2 && res == nullptr) {
         a.ntiles_xy = a.tiles_x * ((a.Ho + 7) / 8);
@@ -606,7 +586,7 @@ static int launch_conv(const ConvLayer& L, TensorView x, int H, int W, TensorVie
         // split-K only for layers with a handful of workgroups (<= 64, i.e. under a quarter of the CUs): measured +35 % on the
         // 1080p block-0 trunk (30 workgroups); above that the partial-sum traffic and the extra launch eat the gain
         int nsplit = 1;
-        if (g_splitk && g_h2b && L.NS == 2 && nb <= 64 && a.nchunks >= 4 && !in1) nsplit = std::min(4, a.nchunks / 2);
+        if (g_splitk && g_h2b && L.NS == 2 && nb <= 64 && a.nchunks >= 4 && !in1 && !y2) nsplit = std::min(4, a.nchunks / 2);      // round-5 A/B of 2 / 8 slices and of the 64-workgroup limit: no change
         int nbl = nb;
         if (nsplit > 1) {
             a.nsplit = nsplit; a.cpad = L.ntiles * L.NS * 32;
@@ -1793,25 +1773,23 @@ static int ensure_ctx_v2(Ctx& c, int w, int h, bool uhd, int nori = 1, int ntemp
     return 0;
 }
 
-static int conv_t(const rife_hip& E, const ConvLayer& L, TensorView x, int H, int W, TensorView y, hipStream_t st, const float* in1 = nullptr, float* out1 = nullptr) {
+static int conv_t(const rife_hip& E, const ConvLayer& L, TensorView x, int H, int W, TensorView y, hipStream_t st, const float* in1 = nullptr, float* out1 = nullptr,
+                  const TensorView* y2 = nullptr) {
     const int mo_h = L.deconv ? H : (H - 1) / L.stride + 1, mo_w = L.deconv ? W : (W - 1) / L.stride + 1;
     Timed t(E.prof, L.cls, L.flops_per_pixel * mo_h * mo_w * (in1 ? 2 : 1), st);
-    return launch_conv(L, x, H, W, y, nullptr, st, nullptr, 0, 0, in1, out1);      // in1 / out1: a second tensor pair through the same launch
+    return launch_conv(L, x, H, W, y, nullptr, st, nullptr, 0, 0, in1, out1, y2);      // in1 / out1: a second tensor pair through the same launch; y2: a second destination
 }
 
 // stem2_fused_kernel (stem_fused_v2.h): block-input assembly at scale S (1 or 2) fused into the 10 -> cout stride-2 convolution that consumes it.
 // RIFE_HIP_V2_FUSED_STEM=0 (A/B): the unfused pair k2_assemble + conv_h2s2_kernel
 static const bool g_v2_fused_stem = env_not_off(ab_getenv("RIFE_HIP_V2_FUSED_STEM"));
 static bool stem2_fusable(const ConvLayer& L, int S, int wp, int hp) {
-    static const bool dbg = ab_getenv("RIFE_HIP_DEBUG_V2") != nullptr;
-    if (dbg) fprintf(stderr, "stem2_fusable: env %d trunk_h2 %d S %d d_wh %p cin %d nchunksh %d stride %d deconv %d cout %d wp %d hp %d\n", (int)g_v2_fused_stem, (int)g_trunk_h2, S,
-                     (void*)L.d_wh, L.cin, L.nchunksh, L.stride, (int)L.deconv, L.cout, wp, hp);
     return g_v2_fused_stem && g_trunk_h2 && (S == 1 || S == 2) && L.d_wh && L.cin == 10 && L.nchunksh == 1 && L.stride == 2 && !L.deconv && L.cout <= 128 && L.cout % 4 == 0 &&
            (wp / S) % 2 == 0 && (hp / S) % 2 == 0;
 }
-template <int S, typename IMG, bool FSCALE>
+template <int S, typename IMG, bool FSCALE, bool R64 = false>
 static int launch_stem2_cfg(const Stem2Args<IMG>& a, int nwg, hipStream_t st) {
-    auto kfn = stem2_fused_kernel<S, IMG, FSCALE>;
+    auto kfn = stem2_fused_kernel<S, IMG, FSCALE, R64>;
     {
         static std::mutex mu; static std::map<int, bool> done;
         int dev = 0; (void)hipGetDevice(&dev);
@@ -1821,7 +1799,7 @@ static int launch_stem2_cfg(const Stem2Args<IMG>& a, int nwg, hipStream_t st) {
             done[dev] = true;
         }
     }
-    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), stem2_lds_bytes(a.nsub), st, a);
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), stem2_lds_bytes(a.nsub, R64), st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("stem2_fused launch: ") + hipGetErrorString(e));
     return 0;
@@ -1835,6 +1813,9 @@ static int launch_stem2_fused(const rife_hip& E, const ConvLayer& L, int S, bool
     a.NS = L.NS; a.nsub = (L.cout + 31) / 32;
     const int nwg = a.tiles_x * ((a.Ho + 3) / 4);
     Timed t(E.prof, L.cls, L.flops_per_pixel * a.Ho * a.Wo, st);
+    // scale 1 on the u8 frames: 64-byte halo records, weights from the L2, three workgroups per CU (stem_fused_v2.h R64); RIFE_HIP_V2_STEM_R64=0 (A/B, test build): two
+    static const bool r64 = env_not_off(ab_getenv("RIFE_HIP_V2_STEM_R64"));
+    if (S == 1 && std::is_same<IMG, ImgU8>::value && r64 && a.nsub <= 2) return launch_stem2_cfg<1, IMG, false, true>(a, nwg, st);
     if (S == 1) return launch_stem2_cfg<1, IMG, false>(a, nwg, st);
     if (fscale) return launch_stem2_cfg<2, IMG, true>(a, nwg, st);
     return launch_stem2_cfg<2, IMG, false>(a, nwg, st);
@@ -1980,12 +1961,15 @@ static int run_v2_synth(const rife_hip& E, Ctx& c, const uint32_t* img0, const u
         }
         {
             Timed t(E.prof, E.prof_fine ? "ctx_warps" : "v2_ctx_misc", 0, st);
+            WarpBatch wb;
             for (int im = 0; im < 2; im++)
                 for (int l = 0; l < 4; l++) {
-                    const int Hl = hp >> (l + 2), Wl = wp >> (l + 2), nq = lvl_c[l] / 4, ppb = 256 / nq;
-                    hipLaunchKernelGGL(k2_warp_nhwc, dim3((Wl + ppb - 1) / ppb, Hl), dim3(256), 0, st, featp[im][l], lvl_c[l], flp[im][l], cat_buf[l], cat_ld[l],
-                                       cat_off[l] + im * lvl_c[l], Wl, Hl);
+                    const int z = 4 * im + l;
+                    wb.feat[z] = featp[im][l]; wb.flow[z] = flp[im][l]; wb.out[z] = cat_buf[l]; wb.C[z] = lvl_c[l]; wb.out_ld[z] = cat_ld[l];
+                    wb.out_coff[z] = cat_off[l] + im * lvl_c[l]; wb.w[z] = wp >> (l + 2); wb.h[z] = hp >> (l + 2);
                 }
+            const int W0 = wp >> 2, H0 = hp >> 2, ppb0 = 256 / (lvl_c[0] / 4);      // level 0: the largest pixel grid and the most pixels per block
+            hipLaunchKernelGGL(k2_warp_nhwc_batch, dim3((W0 + ppb0 - 1) / ppb0, H0, 8), dim3(256), 0, st, wb);
             HIPCHK(hipGetLastError());
         }
     } else
@@ -2044,14 +2028,23 @@ static int run_v2_synth(const rife_hip& E, Ctx& c, const uint32_t* img0, const u
     else if ((rc = conv_t(E, F[0], {c.X, 16, 0}, hp, wp, {c.e0a, 32, 0}, st))) return rc;
     if ((rc = conv_t(E, F[1], {c.e0a, 32, 0}, hp / 2, wp / 2, {c.e0b, 32, 0}, st))) return rc;
     if ((rc = conv_t(E, F[2], {c.e0b, 32, 0}, hp / 2, wp / 2, {c.e0c, 64, 0}, st))) return rc;
-    if ((rc = conv_t(E, F[3], {c.e0c, 64, 0}, hp / 4, wp / 4, {c.B1, 128, 0}, st))) return rc;            // s0 -> B1[0:64]
+    // s0 / s1 / s2 are written twice by their producers - into the next encoder level's concat buffer and into the decoder's (Concat(up, s), fusionnet.param:53, 56, 59) -
+    // instead of being copied (RIFE_HIP_V2_SKIP_COPY=1, A/B in the test build: the three k2_copy_view launches); the split-K form (tiny grids) has no second destination
+    static const bool skip_copy_env = env_on(ab_getenv("RIFE_HIP_V2_SKIP_COPY"));
+    auto dual_ok = [&](const ConvLayer& L, int H, int W) {
+        const long nb = (long)((W + 31) / 32) * ((H + 7) / 8) * L.ntiles;
+        return !skip_copy_env && g_trunk_h2 && L.nchunksh > 0 && L.NS <= 2 && !(L.NS == 2 && nb <= 64 && L.nchunksh >= 4);
+    };
+    const bool dual = dual_ok(F[3], hp / 4, wp / 4) && dual_ok(F[5], hp / 8, wp / 8) && dual_ok(F[7], hp / 16, wp / 16);
+    const TensorView u2v{c.U2, 128, 64}, u1v{c.U1, 256, 128}, u0v{c.U0, 512, 256};
+    if ((rc = conv_t(E, F[3], {c.e0c, 64, 0}, hp / 4, wp / 4, {c.B1, 128, 0}, st, nullptr, nullptr, dual ? &u2v : nullptr))) return rc;            // s0 -> B1[0:64] (+ U2[64:128])
     if ((rc = conv_t(E, F[4], {c.B1, 128, 0}, hp / 4, wp / 4, {c.e1a, 128, 0}, st))) return rc;
-    if ((rc = conv_t(E, F[5], {c.e1a, 128, 0}, hp / 8, wp / 8, {c.B2, 256, 0}, st))) return rc;           // s1 -> B2[0:128]
+    if ((rc = conv_t(E, F[5], {c.e1a, 128, 0}, hp / 8, wp / 8, {c.B2, 256, 0}, st, nullptr, nullptr, dual ? &u1v : nullptr))) return rc;           // s1 -> B2[0:128] (+ U1[128:256])
     if ((rc = conv_t(E, F[6], {c.B2, 256, 0}, hp / 8, wp / 8, {c.e2a, 256, 0}, st))) return rc;
-    if ((rc = conv_t(E, F[7], {c.e2a, 256, 0}, hp / 16, wp / 16, {c.B3, 512, 0}, st))) return rc;         // s2 -> B3[0:256]
+    if ((rc = conv_t(E, F[7], {c.e2a, 256, 0}, hp / 16, wp / 16, {c.B3, 512, 0}, st, nullptr, nullptr, dual ? &u0v : nullptr))) return rc;         // s2 -> B3[0:256] (+ U0[256:512])
     if ((rc = conv_t(E, F[8], {c.B3, 512, 0}, hp / 16, wp / 16, {c.e3a, 512, 0}, st))) return rc;
     if ((rc = conv_t(E, F[9], {c.e3a, 512, 0}, hp / 32, wp / 32, {c.B4, 1024, 0}, st))) return rc;        // s3 -> B4[0:512]
-    {
+    if (!dual) {
         Timed t(E.prof, "v2_skip_copy", 0, st);
         copy_view(c.B3, 512, 0, c.U0, 512, 256, 256, (size_t)(hp / 16) * (wp / 16));                      // Concat(up0, s2)
         copy_view(c.B2, 256, 0, c.U1, 256, 128, 128, (size_t)(hp / 8) * (wp / 8));                        // Concat(up1, s1)
@@ -2380,7 +2373,6 @@ static int load_v2(rife_hip* E, const std::string& dir) {
         }
         free_layer(L);
         L.cin = cin; L.cout = cout; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi; L.cls = cls; L.tag = 0;
-        L.want_rowf = !deconv && stride == 1 && cin == cout && (cout == 128 || cout == 256 || cout == 384);      // IFNet blocks 0 / 1, the 256-channel levels of the two pyramids
         return upload_layer(L, nl->weight.data(), nl->bias.data(), slope, 1.0f);
     };
     {
@@ -3426,7 +3418,6 @@ static int op_conv_common(int gpuid, const float* x, int c, int h, int w, const 
     if ((rc = check_device(gpuid))) return rc;
     ConvLayer L;
     L.cin = c; L.cout = outc; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi;
-    L.want_rowf = !deconv && stride == 1 && !residual && c == outc && (c == 128 || c == 256 || c == 384);      // like load_v2: 256 / 384 reach conv_rowf_kernel (128 with RIFE_HIP_V2_ROWF=7)
     if ((rc = upload_layer(L, weight, bias, slope, 1.0f))) { free_layer(L); return rc; }
     const int ho = deconv ? 2 * h : (h + 2 - 3) / stride + 1, wo = deconv ? 2 * w : (w + 2 - 3) / stride + 1;
     const int ldi = L.cin_p;

@@ -26,15 +26,19 @@ struct Stem2Args {
     int nsub;                  // 32-channel output subtiles (<= 4)
 };
 
-constexpr int stem2_lds_bytes(int nsub) { return (9 * 65 + 1) * 80 + nsub * 32 * 9 * 2 * 16 + 2 * 128 * 4; }
+// R64 (scale 1 only: the gather needs 56 VGPRs): 64-byte halo records with the 16-byte quarters XOR-swizzled by pixel index (quarter q of pixel P at position
+// q ^ ((P >> 2) & 3): 2-way on the stride-2 operand reads like the padded 80-byte records, conflict-free staging writes - the block-3 layout of stem_fused.h) and the
+// weights read from the L2 straight into the operand registers after the gather instead of waiting in LDS: 38.5 KB of LDS per workgroup, THREE workgroups = 24 waves
+// per CU (85 VGPRs) instead of two - the kernel is gather-latency bound.  At most two output subtiles (one per wave group): the scale-1 layers have 48 and 32 channels.
+constexpr int stem2_lds_bytes(int nsub, bool r64 = false) { return r64 ? (9 * 65 + 1) * 64 + 2 * 128 * 4 : (9 * 65 + 1) * 80 + nsub * 32 * 9 * 2 * 16 + 2 * 128 * 4; }
 
-template <int S, typename IMG, bool FSCALE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem2_fused_kernel(Stem2Args<IMG> a) {
-    constexpr int IH = 9, IW = 65, PIXB = 80, NPIX = IH * IW, ROWF = 36;
+template <int S, typename IMG, bool FSCALE, bool R64 = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R64 ? 6 : 4, R64 ? 6 : 4))) void stem2_fused_kernel(Stem2Args<IMG> a) {
+    constexpr int IH = 9, IW = 65, PIXB = R64 ? 64 : 80, NPIX = IH * IW, ROWF = 36;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const int cp = a.nsub * 32;
     unsigned char* const lw = ldsb + (NPIX + 1) * PIXB;                  // record NPIX: dummy target of the lanes without a second pixel
-    float* const lbs = reinterpret_cast<float*>(lw + cp * 9 * 2 * 16);  // bias[128], slope[128]
+    float* const lbs = reinterpret_cast<float*>(lw + (R64 ? 0 : cp * 9 * 2 * 16));  // bias[128], slope[128]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv8 = tid >> 6;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // weights -> LDS as [tap * 2 + half][cp rows][8 f16]; bias and slopes next to them
     {
         const int NT = a.NS * 32;
-        for (int idx = tid; idx < 18 * cp; idx += 512) {
+        if (!R64) for (int idx = tid; idx < 18 * cp; idx += 512) {
             const int t2 = idx / cp, n = idx - t2 * cp;
             const int nt = n / NT, nin = n - nt * NT;
             reinterpret_cast<f32x4*>(lw)[idx] = reinterpret_cast<const f32x4*>(a.wpk)[(nt * 18 + t2) * NT + nin];
@@ -85,8 +89,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             h1[c] = hb; l1[c] = (_Float16)(vb - (float)hb);                                                       \
         }                                                                                                         \
         unsigned char* dst = ldsb + (P) * PIXB;                                                                   \
-        *reinterpret_cast<f16x8*>(dst) = h0; *reinterpret_cast<f16x8*>(dst + 16) = h1;                            \
-        *reinterpret_cast<f16x8*>(dst + 32) = l0; *reinterpret_cast<f16x8*>(dst + 48) = l1;                       \
+        const int sw_ = R64 ? (((P) >> 2) & 3) : 0;                                                               \
+        *reinterpret_cast<f16x8*>(dst + ((0 ^ sw_) << 4)) = h0; *reinterpret_cast<f16x8*>(dst + ((1 ^ sw_) << 4)) = h1; \
+        *reinterpret_cast<f16x8*>(dst + ((2 ^ sw_) << 4)) = l0; *reinterpret_cast<f16x8*>(dst + ((3 ^ sw_) << 4)) = l1; \
     }
     const bool two_px = __builtin_amdgcn_readfirstlane(wv8) < 2;
     if (two_px) {
@@ -103,9 +108,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 #undef STEM2_GATHER
 #undef STEM2_STAGE
+    const bool on0 = grp < a.nsub, on1 = grp + 2 < a.nsub;              // wave-uniform
+    f16x8 wq0[R64 ? 9 : 1];                                            // R64: this wave's weight fragments, issued before the barrier
+    if (R64) {
+        const int NT = a.NS * 32;
+        const int g0 = min(grp, a.nsub - 1);
+        const int nt0 = g0 / a.NS;
+        const f16x8* const w0 = reinterpret_cast<const f16x8*>(a.wpk) + (size_t)(nt0 * 18 + half) * NT + (g0 - nt0 * a.NS) * 32 + li;
+#pragma unroll
+        for (int t = 0; t < 9; t++) wq0[t] = w0[(size_t)(2 * t) * NT];
+    }
     __syncthreads();
 
-    const bool on0 = grp < a.nsub, on1 = grp + 2 < a.nsub;              // wave-uniform
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -114,14 +128,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int t = 0; t < 9; t++) {
         const int dy = t / 3, dx = t % 3;
-        const f16x8 ah = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB);
-        const f16x8 al = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB + 32);
+        f16x8 ah, al;
+        if (R64) {
+            const int P = (2 * wv + dy) * IW + 2 * li + dx;
+            const int ph = half ^ ((P >> 2) & 3);
+            ah = *reinterpret_cast<const f16x8*>(ldsb + P * 64 + (ph << 4));
+            al = *reinterpret_cast<const f16x8*>(ldsb + P * 64 + ((ph ^ 2) << 4));
+        } else {
+            ah = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB);
+            al = *reinterpret_cast<const f16x8*>(ab + (dy * IW + dx) * PIXB + 32);
+        }
         if (on0) {
-            const f16x8 bw = *reinterpret_cast<const f16x8*>(bb + (t * 2 * cp) * 16);
+            const f16x8 bw = R64 ? wq0[t] : *reinterpret_cast<const f16x8*>(bb + (t * 2 * cp) * 16);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, ah, acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, al, acc0, 0, 0, 0);
         }
-        if (on1) {
+        if (!R64 && on1) {
             const f16x8 bw = *reinterpret_cast<const f16x8*>(bb + (t * 2 * cp + 64) * 16);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, ah, acc1, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, al, acc1, 0, 0, 0);
@@ -136,7 +158,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int pl = lane >> 3, chunk = lane & 7;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        if (!(j ? on1 : on0)) continue;
+        if (!(j ? (!R64 && on1) : on0)) continue;
         const int g = grp + 2 * j;
 #pragma unroll
         for (int q = 0; q < 4; q++) {

@@ -106,26 +106,6 @@ def test_conv3x3_split_f16_trunk_path_matches_oracle(c, h, w):
     assert err[:, 7:].max() <= 1e-4           # rows fed only by O(1) activations
 
 
-@pytest.mark.parametrize("c,h,w", [(256, 17, 60), (256, 34, 33), (256, 3, 5), (384, 9, 31), (384, 17, 30), (384, 1, 2), (128, 21, 70)])
-def test_conv3x3_row_kernel_of_the_v2_trunks_matches_oracle(c, h, w, monkeypatch):
-    """conv_rowf_kernel (csrc/conv_rowf.h): C -> C, stride 1, PReLU with per-channel slopes, NHWC fp32 in / out, one pass over K per workgroup (the wide
-    small-grid trunk layers of rife-v2.x: models/rife-v2.3/flownet.param:10-21, 41-52).  Same fp32-grade bar as the per-tile split-f16 kernels; ragged tiles
-    (h not a multiple of the 4 / 2 rows of a workgroup, w not a multiple of 32) and sub-tile tensors included."""
-    monkeypatch.setenv("RIFE_HIP_V2_ROWF", "7")                # 128 channels too (the product serves 256 and 384)
-    rng = np.random.default_rng(c + h + w)
-    x = (rng.standard_normal((c, h, w)) * 3).astype(np.float32)
-    x[:, :1] *= 1e-4
-    x[:, -1:] *= 300.0
-    wt = (rng.standard_normal((c, c, 3, 3)) / np.sqrt(c * 9)).astype(np.float16).astype(np.float32)
-    b = rng.standard_normal(c).astype(np.float32)
-    slope = rng.uniform(0.05, 0.5, c).astype(np.float32)
-    want = pyoracle.conv2d(x, wt, b, stride=1, pad=1)
-    want = np.where(want < 0, want * slope[:, None, None], want)
-    got = amd.op_conv3x3(x, wt, b, stride=1, slope=slope)
-    err = np.abs(got - want)
-    assert err.max() <= 4e-6 * np.abs(want).max(), (float(err.max()), float(np.abs(want).max()))
-
-
 def test_f16_mfma_keeps_subnormals():
     """conv_h2*_kernel relies on the matrix pipe preserving f16 subnormal inputs (lo = f16(a - hi) is often subnormal)."""
     import ctypes
