@@ -23,8 +23,9 @@
 //   C = 192: NB 2, CPW 3 -> KS 4, 8 consumers, 12 waves, 3 N groups;                               LDS: ring 4 x 26,112 + staging 1 x 32 KiB ... (see KsCfg)
 // Arithmetic: the products are those of conv_row_kernel / conv_rs_kernel (fp16 weights x {hi, lo} activations, fp32 accumulation, identity tap
 // for the skip connection); the summation order is this kernel's own (per consumer: chunk-major, taps in order, hi then lo; then the partials kq = 0 .. KS - 1;
-// then the bias), deterministic by construction.  tests/test_gpu_ks.py holds it against the kernels it replaces (<= 1 LSB on the frame, flows
-// to 1e-4); the end-to-end parity tests run on it.
+// then the bias), deterministic by construction.  OPT-IN (RIFE_HIP_KS) and compiled into the test / bench builds only: measured slower with pairs in
+// flight (profiles/r4/ks_ab.txt), so the product does not carry it.  tests/test_gpu_ks.py holds it against the kernels it replaces (<= 1 LSB on the
+// frame, flows to 1e-4) and, directly, within 1 LSB of the CPU oracle.
 #pragma once
 #include <type_traits>
 #include "conv_rs.h"

@@ -3,7 +3,8 @@ conv_t64_kernel, RIFE_HIP_KS=0): same products, its own summation order (per con
 then the bias), so the two engines agree to summation-order noise - frames within 1 LSB with very few channels touched, flows of the blocks it
 serves to 1e-4 - at aligned, ragged and tiny sizes, on a used workspace, through the TTA schedule and through rife_hip_process_batch's lockstep
 groups (one launch for the coarse trunks of two pairs).  Reference layers: models/rife-v4.6/flownet.param:14-42, 66-94, 119-147.
-Parity against the CPU oracle and the reference build is covered by the other test files, which run on this kernel (the default)."""
+The kernel is OPT-IN (RIFE_HIP_KS, test / bench builds only; the product neither compiles nor selects it), so the other test files do NOT run on it:
+the last test of this file holds it - and the RIFE_HIP_RS_SPLIT epilogue variant of conv_rs - within 1 LSB of the CPU oracle directly."""
 import importlib
 import os
 
@@ -80,3 +81,30 @@ def test_ks_tta_passes_match(modeldirs):
     a, b = gen_frames.smooth_pair(100, 60, 11)
     d = np.abs(new.process(a, b, 0.4).astype(np.int32) - old.process(a, b, 0.4).astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+def test_ks_and_rs_split_variants_within_1_lsb_of_the_oracle(modeldirs):
+    """1 LSB against the round-3 kernels + 1 LSB of those against the oracle does not bound the opt-in variants against the oracle at 1 LSB.
+    RIFE_HIP_KS=7 (every layer conv_ks can serve) and RIFE_HIP_RS_SPLIT=1 (read once per process: a child process of the test build) against the CPU oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, importlib; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from oracle import pyoracle\n"
+        "from tools import gen_frames\n"
+        "amd = importlib.import_module('rife-ncnn-vulkan_amd').test_build()\n"
+        "g = amd.RIFE(0, rife_v4=True); g.load(%r)\n"
+        "o = pyoracle.OracleRIFE(rife_v4=True); o.set_gpu_crop(1); o.load(%r)\n"
+        "for (w, h, t, seed) in ((640, 360, 0.5, 3), (256, 192, 0.3, 4), (1000, 520, 0.7, 5)):\n"
+        "    a, b = gen_frames.smooth_pair(w, h, seed)\n"
+        "    d = np.abs(g.process(a, b, t).astype(int) - o.process(a, b, t).astype(int))\n"
+        "    print('MAXLSB', w, h, int(d.max()), float((d == 0).mean()))\n") % (root, modeldirs["rife-v4.6"], modeldirs["rife-v4.6"])
+    env = dict(os.environ, RIFE_HIP_KS="7", RIFE_HIP_RS_SPLIT="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-800:]
+    rows = [l.split() for l in p.stdout.splitlines() if l.startswith("MAXLSB")]
+    assert len(rows) == 3
+    for _, w, h, mx, exact in rows:
+        assert int(mx) <= 1 and float(exact) > 0.99, (w, h, mx, exact)

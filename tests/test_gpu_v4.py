@@ -283,3 +283,33 @@ def test_fused_tta_consensus_is_bit_identical_to_the_two_kernels(modeldirs, w, h
     for t in (0.5, 0.3):
         x0, x1 = g0.process(a, b, t), g1.process(a, b, t)
         assert np.array_equal(x0, x1), "%d bytes differ" % int((x0 != x1).sum())
+
+
+def test_hipgraph_replay_is_opt_in_and_bit_identical(engines, modeldirs):
+    """RIFE_HIP_GRAPH=1 (a PRODUCT switch, read once per process: run_v4_replay in csrc/engine.hip) replays the plain pass <= 1920 x 1088 from a captured
+    hipGraph: warm-up call, capture call, replays with new frames and timesteps - the same bytes as the default launches.  (Until round 5 a closure-type
+    name collision made the switch's static initialiser read RIFE_HIP_TRUNK instead, so the replay was silently ON for every process: the default
+    path below is therefore the one the earlier rounds never ran at these sizes.)"""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    g, _ = engines
+    code = (
+        "import sys, hashlib, importlib; sys.path.insert(0, %r)\n"
+        "from tools import gen_frames\n"
+        "amd = importlib.import_module('rife-ncnn-vulkan_amd')\n"
+        "g = amd.RIFE(0, rife_v4=True); g.load(%r)\n"
+        "for (w, h) in ((160, 96), (100, 60), (160, 96), (640, 360)):\n"
+        "    for i, t in enumerate((0.5, 0.25, 0.7, 0.9, 0.125)):\n"
+        "        a, b = gen_frames.smooth_pair(w, h, 40 + i)\n"
+        "        print('MD5', w, h, i, hashlib.md5(g.process(a, b, t).tobytes()).hexdigest())\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), modeldirs["rife-v4.6"])
+    env = dict(os.environ, RIFE_HIP_GRAPH="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-800:]
+    got = [l.split() for l in p.stdout.splitlines() if l.startswith("MD5")]
+    assert len(got) == 20
+    for _, w, h, i, md5 in got:
+        a, b = gen_frames.smooth_pair(int(w), int(h), 40 + int(i))
+        want = hashlib.md5(g.process(a, b, (0.5, 0.25, 0.7, 0.9, 0.125)[int(i)]).tobytes()).hexdigest()
+        assert md5 == want, (w, h, i)

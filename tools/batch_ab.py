@@ -6,7 +6,7 @@ for RIFE_HIP_KS = 0 / 1 (conv_row vs the round-4 conv_ks trunk kernel for the 12
 import importlib, os, sys, threading, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
-amd = importlib.import_module("rife-ncnn-vulkan_amd")
+amd = importlib.import_module("rife-ncnn-vulkan_amd").test_build()      # the kernel-selection switches this tool flips live in the test build (librife_hip_test.so)
 import torch
 from tools import gen_frames, gen_models
 d = gen_models.ensure(None, "rife-v4.6")

@@ -4,7 +4,7 @@ workers (RIFE_HIP_BATCH_GROUPS=0), pageable and page-locked host frames, 1920x10
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
-amd = importlib.import_module("rife-ncnn-vulkan_amd")
+amd = importlib.import_module("rife-ncnn-vulkan_amd").test_build()      # the kernel-selection switches this tool flips live in the test build (librife_hip_test.so)
 from tools import gen_frames, gen_models
 g = amd.RIFE(0, rife_v4=True); g.load(gen_models.ensure(None, "rife-v4.6"))
 log = open("gpurun_out/batch_groups.txt", "w")

@@ -8,7 +8,7 @@ if __name__ == "__main__":
     os.makedirs("gpurun_out", exist_ok=True)
     log = open("gpurun_out/env_ab.txt", "a")
     here = os.path.dirname(os.path.abspath(__file__))
-    lib = os.path.join(os.path.dirname(here), "rife-ncnn-vulkan_amd", "librife_hip.so")
+    lib = os.path.join(os.path.dirname(here), "rife-ncnn-vulkan_amd", "librife_hip_test.so")      # the switches live in the test build; the product ignores them
     for rnd in range(2):
         for v in variants:
             env = dict(os.environ)

@@ -6,7 +6,7 @@ per pair with one pair in flight (HIP events on the launch stream) and frames/s 
 import importlib, os, sys, threading, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
-amd = importlib.import_module("rife-ncnn-vulkan_amd")
+amd = importlib.import_module("rife-ncnn-vulkan_amd").test_build()      # the kernel-selection switches this tool flips live in the test build (librife_hip_test.so)
 import torch
 from tools import gen_frames, gen_models
 

@@ -4,7 +4,7 @@ import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
 from tools import gen_frames, gen_models
-amd = importlib.import_module("rife-ncnn-vulkan_amd")
+amd = importlib.import_module("rife-ncnn-vulkan_amd").test_build()      # the kernel-selection switches this tool flips live in the test build (librife_hip_test.so)
 d = gen_models.ensure(None, "rife-v4.6")
 def eng(t64):
     os.environ["RIFE_HIP_T64"] = "1" if t64 else "0"
