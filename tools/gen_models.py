@@ -569,9 +569,10 @@ def write_bin(path, weights):
                 f.write(b.astype("<f4").tobytes())
 
 
-def generate(outdir, family="rife-v4.6", seed=0x51FE, real_contextnet=None):
+def generate(outdir, family="rife-v4.6", seed=0x51FE, real_contextnet=None, flow_gain=1.0):
     """Write <outdir>/{flownet,...}.{param,bin}.  `real_contextnet`: optional path to the reference's real
-    rife-v2.3 contextnet.bin (present in the reference tree); copied verbatim when given."""
+    rife-v2.3 contextnet.bin (present in the reference tree); copied verbatim when given.  `flow_gain` multiplies the gain of the flow heads
+    (rife-v4.6: flows and mask logits `flow_gain` times larger - the parity-margin tests, tests/test_gpu_margin.py)."""
     os.makedirs(outdir, exist_ok=True)
     rng = np.random.default_rng(seed)
     for net, builder in FAMILIES[family].items():
@@ -583,7 +584,7 @@ def generate(outdir, family="rife-v4.6", seed=0x51FE, real_contextnet=None):
                 dst.write(src.read())
             continue
         if family == "rife-v4.6":
-            w = synth_weights(g, rng, head_gain=0.25, res_gain=0.5)
+            w = synth_weights(g, rng, head_gain=0.25 * flow_gain, res_gain=0.5)
         elif family == "rife-v4":
             w = synth_weights(g, rng, head_gain=0.25)
         elif family in ("rife", "rife-HD"):
@@ -602,13 +603,13 @@ def default_dir(family="rife-v4.6"):
     return os.path.join(os.environ.get("RIFE_SYNTH_MODELS", os.path.join(root, "_synth_models")), family)
 
 
-def ensure(outdir=None, family="rife-v4.6", seed=0x51FE):
+def ensure(outdir=None, family="rife-v4.6", seed=0x51FE, flow_gain=1.0):
     """Idempotent: (re)generate only if the directory is incomplete."""
     if outdir is None:
-        outdir = default_dir(family)
+        outdir = default_dir(family if flow_gain == 1.0 and seed == 0x51FE else "%s-gain%g-seed%x" % (family, flow_gain, seed))
     need = [os.path.join(outdir, n + e) for n in FAMILIES[family] for e in (".param", ".bin")]
     if not all(os.path.exists(p) for p in need):
-        generate(outdir, family, seed)
+        generate(outdir, family, seed, flow_gain=flow_gain)
     return outdir
 
 

@@ -62,7 +62,7 @@ print("# %s  frames/s: whole-chip 1 in flight %.1f | one part of %d alone %.1f |
     args.workload, layouts["whole"][0], args.parts, layouts["part"][0], len(parts), args.parts, fps_clean, layouts["parts"][0]))
 names = sorted(layouts["whole"][1], key=lambda k: -layouts["parts"][1].get(k, dict(ms=0))["ms"])
 print("%-18s %5s %10s %10s %12s %10s   (us per pair; `parts` = elapsed under contention on 1/%d of the chip; chip-us = parts / %d)" % (
-    "class", "n", "whole", "part", "parts", "chip-us", args.parts, args.parts))
+    "class", "n", "whole", "part", "parts", "chip-us", args.parts, args.parts * args.per_part))
 tot = [0.0, 0.0, 0.0]
 for k in names:
     row = []
@@ -72,5 +72,5 @@ for k in names:
         row.append(v["ms"] * 1e3 / npairs)
         tot[j] += row[-1]
     n = layouts["whole"][1][k]["launches"] / layouts["whole"][2]
-    print("%-18s %5.1f %10.1f %10.1f %12.1f %10.1f" % (k, n, row[0], row[1], row[2], row[2] / args.parts * args.per_part))
-print("%-18s %5s %10.1f %10.1f %12.1f %10.1f" % ("total", "", tot[0], tot[1], tot[2], tot[2] / args.parts * args.per_part))
+    print("%-18s %5.1f %10.1f %10.1f %12.1f %10.1f" % (k, n, row[0], row[1], row[2], row[2] / (args.parts * args.per_part)))
+print("%-18s %5s %10.1f %10.1f %12.1f %10.1f" % ("total", "", tot[0], tot[1], tot[2], tot[2] / (args.parts * args.per_part)))
