@@ -25,7 +25,7 @@
 // for the skip connection); the summation order is this kernel's own (per consumer: chunk-major, taps in order, hi then lo; then the partials kq = 0 .. KS - 1;
 // then the bias), deterministic by construction.  OPT-IN (RIFE_HIP_KS) and compiled into the test / bench builds only: measured slower with pairs in
 // flight (profiles/r4/ks_ab.txt), so the product does not carry it.  tests/test_gpu_ks.py holds it against the kernels it replaces (<= 1 LSB on the
-// frame, flows to 1e-4) and, directly, within 1 LSB of the CPU oracle.
+// frame, flows to 1e-4) and, directly, within 1 LSB of the CPU restatement of the reference that the tests check against.
 #pragma once
 #include <type_traits>
 #include "conv_rs.h"
