@@ -45,6 +45,21 @@ def test_v23_1080p_within_1_lsb(engines):
     assert mx <= 1, (mx, f0)
 
 
+@pytest.mark.parametrize("w,h,uhd", [(3840, 2160, False), (1920, 1080, True), (2560, 1440, False), (1000, 520, False)])
+def test_v23_large_and_odd_grids_within_1_lsb(modeldirs, w, h, uhd):
+    """The round-5 kernels of the v2 schedule at the sizes their grids have not seen in the other tests: stem2_fused_kernel on 4K frames (scale 1: 480 x 136 = 65,280
+    tiles; 64-bit output offsets), on the UHD half-resolution float4 frames (ImgF4 instantiations, scale 1 and 2), on tile rows / columns that are not whole
+    (1440 / 8 = 180, 1000 x 520), the two-tensor ContextNet launches and the batched warps at the same sizes."""
+    d = modeldirs["rife-v2.3"]
+    g = amd.RIFE(0, uhd_mode=uhd, rife_v2=True); g.load(d)
+    o = pyoracle.OracleRIFE(uhd_mode=uhd, rife_v2=True); o.set_gpu_crop(1); o.load(d)
+    a, b = gen_frames.smooth_pair(w, h, 31)
+    got, want = g.process(a, b, 0.5), o.process(a, b, 0.5)
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and (diff == 0).mean() > 0.999, (w, h, uhd, int(diff.max()), float((diff == 0).mean()))
+    assert np.array_equal(g.process(a, b, 0.5), got)                      # deterministic on a used workspace
+
+
 def test_v23_endpoints_and_determinism(engines):
     g, _ = engines
     a, b = gen_frames.smooth_pair(96, 64, 9)
