@@ -182,6 +182,15 @@ __device__ __forceinline__ void flow_upsampled(const float* __restrict__ flow, i
     um = RIFE_UP(m00, m01, m10, m11);
 #undef RIFE_UP
 }
+// the FIRST update (after block 0): F = u[0:4] * S, M = u[4] (k_flow_update<S, true>)
+template <int S>
+__device__ __forceinline__ void flow_first(const float* __restrict__ flow, int wp, int hp, int x, int y, float4& f, float& m) {
+    float4 u; float um;
+    flow_upsampled<S>(flow, wp, hp, x, y, u, um);
+    const float s = (float)S;
+    f = make_float4(u.x * s, u.y * s, u.z * s, u.w * s);
+    m = um;
+}
 template <int S>
 __device__ __forceinline__ void flow_accumulate(const float4 u, const float um, float4& f, float& m) {
     const float s = (float)S;
@@ -200,17 +209,21 @@ struct FlowPending {
 // Blocks 1..3 input (flownet.param:52-62, 107-115, 160-165):
 //   x = Concat(Interp(1/S)(Concat(warp(in0,F.xy), warp(in1,F.zw), in2, M)), Interp(1/S)(F)/S)  -> NHWC16 (12 + 4 zero)
 // one pixel (bx, by) of the block input at 1/S resolution: 12 channels {warp(in0,F.xy) rgb, warp(in1,F.zw) rgb, t, M, F/S xyzw}
-// UPD: the flow update of the previous block (scale 2 S) is applied on the way: every full-resolution pixel read here is updated and written
+// UPD = 1: the flow update of the previous block (scale 2 S) is applied on the way: every full-resolution pixel read here is updated and written
 // to pend.Fw / pend.Mw (same arithmetic as k_flow_update<2 S>: the 12 channels are those of the unfused sequence bit for bit).
-template <int S, bool UPD = false>
+// UPD = 2 (round 5; block 1): F, M do not exist yet - they are what k_flow_update<2 S, FIRST> would have written from the first flow, computed here for the pixels
+// that are sampled (F = Interp(2 S)(flow0) * 2 S, M = its mask channel: flow0 is [hp / 8][wp / 8][8] fp32, L2-resident) and written nowhere; k_flow_update2
+// produces the full-resolution tensors after this block in one pass together with this block's own update.
+template <int S, int UPD = 0>
 __device__ __forceinline__ void assemble_pixel(const uint32_t* __restrict__ img0, const uint32_t* __restrict__ img1, float timestep,
                                                const float4* __restrict__ F, const float* __restrict__ M, int wp, int hp, int x, int y, float o[12],
                                                const FlowPending& pend = FlowPending{}) {
     if (S == 1) {
         const size_t i = (size_t)y * wp + x;
-        float4 f = F[i];
-        float mk = M[i];
-        if (UPD) {
+        float4 f; float mk;
+        if (UPD == 2) flow_first<2 * S>(pend.flow, wp, hp, x, y, f, mk);
+        else { f = F[i]; mk = M[i]; }
+        if (UPD == 1) {
             float4 u; float um;
             flow_upsampled<2 * S>(pend.flow, wp, hp, x, y, u, um);
             flow_accumulate<2 * S>(u, um, f, mk);
@@ -227,9 +240,10 @@ __device__ __forceinline__ void assemble_pixel(const uint32_t* __restrict__ img0
         for (int k = 0; k < 4; k++) {
             const int px = sx + (k & 1), py = sy + (k >> 1);
             const size_t i = (size_t)py * wp + px;
-            float4 f = F[i];
-            float mk = M[i];
-            if (UPD) {
+            float4 f; float mk;
+            if (UPD == 2) flow_first<2 * S>(pend.flow, wp, hp, px, py, f, mk);
+            else { f = F[i]; mk = M[i]; }
+            if (UPD == 1) {
                 float4 u; float um;
                 flow_upsampled<2 * S>(pend.flow, wp, hp, px, py, u, um);
                 flow_accumulate<2 * S>(u, um, f, mk);
@@ -285,6 +299,24 @@ __global__ void k_flow_update(const float* __restrict__ flow, float4* __restrict
         F[i] = f;
         M[i] = m;
     }
+}
+
+// The updates after blocks 0 and 1 in ONE pass over the full-resolution tensors (round 5): F, M = k_flow_update<S1, false> applied to what
+// k_flow_update<S0, true> would have written - the same two expressions in the same order, so the tensors are the two-kernel sequence's bit for bit, without the
+// 20 B / pixel written after block 0 and read again after block 1 (4K: 200 + 178 MB per pair and one launch).  Block 1's stem samples the first update itself
+// (assemble_pixel UPD = 2).
+template <int S0, int S1>
+__global__ void k_flow_update2(const float* __restrict__ flow0, const float* __restrict__ flow1, float4* __restrict__ F, float* __restrict__ M, int wp, int hp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= wp) return;
+    float4 f; float m;
+    flow_first<S0>(flow0, wp, hp, x, y, f, m);
+    float4 u; float um;
+    flow_upsampled<S1>(flow1, wp, hp, x, y, u, um);
+    flow_accumulate<S1>(u, um, f, m);
+    const size_t i = (size_t)y * wp + x;
+    F[i] = f;
+    M[i] = m;
 }
 
 // Tail of the graph + postproc (flownet.param:202-217, rife.cpp:4373-4397 / rife_postproc.comp:39-62):

@@ -1336,7 +1336,7 @@ static bool flow_update_fused_into(const rife_hip& E, const Ctx& c, int b) {
 
 // upd_flow != null: the flow of block b - 1, whose update of F, M this block's stem applies itself (flow_update_fused_into); F, M swap with F2, M2
 static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, const FinalArgs* fin = nullptr, const float* tsp = nullptr, int phases = PH_ALL,
-                           const float* upd_flow = nullptr) {
+                           const float* upd_flow = nullptr, const float* first_flow = nullptr) {
     const rife_hip::Block& B = E.blk[b];
     hipStream_t st = c.stream;
     const int s = B.scale, Hb = c.hp / s, Wb = c.wp / s;
@@ -1362,6 +1362,7 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<4, 2, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
                 fdone[dev] = true;
             }
         }
@@ -1371,12 +1372,16 @@ static int run_block_convs(const rife_hip& E, Ctx& c, int b, float timestep, con
             if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2, 0, true>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
             else hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256, true>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);
             std::swap(c.F, c.F2); std::swap(c.M, c.M2);
+        } else if (first_flow) {      // block 1 right after block 0: F, M are not materialised yet, the stem samples the first update itself (first_flow_merged)
+            if (s != 4) return fail(RIFE_HIP_EINVAL, "the first flow update is sampled by the scale-4 stem only");
+            fa.pend.flow = first_flow;
+            hipLaunchKernelGGL((stem0_fused_kernel<4, 2, 0, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
         } else if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
         else if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
         else hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);      // 64-byte swizzled records, three workgroups per CU
         HIPCHK(hipGetLastError());
     } else {
-        if (upd_flow) return fail(RIFE_HIP_EINVAL, "fused flow update without the fused stem");
+        if (upd_flow || first_flow) return fail(RIFE_HIP_EINVAL, "fused flow update without the fused stem");
         if (b > 0 && (rc = run_assemble(E, c, b, timestep, tsp))) return rc;
         Timed t(E.prof, B.stem0.cls, B.stem0.flops_per_pixel * (Hb / 2) * (Wb / 2), st);
         if ((rc = launch_conv(B.stem0, {c.X, xin_ld, 0}, Hb, Wb, {c.S1, B.c / 2, 0}, nullptr, st))) return rc;
@@ -1485,9 +1490,22 @@ static int run_v4(const rife_hip& E, Ctx& c, const uint8_t* d_in0, const uint8_t
     const bool fuse_tail = !E.v40 && g_trunk_h2 && g_head_h2 && g_fuse_tail && E.blk[3].head.d_wh != nullptr;
     FinalArgs fin{c.img0, c.img1, c.F, c.M, d_out, c.w, c.h, c.wp, c.hp};
     const float* pending = nullptr;                                      // flow whose update of F, M the next block's stem applies
+    // The update after block 0 never reaches HBM on its own (round 5): block 1's scale-4 stem samples it from flow0 (assemble_pixel UPD = 2) and ONE pass after
+    // block 1 writes F, M with both updates applied (k_flow_update2) - bit for bit the tensors of the two-kernel sequence, one launch and 20 B / pixel of writes +
+    // 20 B / pixel of reads less.  RIFE_HIP_MERGE_FLOW0=0 (A/B, test build): the three separate updates.
+    const bool merge_env = env_not_off(ab_getenv("RIFE_HIP_MERGE_FLOW0"));      // per call (a null constant in the product)
+    const bool merge0 = merge_env && !E.v40 && g_trunk_h2 && g_fuse_stem && E.blk[1].stem0.d_wh != nullptr && E.blk[1].scale == 4 && !flow_update_fused_into(E, c, 1) &&
+                        !flow_update_fused_into(E, c, 2);
     for (int b = 0; b < 4; b++) {
-        if ((rc = run_block_convs(E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr, tsp, PH_ALL, pending))) return rc;
+        if ((rc = run_block_convs(E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr, tsp, PH_ALL, pending, (merge0 && b == 1) ? c.flow[0] : nullptr))) return rc;
         pending = nullptr;
+        if (merge0 && b == 0) continue;
+        if (merge0 && b == 1) {
+            Timed t(E.prof, "flow_update", 0, st);
+            hipLaunchKernelGGL((k_flow_update2<8, 4>), grid2d(c.wp, c.hp), dim3(256), 0, st, c.flow[0], c.flow[1], c.F, c.M, c.wp, c.hp);
+            HIPCHK(hipGetLastError());
+            continue;
+        }
         if (b < 3 && flow_update_fused_into(E, c, b + 1)) pending = c.flow[b];
         else if ((b < 3 || E.v40) && (rc = run_flow_update(E, c, b))) return rc;
     }

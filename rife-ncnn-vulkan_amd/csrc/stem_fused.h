@@ -40,9 +40,9 @@ constexpr int stemf_lds_bytes() { return (9 * 65 + 1) * stemf_pixb<ABL>() + 9 * 
 // UPD: k_flow_update<2 S> of the block before (flownet.param:99-105, 152-158) happens here: the kernel visits every full-resolution pixel (S <= 2)
 // anyway, so F, M make one round trip less through HBM per block and the launch disappears; halo pixels shared by tiles are written twice with
 // the same value, into the other F, M buffer.
-template <int S, int NS, int ABL = 0, bool UPD = false>
+template <int S, int NS, int ABL = 0, int UPD = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((ABL & 256) ? 6 : 4, (ABL & 256) ? 6 : 4))) void stem0_fused_kernel(StemFusedArgs a) {
-    static_assert(!UPD || S <= 2, "the scale-4 stem samples a quarter of the full-resolution pixels");
+    static_assert(UPD != 1 || S <= 2, "the scale-4 stem samples a quarter of the full-resolution pixels: it cannot write the updated tensors (UPD = 1), only sample the first update (UPD = 2)");
     constexpr int IH = 9, IW = 65, PIXB = stemf_pixb<ABL>(), NT = NS * 32;
     constexpr int NPIX = IH * IW;
     constexpr int W_16 = 9 * 2 * NT;

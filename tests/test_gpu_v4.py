@@ -313,3 +313,17 @@ def test_hipgraph_replay_is_opt_in_and_bit_identical(engines, modeldirs):
         a, b = gen_frames.smooth_pair(int(w), int(h), 40 + int(i))
         want = hashlib.md5(g.process(a, b, (0.5, 0.25, 0.7, 0.9, 0.125)[int(i)]).tobytes()).hexdigest()
         assert md5 == want, (w, h, i)
+
+
+@pytest.mark.parametrize("w,h,seed", [(640, 360, 1), (100, 60, 2), (33, 47, 3), (1920, 1080, 4), (3840, 2160, 5)])
+def test_merged_first_flow_update_is_bit_identical(engines, modeldirs, w, h, seed, monkeypatch):
+    """Round 5: the update after block 0 is sampled by block 1's stem from flow0 (assemble_pixel UPD = 2) and written together with block 1's update in one
+    pass (k_flow_update2; flownet.param:47-58, 99-105) - against the three separate k_flow_update launches (RIFE_HIP_MERGE_FLOW0=0, test build): the same
+    expressions in the same order, so the frames are the same bytes."""
+    g, _ = engines
+    monkeypatch.setenv("RIFE_HIP_MERGE_FLOW0", "0")           # read by every plain pass of the test build (the product ignores it)
+    g0 = amd_t.RIFE(0, rife_v4=True); g0.load(modeldirs["rife-v4.6"])
+    a, b = (gen_frames.noise_pair if seed % 2 else gen_frames.smooth_pair)(w, h, 60 + seed)
+    for t in (0.5, 0.2):
+        x0, x1 = g0.process(a, b, t), g.process(a, b, t)
+        assert np.array_equal(x0, x1), "%d bytes differ" % int((x0 != x1).sum())
