@@ -672,6 +672,120 @@ int rife_hip_bench_rs(int gpuid, int h, int w, int variant, int iters, float* ms
     return rc;
 }
 
+// bench-only: the depth-fused trunk kernel (conv_rs2.h) on an h x w tensor of random records, two random layers A and B.  With `stats`: its output (walking
+// down, then up) against conv_rs_kernel(A) followed by conv_rs_kernel(B) - the same bytes are expected: stats[0] / stats[1] = differing bytes (down / up),
+// stats[2] = bytes compared, stats[3], [4], [5] = plane, padded row, padded column of the first difference (down), stats[6] = segments per strip, stats[7] = workgroups.
+// Then `iters` launches ping-pong between two tensors.  variant = ablation bits of conv_rs.h | 0x10000 (launches alternate direction) | 0x20000 (always up)
+// | 0x1000000 * g (g > 0: plan for g compute units instead of the chip's).
+int rife_hip_bench_rs2(int gpuid, int h, int w, int variant, int iters, float* ms_out, long long* stats) {
+    tl_cu_budget = 0;
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    std::vector<float> wts((size_t)64 * 64 * 9), bias(64);
+    uint32_t lcg = 777u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((int)(lcg >> 9) - (1 << 22)) / (float)(1 << 22); };   // [-1, 1)
+    std::vector<unsigned char> img[2];
+    for (int l = 0; l < 2; l++) {
+        for (auto& v : wts) v = (float)(_Float16)(rnd() * 0.03f);
+        for (auto& v : bias) v = rnd() * 0.1f;
+        img[l] = pack_t64_image(wts.data(), bias.data(), 0.2f);
+    }
+    const S16Geom G(h, w);
+    const size_t nb = G.bytes(64);
+    unsigned char *x = nullptr, *y = nullptr, *yr = nullptr, *tm = nullptr, *dimg[2] = {nullptr, nullptr};
+    HIPCHK(hipMalloc(&x, nb)); HIPCHK(hipMalloc(&y, nb)); HIPCHK(hipMalloc(&yr, nb)); HIPCHK(hipMalloc(&tm, nb));
+    for (int l = 0; l < 2; l++) { HIPCHK(hipMalloc(&dimg[l], img[l].size())); HIPCHK(hipMemcpy(dimg[l], img[l].data(), img[l].size(), hipMemcpyHostToDevice)); }
+    {
+        std::vector<_Float16> hx(nb / 2, (_Float16)0.f);
+        const size_t pl = G.plane() / 2;
+        for (int yy = 0; yy < h; yy++)
+            for (int xx = 0; xx < w; xx++)
+                for (int c = 0; c < 4; c++)
+                    for (int e = 0; e < 16; e++) {
+                        const float v = rnd(); const _Float16 hh = (_Float16)v;
+                        const size_t px = ((size_t)(yy + 1) * G.pitch + xx + 1) * 16 + e;
+                        hx[(2 * c) * pl + px] = hh; hx[(2 * c + 1) * pl + px] = (_Float16)(v - (float)hh);
+                    }
+        HIPCHK(hipMemcpy(x, hx.data(), nb, hipMemcpyHostToDevice));
+    }
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpuid));
+    const int gover = (variant >> 24) & 0xff;
+    const int plan_cus = gover ? gover : cus;
+    int kparts, nstrips;
+    const int rmin = rs2_plan(h, w, plan_cus, kparts, nstrips);
+    if (rmin < 1) return fail(RIFE_HIP_EINVAL, "conv_rs2 bench: empty segments");
+    Rs2Args a;
+    a.in = x; a.out = y; a.imgA = dimg[0]; a.imgB = dimg[1]; a.H = h; a.W = w; a.pitch = G.pitch; a.plane = G.plane(); a.rowmax = G.pitch - 2;
+    a.kparts = kparts; a.nseg = nstrips * kparts; a.descend = 0; a.limit = (int)(nb - 16);
+    const int nwg = std::min(plan_cus, a.nseg);
+    const bool alternate = (variant & 0x10000) != 0, up = (variant & 0x20000) != 0;
+    variant &= 0xffff | RS_CLK;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rs2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, RS2_LDS));
+    if (stats) {
+        for (int i = 0; i < 8; i++) stats[i] = -1;
+        std::vector<unsigned char> ref(nb), got(nb);
+        if ((h + 1) / 2 >= RS_MIN_PAIRS) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS));
+            RsArgs r;
+            r.in = x; r.out = tm; r.img = dimg[0]; r.H = h; r.W = w; r.pitch = G.pitch; r.plane = G.plane(); r.npairs = (h + 1) / 2; r.nunits = G.tiles_x * r.npairs; r.descend = 0;
+            const int rwg = std::min(cus, r.nunits);
+            HIPCHK(hipMemset(tm, 0, nb)); HIPCHK(hipMemset(yr, 0, nb));
+            hipLaunchKernelGGL((conv_rs_kernel<0>), dim3(rwg), dim3(RS_NTHR), RS_LDS, 0, r);
+            r.in = tm; r.out = yr; r.img = dimg[1];
+            hipLaunchKernelGGL((conv_rs_kernel<0>), dim3(rwg), dim3(RS_NTHR), RS_LDS, 0, r);
+        } else {                                                         // tiny tensors: conv_t64 twice (conv_rs needs 7 rows) - another summation order, bytes differ
+            return fail(RIFE_HIP_EINVAL, "conv_rs2 bench check needs at least 7 rows");
+        }
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(ref.data(), yr, nb, hipMemcpyDeviceToHost));
+        for (int dir = 0; dir < 2; dir++) {
+            HIPCHK(hipMemset(y, 0, nb));
+            a.descend = dir;
+            hipLaunchKernelGGL((conv_rs2_kernel<0>), dim3(nwg), dim3(RS2_NTHR), RS2_LDS, 0, a);
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMemcpy(got.data(), y, nb, hipMemcpyDeviceToHost));
+            long long bad = 0;
+            for (size_t i = 0; i < nb; i++)
+                if (ref[i] != got[i]) {
+                    if (!bad && dir == 0) { stats[3] = (long long)(i / G.plane()); stats[4] = (long long)(i % G.plane() / ((size_t)G.pitch * 32)); stats[5] = (long long)(i % ((size_t)G.pitch * 32) / 32); }
+                    bad++;
+                }
+            stats[dir] = bad;
+        }
+        stats[2] = (long long)nb; stats[6] = kparts; stats[7] = nwg;
+        a.descend = 0;
+    }
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](auto kfn) -> int {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, RS2_LDS));
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(RS2_NTHR), RS2_LDS, 0, a);
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; i++) {
+            a.in = (i & 1) ? y : x; a.out = (i & 1) ? x : y;
+            a.descend = up ? 1 : (alternate ? (i & 1) : 0);
+            hipLaunchKernelGGL(kfn, dim3(nwg), dim3(RS2_NTHR), RS2_LDS, 0, a);
+        }
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        *ms_out = t / iters;
+        return 0;
+    };
+    if (iters > 0) switch (variant) {
+        case 0: rc = run(conv_rs2_kernel<0>); break;
+        case RS_NOSTORE: rc = run(conv_rs2_kernel<RS_NOSTORE>); break;
+        case RS_NODMA: rc = run(conv_rs2_kernel<RS_NODMA>); break;
+        case RS_NOMATH: rc = run(conv_rs2_kernel<RS_NOMATH>); break;
+        case RS_NODMA | RS_NOSTORE: rc = run(conv_rs2_kernel<RS_NODMA | RS_NOSTORE>); break;
+        case RS_NOMATH | RS_NOSTORE: rc = run(conv_rs2_kernel<RS_NOMATH | RS_NOSTORE>); break;
+        case RS_NOMATH | RS_NODMA: rc = run(conv_rs2_kernel<RS_NOMATH | RS_NODMA>); break;
+        default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
+    }
+    (void)hipFree(x); (void)hipFree(y); (void)hipFree(yr); (void)hipFree(tm); (void)hipFree(dimg[0]); (void)hipFree(dimg[1]); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
 // probe of the block-scaled fp8 matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4, both operands e4m3): raw per-lane operand dwords in, the
 // wave's 16 accumulator registers per lane out; the scale dwords go through VGPRs (tools/probes/mx_probe.py pins the operand layout against numpy)
 __global__ void k_probe_mx(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t sa, uint32_t sb, float* __restrict__ d) {

@@ -46,6 +46,7 @@
 #include "conv_t64.h"
 #include "conv_row.h"
 #include "conv_rs.h"
+#include "conv_rs2.h"
 #ifdef RIFE_HIP_TEST_BUILD
 #include "conv_ks.h"      // round-4 K-split trunk kernel: opt-in (RIFE_HIP_KS), measured slower with pairs in flight; not compiled into the product
 #endif
@@ -804,6 +805,55 @@ static int launch_rs(const ConvLayer& L, const unsigned char* in, unsigned char*
     return 0;
 }
 
+// TWO consecutive 64 -> 64 layers in one launch of the depth-fused row-streaming kernel (conv_rs2.h): layer A's rows stay in LDS.  Strips of 30 columns,
+// every strip cut into kparts equal row ranges so that every CU of the (part of the) chip has one segment.  rs2_applies: false where the fused form
+// does not apply - fewer than RS2_MIN_ROWS rows per segment, or a tensor of 2 GB and more (signed 32-bit DMA offsets) - and the caller runs two
+// conv_rs launches instead: the bytes are the same either way.
+static int rs2_plan(int H, int W, int cus, int& kparts, int& nstrips) {
+    nstrips = (W + RS2_SW - 1) / RS2_SW;
+    kparts = std::max(1, cus / nstrips);
+    kparts = std::min(kparts, std::max(1, H / RS2_MIN_ROWS));
+    return H / kparts;                                                  // rows of the shortest segment
+}
+static int rs2_cus() {
+    int dev = 0; (void)hipGetDevice(&dev);
+    static std::mutex mu; static std::map<int, int> ncu;
+    int cus;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = ncu.find(dev);
+        if (it == ncu.end()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rs2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, RS2_LDS) != hipSuccess) return 0;
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+            it = ncu.emplace(dev, std::max(1, n)).first;
+        }
+        cus = it->second;
+    }
+    if (tl_cu_budget > 0) cus = std::min(cus, tl_cu_budget);
+    return cus;
+}
+static bool rs2_applies(int H, int W) {
+    int kparts, nstrips;
+    const int cus = rs2_cus();
+    return cus > 0 && S16Geom(H, W).bytes(64) < (1ull << 31) && rs2_plan(H, W, cus, kparts, nstrips) >= RS2_MIN_ROWS;
+}
+static int launch_rs2(const ConvLayer& LA, const ConvLayer& LB, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, bool descend = false) {
+    if (!LA.d_t64 || LA.cout != 64 || !LB.d_t64 || LB.cout != 64) return fail(RIFE_HIP_EINVAL, "layer has no 64-channel conv_t64 image");
+    const S16Geom G(H, W);
+    const int cus = rs2_cus();
+    int kparts, nstrips;
+    if (cus <= 0 || G.bytes(64) >= (1ull << 31) || rs2_plan(H, W, cus, kparts, nstrips) < RS2_MIN_ROWS) return fail(RIFE_HIP_EINVAL, "conv_rs2 does not apply to this tensor");
+    Rs2Args a;
+    a.in = in; a.out = out; a.imgA = LA.d_t64; a.imgB = LB.d_t64; a.H = H; a.W = W; a.pitch = G.pitch; a.plane = G.plane(); a.rowmax = G.pitch - 2;
+    a.kparts = kparts; a.nseg = nstrips * kparts; a.descend = descend ? 1 : 0; a.limit = (int)(G.bytes(64) - 16);
+    const int nwg = std::min(cus, a.nseg);                               // one workgroup per CU (all of its LDS), all resident
+    hipLaunchKernelGGL((conv_rs2_kernel<0>), dim3(nwg), dim3(RS2_NTHR), RS2_LDS, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("conv_rs2 launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
 // one C -> C (C = 128, 192) residual trunk convolution of a coarse block, S16 in / S16 out: one workgroup per ROWS x 32 pixels (conv_row.h)
 // nb > 0: one launch for the tensors inb[k] -> outb[k] of nb pairs in flight (gridDim.y = nb)
 static int launch_row(const ConvLayer& L, const unsigned char* in, unsigned char* out, int H, int W, hipStream_t st, int nb = 0,
@@ -1052,6 +1102,8 @@ struct rife_hip {
     bool t64 = true;
     // block-3 trunk on the row-streaming kernel (conv_rs.h) instead of conv_t64 (RIFE_HIP_RS=0 at create time: A/B, bit-equality test)
     bool rs = true;
+    // ... two layers per launch, layer A's rows LDS-resident (conv_rs2.h; RIFE_HIP_RS2=0 at create time: A/B, bit-equality test)
+    bool rs2 = true;
     // coarse-block trunks on the weight-stationary K-split kernel (conv_ks.h): bit mask by channel count, see launch_ks (RIFE_HIP_KS at create time)
     int ks_mask = 0;
     // block 3: block-input assembly + both stem convolutions in one row-streaming kernel (stem_rs.h) instead of stem0_fused_kernel + conv_h2s2_kernel
@@ -1415,6 +1467,12 @@ after_stem0:
         }
         unsigned char *pc = PA, *pn = PB;
         if (phases & PH_TRUNK) for (int i = 0; i < 8; i++) {
+            if (!rowk && E.rs && E.rs2 && B.c == 64 && !(i & 1) && rs2_applies(Ht, Wt)) {      // layers i, i + 1 in one launch (conv_rs2.h)
+                Timed t(E.prof, B.res[i].cls, (B.res[i].flops_per_pixel + B.res[i + 1].flops_per_pixel) * Ht * Wt, st);
+                if ((rc = launch_rs2(B.res[i], B.res[i + 1], pc, pn, Ht, Wt, st, (i & 2) != 0))) return rc;
+                std::swap(pc, pn); i++;
+                continue;
+            }
             Timed t(E.prof, B.res[i].cls, B.res[i].flops_per_pixel * Ht * Wt, st);
             if (rowk && ks_serves(E.ks_mask, B.c)) rc = launch_ks(B.res[i], pc, pn, Ht, Wt, st);
             else if (rowk) rc = launch_row(B.res[i], pc, pn, Ht, Wt, st);
@@ -2475,6 +2533,7 @@ rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int 
     E->frame_pool->gpuid = gpuid;
     { const char* e = ab_getenv("RIFE_HIP_T64"); E->t64 = !(e && e[0] == '0'); }
     { const char* e = ab_getenv("RIFE_HIP_RS"); E->rs = !(e && e[0] == '0'); }
+    { const char* e = ab_getenv("RIFE_HIP_RS2"); E->rs2 = !(e && e[0] == '0'); }
     { const char* e = ab_getenv("RIFE_HIP_KS"); if (e && e[0] >= '0' && e[0] <= '9') E->ks_mask = atoi(e); }
     { const char* e = ab_getenv("RIFE_HIP_STEM_RS"); E->stem_rs = !(e && e[0] == '0'); }
     { const char* e = ab_getenv("RIFE_HIP_TTA_CONSENSUS"); E->tta_consensus = !(e && e[0] == '0'); }

@@ -122,3 +122,48 @@ def test_rs_tta_passes_match(modeldirs):
     a, b = gen_frames.smooth_pair(100, 60, 11)
     d = np.abs(new.process(a, b, 0.4).astype(np.int32) - old.process(a, b, 0.4).astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+# ---- round 6: two trunk layers per launch (csrc/conv_rs2.h: layer A's rows stay in LDS) against one conv_rs launch per layer (RIFE_HIP_RS2=0) ----
+def _engine_rs2(modeldir, rs2, **kw):
+    old = os.environ.get("RIFE_HIP_RS2")
+    os.environ["RIFE_HIP_RS2"] = "1" if rs2 else "0"      # read by rife_hip_create
+    try:
+        g = amd.RIFE(0, rife_v4=True, **kw)
+    finally:
+        if old is None:
+            del os.environ["RIFE_HIP_RS2"]
+        else:
+            os.environ["RIFE_HIP_RS2"] = old
+    g.load(modeldir)
+    return g
+
+
+@pytest.fixture(scope="module")
+def pair_rs2(modeldirs):
+    d = modeldirs["rife-v4.6"]
+    return _engine_rs2(d, True), _engine_rs2(d, False)
+
+
+@pytest.mark.parametrize("w,h,t,seed", [(640, 360, 0.5, 1), (256, 192, 0.125, 2), (100, 60, 0.7, 3), (33, 47, 0.9, 4), (1, 1, 0.5, 5), (130, 9, 0.5, 12), (117, 250, 0.5, 13),
+                                        (1920, 1080, 0.5, 6), (1000, 520, 0.3, 7), (3840, 2160, 0.5, 8)])
+def test_rs2_output_is_bit_identical_to_one_launch_per_layer(pair_rs2, w, h, t, seed):
+    """Per layer the products, their order and the epilogue are conv_rs_kernel's, and the LDS ring between the two layers holds the {hi, lo} pairs conv_rs
+    would have stored: frames and block-3 flows are the same BYTES, at aligned, ragged and tiny sizes, on a used workspace (zero borders intact), run to run."""
+    new, old = pair_rs2
+    a, b = gen_frames.smooth_pair(w, h, seed) if w * h < 4000000 else gen_frames.smooth_pair_native(w, h, seed)
+    for x, y, tt in ((a, b, t), (b, a, 1.0 - t)):
+        got, want = new.process(x, y, tt), old.process(x, y, tt)
+        assert np.array_equal(got, want), "%dx%d: %d of %d bytes differ" % (w, h, int((got != want).sum()), got.size)
+    if w * h <= 1920 * 1080:
+        assert np.array_equal(new.v4_extract_flow(a, b, t, 3), old.v4_extract_flow(a, b, t, 3)), "block-3 flows differ at %dx%d" % (w, h)
+    x = new.process(a, b, t)
+    for _ in range(3):
+        assert np.array_equal(x, new.process(a, b, t)), "the depth-fused kernel is not deterministic"
+
+
+def test_rs2_tta_passes_are_bit_identical(modeldirs):
+    d = modeldirs["rife-v4.6"]
+    new, old = _engine_rs2(d, True, tta_mode=True, tta_temporal_mode=True), _engine_rs2(d, False, tta_mode=True, tta_temporal_mode=True)
+    a, b = gen_frames.smooth_pair(200, 120, 11)
+    assert np.array_equal(new.process(a, b, 0.4), old.process(a, b, 0.4))
