@@ -38,7 +38,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA pea
 HBM_PEAK_TBPS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak
 # dominant kernel per family: (profile class, kernel symbol, channels C of the C->C 3x3 trunk conv, MFMA instructions issued per
 # algorithmic product: 2 for the split-f16 scheme (hi and lo) x the identity tap of the folded skip connection)
-DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_rs_kernel (IFNet block-3 trunk: 3x3 conv 64->64 + skip + LeakyReLU; row-streaming, specialised waves; split-f16 MFMA, S16 {hi, lo} tensors)", 64, 2.0 * 38 / 36),
+DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_rs2_kernel (IFNet block-3 trunk: TWO 3x3 convs 64->64 + skip + LeakyReLU per launch, the first layer's rows LDS-resident; row-streaming, specialised waves; split-f16 MFMA, S16 {hi, lo} tensors)", 64, 2.0 * 38 / 36),
             "rife-v2.3": ("v2_flow_trunk_b3", "conv_h2_kernel<3,9,0> (IFNet block-3 trunk: 3x3 conv 96->96 + PReLU, split-f16)", 96, 2.0)}
 
 
@@ -50,15 +50,21 @@ def roofline_of(dom, family, w, h, f32_mode):
         at 1/4 of the padded resolution + fp16 weights (4K block 3: 133.8 MB).  `achieved` and `frac` use these.
       * `bytes_per_launch_stored` = what the kernel really moves: activations are stored as {hi, lo} f16 pairs (4 B per element, the
         fp32-equivalent precision the <= 1 LSB bar needs) -> twice the bytes; `frac_stored_bytes` uses these.
-    Algorithmic flops = 2*C*C*9 per output pixel (38.50 GFLOP at 4K); the split scheme issues 2 x 38/36 as many MFMA flops."""
+    Algorithmic flops = 2*C*C*9 per output pixel (38.50 GFLOP at 4K); the split scheme issues 2 x 38/36 as many MFMA flops.
+    Round 6: a launch of conv_rs2_kernel processes TWO layers (`layers_per_launch`, from the flops the engine books per launch): the algorithmic bytes
+    per launch are SURVEY 8(d)'s per-layer figure x 2 units, the bytes it really moves are ONE input and ONE output tensor (the tensor between the two
+    layers stays in LDS) - `bytes_per_launch_stored` - so on the survey basis `traffic` can now be BELOW `bytes_per_launch`."""
     cls, name, C, mfma_factor = DOMINANT[family]
     if not dom["launches"]:
         return None
     wp, hp = (w + 31) // 32 * 32, (h + 31) // 32 * 32
     pix = (hp // 4) * (wp // 4)
-    bytes_alg = 2.0 * pix * C * 2 + C * C * 9 * 2
-    bytes_stored = 2.0 * pix * C * 4 + C * C * 9 * 2
     flops_launch = dom["flops"] / dom["launches"]
+    layers = max(1, int(round(flops_launch / (2.0 * C * C * 9 * pix))))
+    if layers == 1:
+        name = name.replace("conv_rs2_kernel", "conv_rs_kernel").replace("TWO 3x3 convs", "3x3 conv").replace(" per launch, the first layer's rows LDS-resident", "")
+    bytes_alg = layers * (2.0 * pix * C * 2 + C * C * 9 * 2)
+    bytes_stored = 2.0 * pix * C * 4 + layers * C * C * 9 * 2
     avg_ms = dom["ms"] / dom["launches"]
     tflops = flops_launch / (avg_ms * 1e-3) / 1e12
     tbps = bytes_alg / (avg_ms * 1e-3) / 1e12
@@ -69,14 +75,14 @@ def roofline_of(dom, family, w, h, f32_mode):
                 "launches": dom["launches"], "flops_per_launch": flops_launch, "bytes_per_launch": bytes_alg}
     return {"bound": "hbm", "kernel": name, "achieved": round(tbps * 1e3, 1), "peak": HBM_PEAK_TBPS * 1e3, "unit": "GB/s",
             "frac": round(tbps / HBM_PEAK_TBPS, 4), "frac_survey_basis": round(tbps / HBM_PEAK_TBPS, 4), "traffic": None,
-            "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
-            "flops_per_launch": flops_launch, "bytes_per_launch": bytes_alg, "bytes_basis": "algorithmic: fp16 in + fp16 out + fp16 weights (SURVEY 8(d), App. E-2)",
+            "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"], "layers_per_launch": layers,
+            "flops_per_launch": flops_launch, "bytes_per_launch": bytes_alg, "bytes_basis": "algorithmic: (fp16 in + fp16 out + fp16 weights) per layer (SURVEY 8(d), App. E-2) x layers_per_launch",
             "bytes_per_launch_stored": bytes_stored, "achieved_stored_GBps": round(tbps_stored * 1e3, 1), "frac_stored_bytes": round(tbps_stored / HBM_PEAK_TBPS, 4),
             "algorithmic_tflops": round(tflops, 1), "mfma_frac_survey_basis": round(tflops / F16_MFMA_PEAK_TFLOPS, 4),
             "mfma_frac_issued": round(tflops * mfma_factor / F16_MFMA_PEAK_TFLOPS, 4)}
 
 
-DOMINANT_SYMBOL = {"rife-v4.6": "conv_rs_kernel", "rife-v2.3": "conv_h2_kernel<3, 9, 0>"}
+DOMINANT_SYMBOL = {"rife-v4.6": ("conv_rs2_kernel", "conv_rs_kernel"), "rife-v2.3": ("conv_h2_kernel<3, 9, 0>",)}      # first symbol with dispatches in the trace
 
 
 def live_traffic(workload, family, timeout_s=150):
@@ -100,9 +106,13 @@ def live_traffic(workload, family, timeout_s=150):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s failed (rc %d)" % (ctr, r.returncode)
-            rows = pmc_summary.summarize(files[0], DOMINANT_SYMBOL[family])
+            rows = None
+            for sym in DOMINANT_SYMBOL[family]:
+                rows = pmc_summary.summarize(files[0], sym)
+                if rows:
+                    break
             if not rows:
-                return None, "no dispatch of %s in the %s pass" % (DOMINANT_SYMBOL[family], ctr)
+                return None, "no dispatch of %s in the %s pass" % (" / ".join(DOMINANT_SYMBOL[family]), ctr)
             vals[ctr] = sum(dd[ctr] * dd["_dispatches"] for _, dd in rows) / sum(dd["_dispatches"] for _, dd in rows)
         except Exception as e:
             return None, "%s pass: %s" % (ctr, e)
@@ -397,7 +407,7 @@ def main():
                 roof["traffic"], roof["traffic_source"] = tb, src
             else:
                 roof["traffic_live_failed"] = src
-        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "pmc_%s.json" % args.workload.replace("-", "_")) for r in ("r4", "r3", "r2")) if os.path.exists(f)), "")
+        traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "pmc_%s.json" % args.workload.replace("-", "_")) for r in ("r6", "r5", "r4", "r3", "r2")) if os.path.exists(f)), "")
         if roof is not None and roof.get("traffic") is None and traffic_file:
             tf = json.load(open(traffic_file))                   # from the committed rocprofv3 --pmc passes (not live)
             roof["traffic"] = tf["hbm_bytes_per_launch"]
@@ -406,6 +416,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(modeldir, family, w * h, 16 if tta and tta_temporal else 1, (w, h))
         fps = world * args.steps / elapsed
+        # roofline.e2e_frac: the whole pair against the fused-minimum HBM roofline of SURVEY 8(d) / App. E-3 (every tensor of the graph read and written once
+        # at fp16, 0.701 ms per 4K pair at 8 TB/s) - roofline time / measured time per pair PER GPU, in the timed region (4 pairs in flight): the one number
+        # that compares across rounds
+        if roof is not None and roofline_ms is not None:
+            roof["e2e_frac"] = round(roofline_ms / (elapsed / args.steps * 1e3), 5)
+            roof["e2e_basis"] = "fused-minimum HBM time per pair (%.3f ms, SURVEY 8(d)) / ms_per_step" % roofline_ms
         # the default call certifies EVERY BASELINE config: short legs of the other three workloads, same stream policy as their --workload runs
         configs = None
         if args.workload == "4k" and world == 1 and not args.no_configs and not f32_mode:
@@ -534,6 +550,7 @@ def other_configs(amd, torch, sh, local, eng46, base4k, oracle_small):
                          "cu_partition": "none" if cu_parts <= 1 else "1 / %d of the compute units per stream" % cu_parts,
                          "roofline_frac": None if roof is None else roof["frac"], "roofline_kernel": None if roof is None else roof["kernel"].split(" (")[0],
                          "roofline_avg_launch_ms": None if roof is None else roof["avg_launch_ms"],
+                         "e2e_frac": None if roofline_ms is None else round(roofline_ms * fps / 1e3, 5),
                          "mfma_frac_issued": None if roof is None else roof["mfma_frac_issued"],
                          "max_lsb": max_lsb, "max_lsb_on": "256x160 smooth pair vs the CPU oracle, same mode", "leg_seconds": round(time.perf_counter() - t0, 2)}
             if eng is not eng46:
@@ -597,6 +614,24 @@ def cpu_baseline_small_frames():
     return out
 
 
+def cpu_model():
+    """`lscpu`'s model name (recorded next to the core count); /proc/cpuinfo where lscpu is missing."""
+    try:
+        import subprocess
+        for l in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if l.lower().startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.lower().startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(modeldir, family, pixels, passes, size=None):
     """The reference's `-g -1` BINARY cannot be built here (ncnn/Vulkan absent), so the CPU leg is the oracle
     (kind "port"; `reference_build` next to it = the reference's own src/rife.cpp + warp.cpp compiled against the ncnn look-alike of
@@ -619,9 +654,28 @@ def cpu_baseline(modeldir, family, pixels, passes, size=None):
             break
     per_pair = dt / n
     scale = pixels / float(w * h) * passes
-    res = {"value": round(1.0 / (per_pair * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port",
+    res = {"value": round(1.0 / (per_pair * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(), "nproc": os.cpu_count(),
            "sample": "%d plain %s pair(s) at %dx%d in %.2f s with %d OpenMP threads; scaled by x%.3g (pixels x TTA passes, work is linear in both)"
                      % (n, family, w, h, dt, cores, 1.0 / scale)}
+    # the reference's own default is `-j 1:2:2`: TWO proc threads, i.e. num_threads = 2 on its CPU device (src/main.cpp:783-786, 807-810, 823): the same port with
+    # 2 OpenMP threads on 640x360 pairs (>= 2 pairs, <= 12 s), scaled by the pixel ratio (the work is linear in the pixels)
+    try:
+        o2 = pyoracle.OracleRIFE(rife_v2=family.startswith("rife-v2"), rife_v4=family.startswith("rife-v4"), num_threads=2)
+        o2.load(modeldir)
+        sa, sb = gen_frames.smooth_pair(640, 360, 1000)
+        n2, t2 = 0, time.perf_counter()
+        while True:
+            o2.process(sa, sb, 0.5)
+            n2 += 1
+            d2 = time.perf_counter() - t2
+            if (d2 >= 6.0 and n2 >= 2) or d2 >= 12.0:
+                break
+        sc2 = pixels / float(640 * 360) * passes
+        res["threads_2"] = {"value": round(1.0 / (d2 / n2 * sc2), 6), "unit": "frames/s", "cores": 2,
+                            "sample": "%d plain %s pair(s) at 640x360 in %.2f s with 2 OpenMP threads (the reference's default -j 1:2:2); scaled by x%.3g (pixels x TTA passes)" % (n2, family, d2, 1.0 / sc2)}
+        del o2
+    except Exception as e:
+        res["threads_2"] = {"error": str(e)[:200]}
     try:                                                             # the reference build (oracle/_ref; prebuilt on the GPU box): one pair, same frames, same threads
         from oracle import pyref
         if pyref.available():

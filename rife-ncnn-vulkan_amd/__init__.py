@@ -186,7 +186,7 @@ class Frame:
         self._f, self.w, self.h, self._L = handle, w, h, L or lib()
 
     def release(self):
-        if getattr(self, "_f", None) and _lib is not None:
+        if getattr(self, "_f", None) and getattr(self, "_L", None) is not None:
             self._L.rife_hip_frame_release(self._f)
         self._f = None
 

@@ -780,6 +780,35 @@ int rife_hip_bench_rs2(int gpuid, int h, int w, int variant, int iters, float* m
         case RS_NODMA | RS_NOSTORE: rc = run(conv_rs2_kernel<RS_NODMA | RS_NOSTORE>); break;
         case RS_NOMATH | RS_NOSTORE: rc = run(conv_rs2_kernel<RS_NOMATH | RS_NOSTORE>); break;
         case RS_NOMATH | RS_NODMA: rc = run(conv_rs2_kernel<RS_NOMATH | RS_NODMA>); break;
+        case RS_NODMA | RS_NOSTORE | RS2_NOFRAG: rc = run(conv_rs2_kernel<RS_NODMA | RS_NOSTORE | RS2_NOFRAG>); break;
+        case RS_NODMA | RS_NOSTORE | RS2_NOLO: rc = run(conv_rs2_kernel<RS_NODMA | RS_NOSTORE | RS2_NOLO>); break;
+        case RS2_STAMPS: case RS2_STAMPS | RS_NODMA | RS_NOSTORE: {
+            // barrier trace of one workgroup (the middle one), last launch: per barrier, cycles from the previous release to each wave's arrival, and who came last
+            long long* dst = nullptr;
+            const size_t ns = (size_t)8 * RS2_NSTAMP * 2;
+            HIPCHK(hipMalloc(&dst, ns * 8)); HIPCHK(hipMemset(dst, 0, ns * 8));
+            a.stamps = dst; a.stamp_wg = nwg / 2;
+            rc = variant == RS2_STAMPS ? run(conv_rs2_kernel<RS2_STAMPS>) : run(conv_rs2_kernel<RS2_STAMPS | RS_NODMA | RS_NOSTORE>);
+            std::vector<long long> hs(ns);
+            HIPCHK(hipMemcpy(hs.data(), dst, ns * 8, hipMemcpyDeviceToHost));
+            (void)hipFree(dst);
+            const int nbar = std::min(RS2_NSTAMP, h / kparts + 9);
+            fprintf(stderr, "rs2 barrier trace, variant 0x%x, workgroup %d of %d, %d rows per segment: barrier | cycles since the previous release: arrival of CA0 CA1 CB0 CB1 L EA0 EA1 EB | release | last\n", variant, a.stamp_wg, nwg, h / kparts);
+            static const char* const names[8] = {"CA0", "CA1", "CB0", "CB1", "L", "EA0", "EA1", "EB"};
+            for (int b = 1; b < nbar; b++) {
+                long long prev = 0, rel = 0;
+                for (int wv = 0; wv < 8; wv++) { prev = std::max(prev, hs[((size_t)wv * RS2_NSTAMP + b - 1) * 2 + 1]); rel = std::max(rel, hs[((size_t)wv * RS2_NSTAMP + b) * 2 + 1]); }
+                int last = 0; long long la = 0;
+                fprintf(stderr, "  %3d |", b);
+                for (int wv = 0; wv < 8; wv++) {
+                    const long long arr = hs[((size_t)wv * RS2_NSTAMP + b) * 2];
+                    if (arr > la) { la = arr; last = wv; }
+                    fprintf(stderr, " %5lld", arr - prev);
+                }
+                fprintf(stderr, " | %5lld | %s\n", rel - prev, names[last]);
+            }
+            break;
+        }
         default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
     }
     (void)hipFree(x); (void)hipFree(y); (void)hipFree(yr); (void)hipFree(tm); (void)hipFree(dimg[0]); (void)hipFree(dimg[1]); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -881,9 +910,10 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
         HIPCHK(hipModuleLoad(&mod, g_stem_hsaco.c_str()));
         const std::string fname = std::string("_ZN4rife18stem0_fused_kernelILi") + (S == 4 ? "4" : "2") + "ELi2ELi" + (ABL ? "4096" : "0") + "EEEvNS_13StemFusedArgsE";
         HIPCHK(hipModuleGetFunction(&fn, mod, fname.c_str()));
-        const int ldsb_ext = getenv("RIFE_HIP_PROBE_LDS") ? std::atoi(getenv("RIFE_HIP_PROBE_LDS")) : stemf_lds_bytes<2>();      // > 80 KB: one workgroup per CU
+        const Switches psw = read_switches();
+        const int ldsb_ext = psw.probe_lds >= 0 ? psw.probe_lds : stemf_lds_bytes<2>();      // > 80 KB: one workgroup per CU
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb_ext));
-        const char* scrub = getenv("RIFE_HIP_PROBE_SCRUB");
+        const char* scrub = psw.probe_scrub;
         uint32_t* sink = nullptr;
         if (scrub) { HIPCHK(hipMalloc(&sink, 4)); HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds_scrub), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
         for (int r = 0; r < reps; r++) {
@@ -942,7 +972,7 @@ int rife_hip_probe_stem_det(int gpuid, int variant, int wp, int hp, int reps, lo
                 if (std::memcmp(&h0[k], &hr[k], 4) != 0) {
                     n++;
                     const size_t px = k / cout; const int ch = (int)(k % cout);
-                    if ((ch == 0 || ch == 63 % cout) && shown < (getenv("RIFE_HIP_PROBE_QUIET") ? 0 : 40)) { fprintf(stderr, "  launch %d: out (y %zu, x %zu) ch %d: %.9g vs %.9g\n", r, px / Wo, px % Wo, ch, h0[k], hr[k]); shown++; }
+                    if ((ch == 0 || ch == 63 % cout) && shown < (read_switches().probe_quiet ? 0 : 40)) { fprintf(stderr, "  launch %d: out (y %zu, x %zu) ch %d: %.9g vs %.9g\n", r, px / Wo, px % Wo, ch, h0[k], hr[k]); shown++; }
                 }
             mismatch[r] = n;
         }

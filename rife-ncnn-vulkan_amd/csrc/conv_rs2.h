@@ -67,7 +67,8 @@ struct Rs2Args {
     int nseg;                    // strips * kparts
     int descend;                 // 1: every segment is walked bottom-up (consecutive launches alternate)
     int limit;                   // tensor bytes - 16: the DMA source offsets are clamped to [0, limit] (the strips' column halo reaches 32 B before / after the tensor)
-    long long* stamps = nullptr; // bench builds RIFE_ABL(TAG & RS_CLK): [workgroup][4]
+    long long* stamps = nullptr; // bench builds RIFE_ABL(TAG & RS_CLK): [workgroup][4]; RIFE_ABL(TAG & RS2_STAMPS): see RS2_BAR
+    int stamp_wg = 0;
 };
 
 struct Rs2Seg { int x0, ystart, dir, R; };
@@ -80,6 +81,19 @@ __device__ __forceinline__ Rs2Seg rs2_segment(const Rs2Args& a, const int seg) {
 }
 
 #define RS2_NEXT(V, MOD) { V = V + 1 == (MOD) ? 0 : V + 1; }
+// bench builds, RIFE_ABL(TAG & RS2_STAMPS): lane 0 of every wave of workgroup a.stamp_wg records the shader clock when it arrives at a barrier and when it
+// leaves it: stamps[(wave * RS2_NSTAMP + barrier) * 2 + {0, 1}] (tools/rs2_bench.py prints who the others waited for, step by step)
+enum { RS2_STAMPS = 0x1000, RS2_NOFRAG = 0x10, RS2_NOLO = 0x20 };      // NOFRAG: no LDS fragment reads (MFMAs on whatever the registers hold); NOLO: hi products only
+constexpr int RS2_NSTAMP = 128;
+#define RS2_BAR(KIND)                                                                                                  \
+    {                                                                                                                  \
+        if (RIFE_ABL(TAG & RS2_STAMPS) && (int)blockIdx.x == a.stamp_wg && bar < RS2_NSTAMP && (threadIdx.x & 63) == 0)         \
+            a.stamps[((threadIdx.x >> 6) * RS2_NSTAMP + bar) * 2] = (long long)__builtin_readcyclecounter();           \
+        RS_SYNC_##KIND;                                                                                                \
+        if (RIFE_ABL(TAG & RS2_STAMPS) && (int)blockIdx.x == a.stamp_wg && bar < RS2_NSTAMP && (threadIdx.x & 63) == 0)         \
+            a.stamps[((threadIdx.x >> 6) * RS2_NSTAMP + bar) * 2 + 1] = (long long)__builtin_readcyclecounter();       \
+        bar++;                                                                                                         \
+    }
 
 // consumer wave of one layer: output block N, one row per step, `lead` idle iterations before the first step of a segment, R + extra steps
 template <int N, int NR, int TAG>
@@ -108,6 +122,7 @@ __device__ __forceinline__ void rs2_consumer(const Rs2Args& a, const unsigned ch
     unsigned char* const stg = ldsb + stgbase + ((2 * N + h) * 32 + li) * 64;
     const int qs = (li >> 1) & 3;
 
+    int bar = 0;
     int sq = 0;                                                          // ring slot of the step's first row in walking order
     int sbuf = 0;                                                        // staging buffer of the step (iteration % 3)
     unsigned ad[9];
@@ -130,8 +145,9 @@ __device__ __forceinline__ void rs2_consumer(const Rs2Args& a, const unsigned ch
             constexpr int m = decltype(mc)::value;
             constexpr RsPairDesc d = rs_pair(N, m % RS_NPAIR);
             constexpr int st = (m + 2 * PAR) % NF;
+            if RIFE_ABL(TAG & RS2_NOFRAG) { asm volatile("" : "+v"(fh[st]), "+v"(fl[st])); return; }
             fh[st] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG));
-            fl[st] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG) + RS_SEG);
+            if (!RIFE_ABL(TAG & RS2_NOLO)) fl[st] = *reinterpret_cast<const f16x8*>(ldsb + ad[d.t] + d.c * (2 * RS_SEG) + RS_SEG);
         };
         f32x16 accH, accL;
         if (!RIFE_ABL(TAG & RS_NOMATH)) {
@@ -147,10 +163,10 @@ __device__ __forceinline__ void rs2_consumer(const Rs2Args& a, const unsigned ch
 #pragma unroll
                     for (int q = 0; q < 16; q++) z[q] = 0.f;
                     accH = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[st], z, 0, 0, 0);
-                    accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[st], z, 0, 0, 0);
+                    if (!RIFE_ABL(TAG & RS2_NOLO)) accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[st], z, 0, 0, 0); else accL = z;
                 } else {
                     accH = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fh[st], accH, 0, 0, 0);
-                    accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[st], accL, 0, 0, 0);
+                    if (!RIFE_ABL(TAG & RS2_NOLO)) accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, fl[st], accL, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -167,13 +183,13 @@ __device__ __forceinline__ void rs2_consumer(const Rs2Args& a, const unsigned ch
             d4[q ^ qs] = v;
         }
         RS2_NEXT(sbuf, RS2_NSTG)
-        RS_SYNC_BARE();
+        RS2_BAR(BARE())
     };
     for (int seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
         const int R = rs2_segment(a, seg).R;
         const int S = R + extra, NIT = R + lag + 2;
-        RS_SYNC_LGKM();                                                  // the segment's first rows have landed (L), bias in LDS
-        for (int i = 0; i < lead; i++) RS_SYNC_BARE();
+        RS2_BAR(LGKM())                                                  // the segment's first rows have landed (L), bias in LDS
+        for (int i = 0; i < lead; i++) RS2_BAR(BARE())
         sq = 0; sbuf = lead % RS2_NSTG;
         step_addresses();
         if (!RIFE_ABL(TAG & RS_NOMATH)) for_each_slot<0, RS_PF>([&](auto mc) {       // first fragments of the first step (parity 0)
@@ -185,7 +201,7 @@ __device__ __forceinline__ void rs2_consumer(const Rs2Args& a, const unsigned ch
         int k = 0;
         for (; k + 1 < S; k += 2) { step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); }
         if (k < S) step(std::integral_constant<int, 0>{});
-        for (int i = lead + S; i < NIT; i++) RS_SYNC_BARE();
+        for (int i = lead + S; i < NIT; i++) RS2_BAR(BARE())
     }
 }
 
@@ -228,6 +244,7 @@ __global__ __launch_bounds__(RS2_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))
     } else if (wv == 4) {
         // ------------------------------------------------------------------------------------------------ loader
         // piece i of a row covers LDS units 64 i .. 64 i + 63 (16 bytes each) of the 544 of a row slot: unit = (segment, pixel, half)   [conv_rs.h]
+        int bar = 0;
         int soff[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) {
@@ -255,11 +272,11 @@ __global__ __launch_bounds__(RS2_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))
                 issued++;
             };
             auto wait_barrier = [&](const int pending) {                 // all but the newest `pending` rows have landed (9 DMA instructions per row)
-                if RIFE_ABL(TAG & RS_NODMA) RS_SYNC_LGKM();
-                else if (pending <= 0) RS_SYNC_VM(0);
-                else if (pending == 1) RS_SYNC_VM(9);
-                else if (pending == 2) RS_SYNC_VM(18);
-                else RS_SYNC_VM(27);
+                if RIFE_ABL(TAG & RS_NODMA) RS2_BAR(LGKM())
+                else if (pending <= 0) RS2_BAR(VM(0))
+                else if (pending == 1) RS2_BAR(VM(9))
+                else if (pending == 2) RS2_BAR(VM(18))
+                else RS2_BAR(VM(27))
             };
             static_assert(RS2_AH == 3, "counted waits above");
             while (issued < min(needed, 4 + RS2_AH)) issue();
@@ -272,14 +289,15 @@ __global__ __launch_bounds__(RS2_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))
     } else if (wv < 7) {
         // ------------------------------------------------------------------------------------------------ epilogue of layer A -> ring B
         const int e = wv - 5;
+        int bar = 0;
         const int px = lane >> 1, jh = lane & 1, qs = (px >> 1) & 3;
         const float slope = reinterpret_cast<const float*>(a.imgA + 4 * t64_wch(2))[64];
         const unsigned dcol = (unsigned)(px * 32 + ((jh ^ ((px >> 3) & 1)) << 4));
         for (int seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
             const Rs2Seg s = rs2_segment(a, seg);
             const int NIT = s.R + lag + 2;
-            RS_SYNC_LGKM();
-            RS_SYNC_BARE(); RS_SYNC_BARE();                              // iterations 0, 1
+            RS2_BAR(LGKM())
+            RS2_BAR(BARE()) RS2_BAR(BARE())                              // iterations 0, 1
             int slot = 0, sb = 0;
             const int xA = s.x0 - 1 + px;
             const bool colok = xA >= 0 && xA < a.W;
@@ -296,18 +314,19 @@ __global__ __launch_bounds__(RS2_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))
                     *reinterpret_cast<f16x8*>(dst + (2 * cc + 1) * RS_SEG) = lv;
                 }
                 RS2_NEXT(slot, RS2_NRB) RS2_NEXT(sb, RS2_NSTG)
-                RS_SYNC_LGKM();                                          // the row is in ring B before the barrier
+                RS2_BAR(LGKM())                                          // the row is in ring B before the barrier
             }
-            for (int i = s.R + 4; i < NIT; i++) RS_SYNC_BARE();
+            for (int i = s.R + 4; i < NIT; i++) RS2_BAR(BARE())
         }
     } else {
         // ------------------------------------------------------------------------------------------------ epilogue of layer B -> global
         const int px = lane >> 1, jh = lane & 1, qs = (px >> 1) & 3;
         const float slope = reinterpret_cast<const float*>(a.imgB + 4 * t64_wch(2))[64];
+        int bar = 0;
         for (int seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
             const Rs2Seg s = rs2_segment(a, seg);
-            RS_SYNC_LGKM();
-            for (int i = 0; i < lag + 2; i++) RS_SYNC_BARE();
+            RS2_BAR(LGKM())
+            for (int i = 0; i < lag + 2; i++) RS2_BAR(BARE())
             int sb = lag % RS2_NSTG;
             const int x = s.x0 + px;
             const bool store = px < RS2_SW && x < a.rowmax && !RIFE_ABL(TAG & RS_NOSTORE);
@@ -326,7 +345,7 @@ __global__ __launch_bounds__(RS2_NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
                 }
                 RS2_NEXT(sb, RS2_NSTG)
-                RS_SYNC_LGKM();                                          // my reads of the staging buffer are done before the consumers may reuse it
+                RS2_BAR(LGKM())                                          // my reads of the staging buffer are done before the consumers may reuse it
             }
         }
     }

@@ -1,0 +1,1109 @@
+// engine_abi.h: the C-ABI of include/rife_hip.h (+ include/rife_hip_test.h in the test build, bench_hooks.h in the bench build)
+// One translation unit (engine.hip includes the engine_*.h sections in dependency order; every function here is file-local).
+// No include guard on purpose: a section is included exactly once, by engine.hip.
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+extern "C" {
+
+const char* rife_hip_last_error(void) { return g_err.c_str(); }
+
+int rife_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+rife_hip_t* rife_hip_create(int gpuid, int tta_mode, int tta_temporal_mode, int uhd_mode, int num_threads, int rife_v2, int rife_v4) {
+    if (check_device(gpuid)) return nullptr;
+    rife_hip* E = new rife_hip;
+    E->gpuid = gpuid; E->tta = tta_mode; E->tta_temporal = tta_temporal_mode; E->uhd = uhd_mode;
+    E->num_threads = num_threads; E->v2 = rife_v2; E->v4 = rife_v4;
+    E->frame_pool = std::make_shared<FramePool>();
+    E->frame_pool->gpuid = gpuid;
+    const Switches sw = read_switches();                                 // engine scope: the kernel-selection switches of the test build (product: the defaults)
+    E->t64 = sw.t64; E->rs = sw.rs; E->rs2 = sw.rs2; E->stem_rs = sw.stem_rs; E->tta_consensus = sw.tta_consensus;
+    E->tail_rs = sw.tail_rs; E->tail_rs_always = sw.tail_rs_always; E->fuse_flow = sw.fuse_flow;
+    if (sw.ks_mask >= 0) E->ks_mask = sw.ks_mask;
+    if (E->fuse_flow) g_fuse_flow_buffers = true;
+    return E;
+}
+
+void rife_hip_destroy(rife_hip_t* r) { delete r; }
+
+static int rife_hip_load_impl(rife_hip_t* E, const char* modeldir) {
+    if (!E || !modeldir) return fail(RIFE_HIP_EINVAL, "null argument");
+    int rc;
+    if ((rc = check_device(E->gpuid))) return rc;
+    if (E->v2 && !E->v4) {
+        if ((rc = load_v2(E, modeldir))) return rc;
+        E->loaded = true;
+        return 0;
+    }
+    if (!E->v4) {
+        if ((rc = load_v1(E, modeldir))) return rc;
+        E->loaded = true;
+        return 0;
+    }
+    NcnnModel m;
+    const std::string base = std::string(modeldir) + "/flownet";
+    if (!m.load_param(base + ".param")) return fail(RIFE_HIP_EIO, m.error);
+    const uint64_t gh = m.structural_hash("out0");
+    if (gh != V46_HASH_OUT0 && gh != RIFE_V40_HASH_OUT0)
+        return fail(RIFE_HIP_EMODEL, base + ".param is neither the rife-v4.6 nor the rife-v4 IFNet graph this engine schedules");
+    if (!m.load_bin(base + ".bin")) return fail(RIFE_HIP_EIO, m.error);
+    std::vector<const NcnnLayer*> wl = m.weighted();
+    E->v40 = gh == RIFE_V40_HASH_OUT0;
+    if (E->v40) {
+        // rife-v4 (4.0): every conv is followed by its PReLU in the weight stream; the 5-channel head is padded to 8 output channels
+        // (zero weights / bias) so that flow{b} keeps the [.][.][8] = {x, y, z, w, mask, 0, 0, 0} layout of the v4.6 schedule
+        static const int C[4] = {192, 128, 96, 64}, SC[4] = {8, 4, 2, 1};
+        size_t k = 0;
+        for (int b = 0; b < 4; b++) {
+            rife_hip::Block& B = E->blk[b];
+            B.c = C[b]; B.scale = SC[b];
+            static const char* const SN0[4] = {"stem0_b0", "stem0_b1", "stem0_b2", "stem0_b3"};
+            static const char* const SN1[4] = {"stem1_b0", "stem1_b1", "stem1_b2", "stem1_b3"};
+            static const char* const TN[4] = {"trunk_b0", "trunk_b1", "trunk_b2", "trunk_b3"};
+            static const char* const HN[4] = {"head_b0", "head_b1", "head_b2", "head_b3"};
+            auto take = [&](ConvLayer& L, int cin, int cout, int stride, bool deconv, const char* cls) -> int {
+                if (k >= wl.size()) return fail(RIFE_HIP_EMODEL, "weight stream ended early");
+                const NcnnLayer* nl = wl[k++];
+                const int kk = deconv ? 16 : 9;
+                if (nl->type != (deconv ? "Deconvolution" : "Convolution") || nl->geti(0, 0) != cout || (int)nl->weight.size() != cin * cout * kk ||
+                    nl->geti(3, 1) != stride)
+                    return fail(RIFE_HIP_EMODEL, "weighted layer " + nl->name + " does not match the rife-v4 schedule");
+                free_layer(L);
+                L.cin = cin; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = deconv ? EPI_DECONV : EPI_STORE; L.cls = cls; L.tag = 0; L.skip = false;
+                if (deconv) {
+                    L.cout = 8;
+                    std::vector<float> w((size_t)8 * cin * 16, 0.f), bias(8, 0.f);
+                    std::copy(nl->weight.begin(), nl->weight.end(), w.begin());              // ncnn deconv weights are [oc][ic][ky][kx]
+                    std::copy(nl->bias.begin(), nl->bias.end(), bias.begin());
+                    return upload_layer(L, w.data(), bias.data(), nullptr, 1.0f);
+                }
+                L.cout = cout;
+                if (k >= wl.size() || wl[k]->type != "PReLU" || (int)wl[k]->slope.size() != cout) return fail(RIFE_HIP_EMODEL, "PReLU expected after " + nl->name);
+                return upload_layer(L, nl->weight.data(), nl->bias.data(), wl[k++]->slope.data(), 1.0f);
+            };
+            if ((rc = take(B.stem0, b == 0 ? 7 : 12, C[b] / 2, 2, false, SN0[b]))) return rc;
+            if ((rc = take(B.stem1, C[b] / 2, C[b], 2, false, SN1[b]))) return rc;
+            for (int i = 0; i < 8; i++) if ((rc = take(B.res[i], C[b], C[b], 1, false, TN[b]))) return rc;
+            if ((rc = take(B.head, C[b], 5, 2, true, HN[b]))) return rc;
+        }
+        if (k != wl.size()) return fail(RIFE_HIP_EMODEL, "flownet.bin has extra weighted layers");
+        E->loaded = true;
+        return 0;
+    }
+    if (wl.size() != 44) return fail(RIFE_HIP_EMODEL, "unexpected number of weighted layers");
+    static const int C[4] = {192, 128, 96, 64}, SC[4] = {8, 4, 2, 1};
+    size_t k = 0;
+    for (int b = 0; b < 4; b++) {
+        rife_hip::Block& B = E->blk[b];
+        B.c = C[b]; B.scale = SC[b];
+        char name[64];
+        auto setup = [&](ConvLayer& L, int cin, int cout, int stride, bool deconv, int epi, float slope, const char* cls, bool fold_skip = false) -> int {
+            const NcnnLayer* nl = wl[k++];
+            const int kk = deconv ? 16 : 9;
+            if (nl->type != (deconv ? "Deconvolution" : "Convolution") || nl->geti(0, 0) != cout || (int)nl->weight.size() != cin * cout * kk ||
+                nl->geti(3, 1) != stride)
+                return fail(RIFE_HIP_EMODEL, "weighted layer " + nl->name + " does not match the rife-v4.6 schedule");
+            free_layer(L);
+            L.cin = cin; L.cout = cout; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi; L.cls = cls;
+            L.tag = std::strcmp(cls, "trunk_b3") == 0 ? 3 : 0;
+            L.skip = fold_skip;
+            L.want_t64 = fold_skip && cin == cout;
+            L.want_s16out = !deconv && stride == 2 && cout == C[b];
+            return upload_layer(L, nl->weight.data(), nl->bias.data(), nullptr, slope);
+        };
+        std::snprintf(name, sizeof name, "stem0_b%d", b);
+        if ((rc = setup(B.stem0, b == 0 ? 7 : 12, C[b] / 2, 2, false, EPI_STORE, 0.2f, name))) return rc;
+        std::snprintf(name, sizeof name, "stem1_b%d", b);
+        if ((rc = setup(B.stem1, C[b] / 2, C[b], 2, false, EPI_STORE, 0.2f, name))) return rc;
+        std::snprintf(name, sizeof name, "trunk_b%d", b);
+        for (int i = 0; i < 8; i++)
+            if ((rc = setup(B.res[i], C[b], C[b], 1, false, EPI_STORE, 0.2f, name, true))) return rc;
+        std::snprintf(name, sizeof name, "head_b%d", b);
+        if ((rc = setup(B.head, C[b], 24, 2, true, EPI_DECONV_PS, 1.0f, name))) return rc;
+    }
+    E->loaded = true;
+    return 0;
+}
+int rife_hip_load(rife_hip_t* E, const char* modeldir) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_load_impl(E, modeldir); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_load: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_load: unknown exception"); }
+}
+
+static int process_common(const rife_hip* E, int w, int h, float timestep) {
+    tl_cu_budget = 0;                                                    // every entry point starts on the whole chip; rife_hip_process_device sets its stream's part
+    if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
+    if (!E->loaded) return fail(RIFE_HIP_EINVAL, "process() before load()");
+    if (w <= 0 || h <= 0) return fail(RIFE_HIP_EINVAL, "bad frame size");
+    if ((long long)((w + 31) / 32 * 32) * ((h + 31) / 32 * 32) > (1ll << 27))      // element indices are ints and the widest full-resolution tensor has 16 channels; (stem_rs has its own gate, block_on_stem_rs)
+        return fail(RIFE_HIP_EINVAL, "frame too large (more than 2^27 padded pixels)");
+    (void)timestep;
+    if (E->uhd && !E->v4 && (((w + 31) / 32 * 32 / 2) % 32 || ((h + 31) / 32 * 32 / 2) % 32))
+        return fail(RIFE_HIP_EINVAL, "UHD mode needs a padded frame whose half size is a multiple of 32 (the reference's graph mis-sizes otherwise)");
+    return 0;
+}
+
+// Workspace pool of the host-buffer entry points (rife_hip_process from the reference's proc threads, process_frames, the workers of process_batch).
+// Round 6: the pool lays its streams out over the chip the way bench.py's resident-frame legs do, from the number of callers in flight: fewer than four
+// -> ordinary streams (the whole chip each: 1 in flight is fastest there, 2 - 3 gain nothing from a partition, profiles/r4/cumask_probe.txt); four and more ->
+// frames of 4 Mpixel and more two per half of the compute units, smaller ones one per quarter (CU index mod parts, like rife_hip_stream_create).  The bytes do
+// not depend on the layout (kernel selection never looks at a partition).  RIFE_HIP_POOL_PARTS (A/B, test build): 0 = never partition, n = always n parts.
+// "Callers in flight" is the MOST that were in flight at any of the last 32 leases, not the count of the moment: four threads that call back to back are
+// seen as 3 or 4 at a lease, and a layout that followed the moment rebuilt a 1.6 GB workspace at every flip (measured: 4 threads 229 frames/s against 469 from
+// 3, profiles/r6/host_path_before_hysteresis.txt).
+// Trimming: a released workspace is destroyed when the pool holds more than that same high-water mark (a burst of N concurrent 4K callers no longer pins
+// N x 1.6 GB for the engine's life); workspaces of the layout that is no longer in use go first, then the oldest.
+static int pool_layout(int callers, int w, int h) {
+    const int forced = process_switches().pool_parts;
+    if (forced == 0 || forced == 1) return 1;
+    if (forced == 2 || forced == 4) return forced;
+    if (callers < 4) return 1;
+    return (long long)w * h >= 4000000ll ? 2 : 4;
+}
+// force_parts = 1: a whole-chip stream whatever the callers in flight (the lockstep groups of process_batch: a group's batched coarse-block launches ride on ONE
+// of its two streams and must see the whole chip)
+static int lease_ctx(const rife_hip* E, std::unique_ptr<Ctx>& c, int w, int h, int force_parts = 0) {
+    int parts, part = 0;
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        const int callers = ++E->leased;
+        E->lease_hist[E->lease_n++ % 32] = callers;
+        int hw = 1;
+        for (int v : E->lease_hist) hw = std::max(hw, v);
+        parts = force_parts ? force_parts : pool_layout(hw, w, h);
+        if (!force_parts) E->pool_parts_now = parts;
+        // a pooled workspace of this layout, on the partition with the fewest workspaces in use (newest first among equals: its tensors are the likeliest to
+        // have this frame size); none pooled: a new one on the least-used partition
+        int pick = -1;
+        for (int i = (int)E->free_ctx.size() - 1; i >= 0; i--) {
+            const Ctx& f = *E->free_ctx[i];
+            if (f.pool_parts != parts) continue;
+            if (pick < 0 || E->part_live[parts][f.pool_part] < E->part_live[parts][E->free_ctx[pick]->pool_part]) pick = i;
+        }
+        if (pick >= 0) { c = std::move(E->free_ctx[pick]); E->free_ctx.erase(E->free_ctx.begin() + pick); part = c->pool_part; }
+        else for (int p = 1; p < parts; p++) if (E->part_live[parts][p] < E->part_live[parts][part]) part = p;
+        E->part_live[parts][part]++;
+    }
+    if (!c) {
+        c.reset(new Ctx);
+        c->pool_parts = parts; c->pool_part = part;
+        if (parts > 1) {
+            const int ncu = device_cus(true);
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            int mine = 0;
+            for (int cu = 0; cu < ncu; cu++) if (cu % parts == part) { mask[cu / 32] |= 1u << (cu % 32); mine++; }
+            if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipExtStreamCreateWithCUMask failed");
+            c->cu_budget = mine;
+        } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
+        c->own_stream = true;
+    }
+    tl_cu_budget = c->cu_budget;                                         // the caller enqueues on this workspace's stream next
+    return E->v4 ? ensure_ctx(*c, w, h) : E->v1 ? ensure_ctx_v1(*c, w, h, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1)
+                                                : ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1, E->v3, ctx_batch_serves(*E));
+}
+
+// the caller has drained the workspace's stream (every path synchronises before it releases)
+static void release_ctx(const rife_hip* E, std::unique_ptr<Ctx>& c) {
+    std::vector<std::unique_ptr<Ctx>> dead;                              // destroyed outside the lock (hipFree, hipStreamDestroy)
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        E->leased--;
+        E->part_live[c->pool_parts][c->pool_part]--;
+        E->free_ctx.push_back(std::move(c));
+        int hw = 1;
+        for (int v : E->lease_hist) hw = std::max(hw, v);
+        while ((int)E->free_ctx.size() + E->leased > hw) {               // another layout's first, then the oldest
+            size_t v = 0;
+            for (size_t i = 0; i < E->free_ctx.size(); i++) if (E->free_ctx[i]->pool_parts != E->pool_parts_now) { v = i; break; }
+            dead.push_back(std::move(E->free_ctx[v])); E->free_ctx.erase(E->free_ctx.begin() + v);
+        }
+    }
+}
+
+// H2D of both frames, the whole pass and the D2H of the result, all enqueued on the workspace's stream (no host wait)
+static int enqueue_host_pair(const rife_hip* E, Ctx& c, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, uint8_t* out) {
+    const size_t nbytes = (size_t)w * h * 3;
+    hipError_t e = hipMemcpyAsync(c.d_in0, in0, nbytes, hipMemcpyHostToDevice, c.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c.d_in1, in1, nbytes, hipMemcpyHostToDevice, c.stream);
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("H2D: ") + hipGetErrorString(e));
+    int rc;
+    if (E->v1) rc = run_v1(*E, c, c.d_in0, c.d_in1, c.d_out);
+    else if (!E->v4) rc = run_v2(*E, c, c.d_in0, c.d_in1, c.d_out);
+    else if (E->tta || E->tta_temporal) {
+        // the TTA workspaces are shared by all callers: serialise, and drain before the next caller may reuse them
+        std::lock_guard<std::mutex> g(E->tta_mu);
+        rc = run_v4_tta(*E, c.stream, c.d_in0, c.d_in1, w, h, timestep, c.d_out);
+        if (!rc && hipStreamSynchronize(c.stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "TTA stream sync failed");
+    } else rc = run_v4_replay(*E, c, c.d_in0, c.d_in1, timestep, c.d_out);
+    if (rc) return rc;
+    e = hipMemcpyAsync(out, c.d_out, nbytes, hipMemcpyDeviceToHost, c.stream);
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("D2H: ") + hipGetErrorString(e));
+    return 0;
+}
+
+static int rife_hip_process_impl(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, uint8_t* out) {
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (!in0 || !in1 || !out) return fail(RIFE_HIP_EINVAL, "null frame pointer");
+    const size_t nbytes = (size_t)w * h * 3;
+    // rife.cpp:2470-2480: timestep 0 / 1 return an input frame unchanged (the reference rebinds the Mat; a copy is pixel-identical)
+    if (timestep == 0.f) { std::memmove(out, in0, nbytes); return 0; }
+    if (timestep == 1.f) { std::memmove(out, in1, nbytes); return 0; }
+    if ((rc = check_device(E->gpuid))) return rc;
+    std::unique_ptr<Ctx> c;
+    rc = lease_ctx(E, c, w, h);
+    if (!rc) rc = enqueue_host_pair(E, *c, in0, in1, w, h, timestep, out);
+    if (c && hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(RIFE_HIP_EHIP, "stream sync failed");
+    if (c) release_ctx(E, c);
+    return rc;
+}
+int rife_hip_process(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, uint8_t* out) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_process_impl(E, in0, in1, w, h, timestep, out); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_process: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_process: unknown exception"); }
+}
+
+// n independent frame pairs from host memory in one call.  Copies from / to pageable host memory block the thread that issues
+// them, so overlap of one pair's copies with another pair's kernels needs several host threads - the reference's proc threads
+// (src/main.cpp:849-866).  The batch call brings its own: 2 workers (the reference default), each a plain rife_hip_process() loop over its share of
+// the pairs (every call leases its own workspace + stream).  Same pixels as n rife_hip_process() calls.
+struct rife_hip_frame {
+    uint8_t* d = nullptr;      // tight u8 HWC RGB, the layout every run_* entry takes
+    int w = 0, h = 0, gpuid = 0;
+    size_t nbytes = 0;
+    std::shared_ptr<FramePool> pool;
+};
+
+int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0, const uint8_t* const* in1, const float* timestep,
+                           uint8_t* const* out, int w, int h) {
+    int rc;
+    if (n < 0 || (n > 0 && (!in0 || !in1 || !timestep || !out))) return fail(RIFE_HIP_EINVAL, "bad batch arguments");
+    if ((rc = process_common(E, w, h, 0.5f))) return rc;
+    for (int i = 0; i < n; i++) if (!in0[i] || !in1[i] || !out[i]) return fail(RIFE_HIP_EINVAL, "null frame pointer");
+    if (n == 0) return 0;
+    if ((rc = check_device(E->gpuid))) return rc;
+    // three workers = three pairs in flight: tools/host_path_bench2.py, 4K, 48 pairs: process() from 1 / 2 / 3 / 4 caller threads
+    // 192 / 341 / 389 / 365 frames/s from pageable frames (resident frames: 395), 244 / 307 / 349 / 344 from page-locked ones
+    const int batch_workers = process_switches().batch_workers;
+    const int K = std::min(n, batch_workers ? batch_workers : 4);      // round 4: four workers (measured against 3 / 5 / 6 / 8: 4K 439 vs 426 / 426 / 431 / 446, 1080p 1,334 vs 1,251 / 1,367 / 1,443 / 1,398 pageable; page-locked best at 4)
+    // A host frame that serves several pairs of the batch (consecutive pairs of a sequence share one) crosses PCIe once: it becomes a
+    // resident frame on first use and is released after its last (stream mode, below).  Batches without shared frames run as before.
+    struct Shared { std::mutex mu; rife_hip_frame_t* f = nullptr; int left = 0; };
+    std::map<const uint8_t*, std::unique_ptr<Shared>> shared;
+    bool any_shared = false;
+    for (int i = 0; i < n; i++) {
+        if (timestep[i] == 0.f || timestep[i] == 1.f) continue;
+        for (const uint8_t* p : {in0[i], in1[i]}) {
+            auto& sl = shared[p];
+            if (!sl) sl.reset(new Shared);
+            any_shared |= ++sl->left > 1;
+        }
+    }
+    auto resident = [&](const uint8_t* p, rife_hip_frame_t*& f) -> int {
+        Shared& sl = *shared.find(p)->second;
+        std::lock_guard<std::mutex> g(sl.mu);
+        const int r = sl.f ? 0 : rife_hip_frame_upload(E, p, w, h, &sl.f);
+        f = sl.f;
+        return r;
+    };
+    auto retire = [&](const uint8_t* p) {
+        Shared& sl = *shared.find(p)->second;
+        std::lock_guard<std::mutex> g(sl.mu);
+        if (--sl.left == 0) { rife_hip_frame_release(sl.f); sl.f = nullptr; }
+    };
+    std::vector<int> rcs(K, 0);
+    std::vector<std::string> errs(K);
+    // Lockstep groups (plain rife-v4.6 on the S16 trunks): three workers, each takes groups of two consecutive pairs through run_v4_group - the coarse
+    // blocks of a group are batched launches - so up to six pairs are in flight and one worker's copies overlap the others' passes.  A trailing odd pair,
+    // timestep 0 / 1 copies and every other model family take the per-pair path below.
+    // (only where the coarse grids leave CUs idle - block 0 on the row kernel, frames up to ~1080p: at 3840x2160 a coarse layer of ONE pair already
+    // fills the chip, measured 405 - 413 frames/s in groups against 400 - 425 per pair; RIFE_HIP_BATCH_GROUPS=1 / 0 forces / forbids the path)
+    const int genv = read_switches().batch_groups;      // per call: 1 / 0 force / forbid, -1 by grid size
+    const int Ht0 = (h + 31) / 32, Wt0 = (w + 31) / 32;
+    const bool small_grid = ((Wt0 + 31) / 32) * Ht0 <= device_cus(true) * 5 / 8;      // MI355X: 160 workgroups, block 0 on the row kernel (block_on_row_kernel)
+    const bool groups = E->v4 && !E->v40 && !E->v1 && !E->tta && !E->tta_temporal && E->t64 && n >= 2 && (genv >= 0 ? genv != 0 : small_grid);
+    if (groups) {
+        std::vector<std::array<int, 2>> grp;                 // pair indices of a group, -1 = none
+        std::vector<int> singles;
+        {
+            int pend = -1;
+            for (int i = 0; i < n; i++) {
+                if (timestep[i] == 0.f || timestep[i] == 1.f) { singles.push_back(i); continue; }
+                if (pend < 0) pend = i; else { grp.push_back({pend, i}); pend = -1; }
+            }
+            if (pend >= 0) singles.push_back(pend);
+        }
+        const int KG = std::min<int>(batch_workers ? batch_workers : 4, (int)grp.size() + (singles.empty() ? 0 : 1));      // four workers x two pairs in flight
+        std::vector<int> grc(std::max(KG, 1), 0);
+        std::vector<std::string> gerr(std::max(KG, 1));
+        const size_t nbytes = (size_t)w * h * 3;
+        auto one_pair = [&](int i) -> int {
+            if (timestep[i] == 0.f || timestep[i] == 1.f) return rife_hip_process(E, in0[i], in1[i], w, h, timestep[i], out[i]);
+            rife_hip_frame_t *f0 = nullptr, *f1 = nullptr;
+            int r = resident(in0[i], f0);
+            if (!r) r = resident(in1[i], f1);
+            if (!r) r = rife_hip_process_frames(E, f0, f1, timestep[i], out[i]);
+            retire(in0[i]); retire(in1[i]);
+            return r;
+        };
+        auto gworker = [&](int k) {
+            (void)hipSetDevice(E->gpuid);
+            std::unique_ptr<Ctx> c[2];
+            int r = 0;
+            for (size_t q = k; q < grp.size() && !r; q += KG) {
+                const int ia = grp[q][0], ib = grp[q][1];
+                rife_hip_frame_t* f[4] = {nullptr, nullptr, nullptr, nullptr};
+                const uint8_t* hp[4] = {in0[ia], in1[ia], in0[ib], in1[ib]};
+                int nres = 0;
+                for (; nres < 4 && !r; nres++) r = resident(hp[nres], f[nres]);
+                if (r) nres--;
+                for (int g = 0; g < 2 && !r; g++) if (!c[g]) r = lease_ctx(E, c[g], w, h, 1);
+                if (!r) {
+                    Ctx* cs[2] = {c[0].get(), c[1].get()};
+                    const uint8_t* d0[2] = {f[0]->d, f[2]->d}; const uint8_t* d1[2] = {f[1]->d, f[3]->d};
+                    const float ts[2] = {timestep[ia], timestep[ib]};
+                    uint8_t* dout[2] = {c[0]->d_out, c[1]->d_out};
+                    r = run_v4_group(*E, cs, 2, d0, d1, ts, dout);
+                    if (!r && hipMemcpyAsync(out[ia], c[0]->d_out, nbytes, hipMemcpyDeviceToHost, c[0]->stream) != hipSuccess) r = fail(RIFE_HIP_EHIP, "D2H failed");
+                    if (!r && hipMemcpyAsync(out[ib], c[1]->d_out, nbytes, hipMemcpyDeviceToHost, c[1]->stream) != hipSuccess) r = fail(RIFE_HIP_EHIP, "D2H failed");
+                }
+                for (int g = 0; g < 2; g++) if (c[g] && hipStreamSynchronize(c[g]->stream) != hipSuccess && !r) r = fail(RIFE_HIP_EHIP, "stream sync failed");
+                for (int j = 0; j < nres; j++) retire(hp[j]);
+            }
+            for (int g = 0; g < 2; g++) if (c[g]) release_ctx(E, c[g]);
+            if (!r && k == KG - 1) for (int i : singles) if ((r = one_pair(i))) break;       // the leftovers ride on the last worker
+            if (r) { grc[k] = r; gerr[k] = g_err; }
+        };
+        std::vector<std::thread> gth;
+        for (int k = 1; k < KG; k++) gth.emplace_back(gworker, k);
+        if (KG > 0) gworker(0);
+        for (auto& t : gth) t.join();
+        for (auto& kv : shared) if (kv.second->f) rife_hip_frame_release(kv.second->f);      // only after an error
+        for (int k = 0; k < KG; k++) if (grc[k]) { g_err = gerr[k]; return grc[k]; }
+        return 0;
+    }
+    auto worker = [&](int k) {
+        (void)hipSetDevice(E->gpuid);
+        for (int i = k; i < n; i += K) {
+            int r;
+            if (!any_shared || timestep[i] == 0.f || timestep[i] == 1.f) r = rife_hip_process(E, in0[i], in1[i], w, h, timestep[i], out[i]);
+            else {
+                rife_hip_frame_t *f0 = nullptr, *f1 = nullptr;
+                r = resident(in0[i], f0);
+                if (!r) r = resident(in1[i], f1);
+                if (!r) r = rife_hip_process_frames(E, f0, f1, timestep[i], out[i]);
+                retire(in0[i]); retire(in1[i]);
+            }
+            if (r) { rcs[k] = r; errs[k] = g_err; return; }     // g_err is thread-local: carry it back to the caller
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < K; k++) th.emplace_back(worker, k);
+    worker(0);
+    for (auto& t : th) t.join();
+    for (auto& kv : shared) if (kv.second->f) rife_hip_frame_release(kv.second->f);      // only after an error
+    for (int k = 0; k < K; k++) if (rcs[k]) { g_err = errs[k]; return rcs[k]; }
+    return 0;
+}
+
+// ---- stream mode: frames resident in device memory across calls (include/rife_hip.h) ----
+
+static int rife_hip_frame_upload_impl(const rife_hip_t* E, const uint8_t* rgb, int w, int h, rife_hip_frame_t** frame) {
+    if (frame) *frame = nullptr;
+    if (!E || !rgb || !frame) return fail(RIFE_HIP_EINVAL, "null argument");
+    if (w <= 0 || h <= 0) return fail(RIFE_HIP_EINVAL, "bad frame size");
+    int rc;
+    if ((rc = check_device(E->gpuid))) return rc;
+    std::unique_ptr<rife_hip_frame> f(new rife_hip_frame);
+    f->w = w; f->h = h; f->gpuid = E->gpuid;
+    const size_t nbytes = (size_t)w * h * 3;
+    f->nbytes = nbytes; f->pool = E->frame_pool;
+    if (!(f->d = f->pool->take(nbytes))) return fail(RIFE_HIP_EHIP, "hipMalloc of a resident frame failed");
+    // a copy on its own stream, drained here: the frame is complete before any stream of any caller can see the handle
+    hipStream_t st = nullptr;
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        if (!E->upload_streams.empty()) { st = E->upload_streams.back(); E->upload_streams.pop_back(); }
+    }
+    hipError_t e = st ? hipSuccess : hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(f->d, rgb, nbytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (st) { std::lock_guard<std::mutex> g(E->mu); E->upload_streams.push_back(st); }
+    if (e != hipSuccess) { f->pool->give(f->d, nbytes); return fail(RIFE_HIP_EHIP, std::string("frame upload: ") + hipGetErrorString(e)); }
+    *frame = f.release();
+    return 0;
+}
+int rife_hip_frame_upload(const rife_hip_t* E, const uint8_t* rgb, int w, int h, rife_hip_frame_t** frame) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_frame_upload_impl(E, rgb, w, h, frame); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_frame_upload: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_frame_upload: unknown exception"); }
+}
+
+void rife_hip_frame_release(rife_hip_frame_t* f) {
+    if (!f) return;
+    if (f->d) f->pool->give(f->d, f->nbytes);
+    delete f;
+}
+
+static int rife_hip_process_frames_impl(const rife_hip_t* E, const rife_hip_frame_t* f0, const rife_hip_frame_t* f1, float timestep, uint8_t* out) {
+    if (!f0 || !f1 || !out) return fail(RIFE_HIP_EINVAL, "null frame pointer");
+    if (f0->w != f1->w || f0->h != f1->h) return fail(RIFE_HIP_EINVAL, "the two frames differ in size");
+    const int w = f0->w, h = f0->h;
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (f0->gpuid != E->gpuid || f1->gpuid != E->gpuid) return fail(RIFE_HIP_EINVAL, "frame was uploaded to another device");
+    if ((rc = check_device(E->gpuid))) return rc;
+    const size_t nbytes = (size_t)w * h * 3;
+    if (timestep == 0.f || timestep == 1.f) {                 // rife.cpp:2470-2480 (a copy stream of the pool, never the legacy stream)
+        hipStream_t st = nullptr;
+        {
+            std::lock_guard<std::mutex> g(E->mu);
+            if (!E->upload_streams.empty()) { st = E->upload_streams.back(); E->upload_streams.pop_back(); }
+        }
+        hipError_t e = st ? hipSuccess : hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemcpyAsync(out, timestep == 0.f ? f0->d : f1->d, nbytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (st) { std::lock_guard<std::mutex> g(E->mu); E->upload_streams.push_back(st); }
+        if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("frame download: ") + hipGetErrorString(e));
+        return 0;
+    }
+    std::unique_ptr<Ctx> c;
+    rc = lease_ctx(E, c, w, h);
+    if (!rc) {
+        Ctx& C = *c;
+        if (E->v1) rc = run_v1(*E, C, f0->d, f1->d, C.d_out);
+        else if (!E->v4) rc = run_v2(*E, C, f0->d, f1->d, C.d_out);
+        else if (E->tta || E->tta_temporal) {
+            std::lock_guard<std::mutex> g(E->tta_mu);
+            rc = run_v4_tta(*E, C.stream, f0->d, f1->d, w, h, timestep, C.d_out);
+            if (!rc && hipStreamSynchronize(C.stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "TTA stream sync failed");
+        } else rc = run_v4_replay(*E, C, f0->d, f1->d, timestep, C.d_out);
+        if (!rc && hipMemcpyAsync(out, C.d_out, nbytes, hipMemcpyDeviceToHost, C.stream) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "D2H failed");
+    }
+    if (c && hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(RIFE_HIP_EHIP, "stream sync failed");
+    if (c) release_ctx(E, c);
+    return rc;
+}
+int rife_hip_process_frames(const rife_hip_t* E, const rife_hip_frame_t* f0, const rife_hip_frame_t* f1, float timestep, uint8_t* out) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_process_frames_impl(E, f0, f1, timestep, out); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_process_frames: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_process_frames: unknown exception"); }
+}
+
+static int rife_hip_process_device_impl(const rife_hip_t* E, const void* d_in0, const void* d_in1, int w, int h, float timestep, void* d_out, void* hip_stream) {
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (!d_in0 || !d_in1 || !d_out) return fail(RIFE_HIP_EINVAL, "null frame pointer");
+    if ((rc = check_device(E->gpuid))) return rc;
+    const size_t nbytes = (size_t)w * h * 3;
+    Ctx* c;
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        auto ps = E->part_streams.find(hip_stream);
+        if (ps != E->part_streams.end()) tl_cu_budget = ps->second;      // a stream of rife_hip_stream_create: persistent grids for its part of the chip
+        auto& slot = E->stream_ctx[hip_stream];
+        if (!slot) {
+            slot.reset(new Ctx);
+            if (hip_stream) slot->stream = (hipStream_t)hip_stream;
+            else {
+                if (hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
+                slot->own_stream = true;
+            }
+        }
+        c = slot.get();
+    }
+    // two host threads on the same stream (in particular NULL = the engine's own) share one workspace: the second waits here instead of
+    // racing on its (re)allocation and scratch tensors - work on one stream executes in order anyway
+    std::lock_guard<std::mutex> use(c->use);
+    if (timestep == 0.f || timestep == 1.f) {
+        HIPCHK(hipMemcpyAsync(d_out, timestep == 0.f ? d_in0 : d_in1, nbytes, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        if (E->v1) {
+            if ((rc = ensure_ctx_v1(*c, w, h, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1))) return rc;
+            if ((rc = run_v1(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, (uint8_t*)d_out))) return rc;
+        } else if (!E->v4) {
+            if ((rc = ensure_ctx_v2(*c, w, h, E->uhd, E->tta ? 8 : 1, E->tta_temporal ? 2 : 1, E->v3, ctx_batch_serves(*E)))) return rc;
+            if ((rc = run_v2(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, (uint8_t*)d_out))) return rc;
+        } else if (E->tta || E->tta_temporal) {
+            // the TTA workspaces are shared: serialise, and drain before another stream may reuse them
+            std::lock_guard<std::mutex> g(E->tta_mu);
+            if ((rc = run_v4_tta(*E, c->stream, (const uint8_t*)d_in0, (const uint8_t*)d_in1, w, h, timestep, (uint8_t*)d_out))) return rc;
+            HIPCHK(hipStreamSynchronize(c->stream));
+        } else {
+            if ((rc = ensure_ctx(*c, w, h))) return rc;
+            if ((rc = run_v4_replay(*E, *c, (const uint8_t*)d_in0, (const uint8_t*)d_in1, timestep, (uint8_t*)d_out))) return rc;
+        }
+    }
+    if (!hip_stream) HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int rife_hip_process_device(const rife_hip_t* E, const void* d_in0, const void* d_in1, int w, int h, float timestep, void* d_out, void* hip_stream) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_process_device_impl(E, d_in0, d_in1, w, h, timestep, d_out, hip_stream); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_process_device: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_process_device: unknown exception"); }
+}
+
+// n resident pairs in one call (include/rife_hip.h): lockstep groups of two pairs (run_v4_group: the coarse-block trunks of a group are one
+// launch per layer) on leased workspaces and their streams, forked from and joined into `hip_stream` with events - no host wait.
+static int rife_hip_process_device_batch_impl(const rife_hip_t* E, int n, const void* const* d_in0, const void* const* d_in1, const float* timestep,
+                                              void* const* d_out, int w, int h, void* hip_stream) {
+    int rc;
+    if (n < 0 || (n > 0 && (!d_in0 || !d_in1 || !timestep || !d_out))) return fail(RIFE_HIP_EINVAL, "bad batch arguments");
+    if ((rc = process_common(E, w, h, 0.5f))) return rc;
+    for (int i = 0; i < n; i++) if (!d_in0[i] || !d_in1[i] || !d_out[i]) return fail(RIFE_HIP_EINVAL, "null frame pointer");
+    if (n == 0) return 0;
+    if ((rc = check_device(E->gpuid))) return rc;
+    const bool groups = E->v4 && !E->v40 && !E->v1 && !E->tta && !E->tta_temporal && E->t64;
+    if (!groups) {      // other families / TTA: the pairs one after the other on the caller's stream
+        for (int i = 0; i < n; i++)
+            if ((rc = rife_hip_process_device_impl(E, d_in0[i], d_in1[i], w, h, timestep[i], d_out[i], hip_stream))) return rc;
+        return 0;
+    }
+    hipStream_t user = (hipStream_t)hip_stream;
+    const size_t nbytes = (size_t)w * h * 3;
+    // the fork event goes back to the pool on EVERY exit path (re-recorded by its next user; waits already enqueued keep their own snapshot of it)
+    struct ForkLease {
+        const rife_hip_t* E; hipEvent_t ev = nullptr;
+        ~ForkLease() { if (ev) { std::lock_guard<std::mutex> g(E->mu); E->batch_fork.push_back(ev); } }
+    } fk{E};
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        if (!E->batch_fork.empty()) { fk.ev = E->batch_fork.back(); E->batch_fork.pop_back(); }
+    }
+    if (!fk.ev) HIPCHK(hipEventCreateWithFlags(&fk.ev, hipEventDisableTiming));
+    hipEvent_t fork = fk.ev;
+    if (user) HIPCHK(hipEventRecord(fork, user));      // NULL = "the engine's own streams": nothing to order against, the call synchronises before it returns
+    // At most MAXG groups (2 MAXG workspaces) are in flight however many pairs the call carries: further groups re-use them round-robin - work on a
+    // workspace's stream executes in order, so a re-used workspace simply queues behind its previous pair (device memory stays O(1) in n).
+    constexpr int MAXG = 4;
+    std::vector<std::unique_ptr<Ctx>> cs;
+    std::unique_ptr<Ctx> copy_ctx;                       // timestep 0 / 1 with no caller stream: one internal stream for the D2D copies
+    size_t next_slot = 0;
+    auto lease_new = [&](std::unique_ptr<Ctx>& c) -> bool {
+        if (lease_ctx(E, c, w, h, 1)) return false;
+        if (!c->ev_group && hipEventCreateWithFlags(&c->ev_group, hipEventDisableTiming) != hipSuccess) { release_ctx(E, c); return false; }
+        if (user && hipStreamWaitEvent(c->stream, fork, 0) != hipSuccess) { release_ctx(E, c); return false; }
+        return true;
+    };
+    auto lease = [&]() -> Ctx* {
+        if (cs.size() < (size_t)(2 * MAXG)) {
+            std::unique_ptr<Ctx> c;
+            if (!lease_new(c)) return nullptr;
+            cs.push_back(std::move(c));
+            return cs.back().get();
+        }
+        Ctx* c = cs[next_slot++ % cs.size()].get();     // always taken in pairs from an even-sized pool: the two of a group are distinct
+        tl_cu_budget = c->cu_budget;
+        return c;
+    };
+    rc = 0;
+    int pend = -1;
+    for (int i = 0; i <= n && !rc; i++) {
+        const bool copy = i < n && (timestep[i] == 0.f || timestep[i] == 1.f);
+        if (i < n && copy) {             // rife.cpp:2470-2480: an input frame unchanged - a D2D copy, no workspace; on the caller's stream when there is one
+            hipStream_t cst = user;
+            if (!cst) {
+                if (!copy_ctx && !lease_new(copy_ctx)) { rc = fail(RIFE_HIP_EHIP, "rife_hip_process_device_batch: no workspace (" + g_err + ")"); break; }
+                cst = copy_ctx->stream;
+            }
+            if (hipMemcpyAsync(d_out[i], timestep[i] == 0.f ? d_in0[i] : d_in1[i], nbytes, hipMemcpyDeviceToDevice, cst) != hipSuccess) rc = fail(RIFE_HIP_EHIP, "copy failed");
+            continue;
+        }
+        if (i < n && pend < 0) { pend = i; continue; }
+        if (pend < 0) break;
+        Ctx* a = lease(); Ctx* b = (a && i < n) ? lease() : nullptr;      // the odd pair left over is the call's LAST work item: one workspace, no partner
+        if (!a || (i < n && !b)) { rc = fail(RIFE_HIP_EHIP, "rife_hip_process_device_batch: no workspace (" + g_err + ")"); break; }
+        if (i < n) {            // group (pend, i)
+            Ctx* g2[2] = {a, b};
+            const uint8_t* p0[2] = {(const uint8_t*)d_in0[pend], (const uint8_t*)d_in0[i]};
+            const uint8_t* p1[2] = {(const uint8_t*)d_in1[pend], (const uint8_t*)d_in1[i]};
+            const float ts[2] = {timestep[pend], timestep[i]};
+            uint8_t* po[2] = {(uint8_t*)d_out[pend], (uint8_t*)d_out[i]};
+            rc = run_v4_group(*E, g2, 2, p0, p1, ts, po);
+        } else {
+            tl_cu_budget = a->cu_budget;
+            rc = run_v4_replay(*E, *a, (const uint8_t*)d_in0[pend], (const uint8_t*)d_in1[pend], timestep[pend], (uint8_t*)d_out[pend]);
+        }
+        pend = -1;
+    }
+    // join: the caller's stream continues after every internal stream (also after an error: nothing may still run on the frames when we return control of them)
+    if (copy_ctx) cs.push_back(std::move(copy_ctx));
+    for (auto& c : cs) {
+        if (!user) { if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(RIFE_HIP_EHIP, "stream sync failed"); }
+        else if (hipEventRecord(c->ev_group, c->stream) != hipSuccess || hipStreamWaitEvent(user, c->ev_group, 0) != hipSuccess) { (void)hipStreamSynchronize(c->stream); if (!rc) rc = fail(RIFE_HIP_EHIP, "join failed"); }
+    }
+    for (auto& c : cs) release_ctx(E, c);
+    return rc;
+}
+int rife_hip_process_device_batch(const rife_hip_t* E, int n, const void* const* d_in0, const void* const* d_in1, const float* timestep,
+                                  void* const* d_out, int w, int h, void* hip_stream) {
+    try { return rife_hip_process_device_batch_impl(E, n, d_in0, d_in1, timestep, d_out, w, h, hip_stream); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_process_device_batch: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_process_device_batch: unknown exception"); }
+}
+
+// ---- streams that own a part of the chip (include/rife_hip.h) ----
+int rife_hip_stream_create(const rife_hip_t* E, int part, int nparts, void** hip_stream) {
+    if (hip_stream) *hip_stream = nullptr;
+    if (!E || !hip_stream) return fail(RIFE_HIP_EINVAL, "null argument");
+    int rc;
+    if ((rc = check_device(E->gpuid))) return rc;
+    const int ncu = device_cus(true);
+    if (nparts < 1 || nparts > ncu || part < 0 || part >= nparts) return fail(RIFE_HIP_EINVAL, "bad partition");
+    hipStream_t st = nullptr;
+    int mine = 0;
+    if (nparts == 1) {
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        mine = ncu;
+    } else {
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int cu = 0; cu < ncu; cu++)
+            if (cu % nparts == part) { mask[cu / 32] |= 1u << (cu % 32); mine++; }
+        HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    }
+    std::lock_guard<std::mutex> g(E->mu);
+    E->part_streams[(void*)st] = mine;
+    *hip_stream = (void*)st;
+    return 0;
+}
+int rife_hip_stream_destroy(const rife_hip_t* E, void* hip_stream) {
+    if (!E || !hip_stream) return fail(RIFE_HIP_EINVAL, "null argument");
+    int rc;
+    if ((rc = check_device(E->gpuid))) return rc;
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        auto it = E->part_streams.find(hip_stream);
+        if (it == E->part_streams.end()) return fail(RIFE_HIP_EINVAL, "not a stream of rife_hip_stream_create");
+        E->part_streams.erase(it);
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
+    {
+        std::lock_guard<std::mutex> g(E->mu);
+        E->stream_ctx.erase(hip_stream);                                 // its workspace
+    }
+    HIPCHK(hipStreamDestroy((hipStream_t)hip_stream));
+    return 0;
+}
+
+// ---- page-locked host frames (include/rife_hip.h) ----
+void* rife_hip_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { g_err = "hipHostMalloc failed"; return nullptr; }
+    return p;
+}
+void rife_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
+int rife_hip_host_register(void* p, size_t bytes) {
+    if (!p || bytes == 0) return fail(RIFE_HIP_EINVAL, "null range");
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return 0;
+}
+int rife_hip_host_unregister(void* p) {
+    if (!p) return fail(RIFE_HIP_EINVAL, "null pointer");
+    HIPCHK(hipHostUnregister(p));
+    return 0;
+}
+
+int rife_hip_profile_enable(rife_hip_t* E, int on) {
+    if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
+    E->prof.collect();
+    E->prof.on = on != 0;
+    if (on) {
+        std::lock_guard<std::mutex> g(E->prof.mu);
+        std::fill(E->prof.ms.begin(), E->prof.ms.end(), 0.0);
+        std::fill(E->prof.flops.begin(), E->prof.flops.end(), 0.0);
+        std::fill(E->prof.launches.begin(), E->prof.launches.end(), 0LL);
+    }
+    return 0;
+}
+
+int rife_hip_profile_read(rife_hip_t* E, char* names, size_t names_cap, double* total_ms, long long* launches, double* flops, int max_classes) {
+    if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
+    E->prof.collect();
+    std::lock_guard<std::mutex> g(E->prof.mu);
+    std::string all;
+    int n = std::min<int>(max_classes, (int)E->prof.names.size());
+    for (int i = 0; i < n; i++) {
+        all += E->prof.names[i]; all += '\n';
+        total_ms[i] = E->prof.ms[i]; launches[i] = E->prof.launches[i]; flops[i] = E->prof.flops[i];
+    }
+    if (names && names_cap) { std::strncpy(names, all.c_str(), names_cap - 1); names[names_cap - 1] = 0; }
+    return n;
+}
+
+#ifdef RIFE_HIP_TEST_BUILD      // ======== include/rife_hip_test.h: test and bench builds only ========
+// ---- stage tap: flow{fi} with optional injection of flow0..flow{n_inject-1} (rife.cpp:2653-2669) -------------
+int rife_hip_v4_extract_flow(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, int fi,
+                             const float* const* inject, int n_inject, float* out6chw) {
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (!E->v4) return fail(RIFE_HIP_EINVAL, "stage taps exist for the rife-v4 family only");
+    if (fi < 0 || fi > 3 || n_inject < 0 || n_inject > fi) return fail(RIFE_HIP_EINVAL, "bad stage index");
+    if ((rc = check_device(E->gpuid))) return rc;
+    Ctx c;
+    if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
+    c.own_stream = true;
+    if ((rc = ensure_ctx(c, w, h))) return rc;
+    const size_t nbytes = (size_t)w * h * 3;
+    HIPCHK(hipMemcpyAsync(c.d_in0, in0, nbytes, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(c.d_in1, in1, nbytes, hipMemcpyHostToDevice, c.stream));
+    launch_preproc(c.stream, c.d_in0, c.w, c.h, c.img0, c.wp, c.hp);
+    launch_preproc(c.stream, c.d_in1, c.w, c.h, c.img1, c.wp, c.hp);
+    float* tmp = nullptr;
+    if ((rc = dalloc(c, tmp, (size_t)c.wp * c.hp * 6))) return rc;
+    const int nc = E->v40 ? 5 : 6;      // channels of blob flow{b}: rife-v4.6 PixelShuffle output 6, rife-v4 deconv output 5
+    for (int b = 0; b <= fi; b++) {
+        const int s = E->flow_div(b), Hb = c.hp / s, Wb = c.wp / s;
+        if (b < n_inject) {
+            HIPCHK(hipMemcpyAsync(tmp, inject[b], (size_t)Hb * Wb * nc * 4, hipMemcpyHostToDevice, c.stream));
+            hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(Wb, Hb), dim3(256), 0, c.stream, tmp, c.flow[b], nc, Hb, Wb, 8);
+        } else {
+            if ((rc = run_block_convs(*E, c, b, timestep))) return rc;
+        }
+        if (b < fi && (rc = run_flow_update(*E, c, b))) return rc;
+    }
+    const int s = E->flow_div(fi), Hb = c.hp / s, Wb = c.wp / s;
+    hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(Wb, Hb), dim3(256), 0, c.stream, c.flow[fi], tmp, nc, Hb, Wb, 8);
+    HIPCHK(hipMemcpyAsync(out6chw, tmp, (size_t)Hb * Wb * nc * 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+// ---- parity taps of the gather code (round 3): the 12-channel block input and the tail of the graph, on injected flows --------------------
+// Shared prologue: frames -> padded RGBX, then for every block k < n_inject the injected blob flow{k} goes through the hot path's own
+// k_flow_update into F, M (flownet.param:47-58, 99-105, 152-158).
+// `pending` != null: as in run_v4, the update of the LAST injected flow is left to the fused stem of the next block where the product does so
+// (flow_update_fused_into); *pending is then that flow.
+static int tap_prologue(const rife_hip_t* E, Ctx& c, const uint8_t* in0, const uint8_t* in1, int w, int h, const float* const* inject, int n_inject, float*& tmp,
+                        const float** pending = nullptr) {
+    int rc;
+    if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
+    c.own_stream = true;
+    if ((rc = ensure_ctx(c, w, h))) return rc;
+    const size_t nbytes = (size_t)w * h * 3;
+    HIPCHK(hipMemcpyAsync(c.d_in0, in0, nbytes, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(c.d_in1, in1, nbytes, hipMemcpyHostToDevice, c.stream));
+    launch_preproc(c.stream, c.d_in0, c.w, c.h, c.img0, c.wp, c.hp);
+    launch_preproc(c.stream, c.d_in1, c.w, c.h, c.img1, c.wp, c.hp);
+    if ((rc = dalloc(c, tmp, (size_t)c.wp * c.hp * 16))) return rc;
+    for (int k = 0; k < n_inject; k++) {
+        const int s = E->blk[k].scale, Hb = c.hp / s, Wb = c.wp / s;
+        HIPCHK(hipMemcpyAsync(tmp, inject[k], (size_t)Hb * Wb * 6 * 4, hipMemcpyHostToDevice, c.stream));
+        hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(Wb, Hb), dim3(256), 0, c.stream, tmp, c.flow[k], 6, Hb, Wb, 8);
+        if (pending && k == n_inject - 1 && k < 3 && flow_update_fused_into(*E, c, k + 1)) { *pending = c.flow[k]; continue; }
+        if (k < 3 && (rc = run_flow_update(*E, c, k))) return rc;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// what = 0: block input of IFBlock b (1..3; blobs 99 / 199 / 262 of models/rife-v4.6/flownet.param:62, 115, 165) as k_assemble<S> computes it
+//           (the unfused form of the same assemble_pixel<S> / warp_rgbx code);
+// what = 1: the same tensor read back THROUGH THE PRODUCT'S FUSED STEM KERNEL stem0_fused_kernel<S, ...> (stem_fused.h), which keeps it in
+//           LDS only: the kernel is run with one-hot weights (output channel 12 p + k = input channel k under tap (1 + p / 2, 1 + p % 2), bias 0,
+//           slope 1), so that its stride-2 output holds the block input's four pixel parities; the split-f16 matrix path returns hi + lo of
+//           every value, i.e. the value to 2^-22 relative;
+// what = 2: blob out0 (flownet.param:217) before the postproc, from the unfused float tail k_final_float (b ignored; n_inject = 4);
+// what = 4 / 3: F, M as block b's stem reads them: after k_flow_update / written by the stem that applies the update of flow{b-1} itself.
+// what = 5: block 3's input through stem_rs_kernel, the product's kernel for that block (see below).
+// out: planar CHW fp32, 12 x hp/S x wp/S (what 0, 1) or 3 x hp x wp (what 2).  n_inject must be b (what 0, 1) or 4 (what 2).
+static int rife_hip_v4_tap_impl(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, int what, int b,
+                                const float* const* inject, int n_inject, float* out) {
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (!E->v4 || E->v40) return fail(RIFE_HIP_EINVAL, "the gather taps exist for the rife-v4.6 graph only");
+    if (what < 0 || what > 5) return fail(RIFE_HIP_EINVAL, "bad tap");
+    if (what == 5 && b != 3) return fail(RIFE_HIP_EINVAL, "the row-streaming stem kernel serves block 3");
+    if (what == 2 ? n_inject != 4 : (b < 1 || b > 3 || n_inject != b)) return fail(RIFE_HIP_EINVAL, "bad block / injection count");
+    if ((rc = check_device(E->gpuid))) return rc;
+    Ctx c; float* tmp = nullptr;
+    const float* pending = nullptr;
+    if ((rc = tap_prologue(E, c, in0, in1, w, h, inject, n_inject, tmp, (what == 1 || what == 3) ? &pending : nullptr))) return rc;
+    hipStream_t st = c.stream;
+    // what = 3 / 4: F (4 channels) and M as block b's stem finds them, [5][hp][wp]: 4 = after k_flow_update, 3 = as written by the stem that applies
+    // the last update itself (only where the product fuses it: EINVAL otherwise)
+    auto copy_fm = [&](const float4* F, const float* M) -> int {
+        hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(c.wp, c.hp), dim3(256), 0, st, reinterpret_cast<const float*>(F), tmp, 4, c.hp, c.wp, 4);
+        HIPCHK(hipGetLastError());
+        const size_t P = (size_t)c.wp * c.hp;
+        HIPCHK(hipMemcpyAsync(out, tmp, P * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(out + 4 * P, M, P * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    };
+    if (what == 4) return copy_fm(c.F, c.M);
+    if (what == 5) {
+        // Block 3's input THROUGH THE PRODUCT'S ROW-STREAMING STEM KERNEL stem_rs_kernel (stem_rs.h): both of its convolutions run with one-hot
+        // weights.  Stem 0: output channel 12 j + k = input channel k under tap (1 + g, 1 + j) (pixel parity p = 2 g + j of the block input; two
+        // parities per launch); stem 1: output channel = input channel under tap (ty, tx) in {1, 2}^2 (the four parities of the half-resolution
+        // tensor).  Eight launches return every pixel of the 12-channel block input once; each value passed the split-f16 matrix path twice
+        // (hi + lo of hi + lo: 2^-21 relative).  Bias 0, slope 1.
+        const int Hq = c.hp / 4, Wq = c.wp / 4;
+        const S16Geom G(Hq, Wq);
+        const size_t nb = G.bytes(64), pl = G.plane();
+        unsigned char* dout = nullptr; uint16_t *dw0 = nullptr, *dw1 = nullptr; float *dbias = nullptr, *dslope = nullptr;
+        if ((rc = dalloc(c, dout, nb)) || (rc = dalloc(c, dw0, (size_t)9 * 2 * 32 * 8)) || (rc = dalloc(c, dw1, (size_t)2 * 9 * 2 * 64 * 8)) ||
+            (rc = dalloc(c, dbias, 64)) || (rc = dalloc(c, dslope, 64))) return rc;
+        std::vector<float> hz(64, 0.f), ho(64, 1.f);
+        HIPCHK(hipMemcpyAsync(dbias, hz.data(), 256, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dslope, ho.data(), 256, hipMemcpyHostToDevice, st));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_rs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, SRS_LDS));
+        std::vector<unsigned char> host(nb);
+        int inv[32];                                                     // row of a 32-row block that holds channel ch (pack_weights_h2_perm)
+        for (int i = 0; i < 32; i++) inv[s16_row_channel(i)] = i;
+        for (int g = 0; g < 2; g++)
+            for (int ty = 1; ty <= 2; ty++)
+                for (int tx = 1; tx <= 2; tx++) {
+                    std::vector<uint16_t> h0((size_t)9 * 2 * 32 * 8, 0), h1((size_t)2 * 9 * 2 * 64 * 8, 0);
+                    for (int j = 0; j < 2; j++)
+                        for (int k = 0; k < 12; k++) h0[(((size_t)((1 + g) * 3 + 1 + j) * 2 + k / 8) * 32 + 12 * j + k) * 8 + k % 8] = f2h(1.f);
+                    for (int oc = 0; oc < 24; oc++)
+                        h1[((((size_t)(oc / 16) * 9 + ty * 3 + tx) * 2 + (oc % 16) / 8) * 64 + inv[oc]) * 8 + oc % 8] = f2h(1.f);
+                    HIPCHK(hipMemcpyAsync(dw0, h0.data(), h0.size() * 2, hipMemcpyHostToDevice, st));
+                    HIPCHK(hipMemcpyAsync(dw1, h1.data(), h1.size() * 2, hipMemcpyHostToDevice, st));
+                    HIPCHK(hipMemsetAsync(dout, 0, nb, st));
+                    StemRsArgs a;
+                    a.img0 = c.img0; a.img1 = c.img1; a.F = c.F; a.M = c.M; a.w0 = dw0; a.bias0 = dbias; a.slope0 = dslope; a.w1 = dw1; a.bias1 = dbias; a.slope1 = dslope;
+                    a.out = dout; a.timestep = timestep; a.tsp = nullptr; a.wp = c.wp; a.hp = c.hp; a.Hq = Hq; a.Wq = Wq; a.pitch = G.pitch; a.plane = G.plane();
+                    a.nunits = ((Wq + SRS_SW - 1) / SRS_SW) * Hq;
+                    const int nwg = std::min(2 * device_cus(), a.nunits);
+                    hipLaunchKernelGGL((stem_rs_kernel<0>), dim3(nwg), dim3(SRS_NTHR), SRS_LDS, st, a);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipMemcpyAsync(host.data(), dout, nb, hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    for (int j = 0; j < 2; j++)
+                        for (int k = 0; k < 12; k++) {
+                            const int oc = 12 * j + k;
+                            const _Float16* hi = reinterpret_cast<const _Float16*>(host.data() + (size_t)(2 * (oc / 16)) * pl);
+                            const _Float16* lo = reinterpret_cast<const _Float16*>(host.data() + (size_t)(2 * (oc / 16) + 1) * pl);
+                            for (int q = 0; q < Hq; q++)
+                                for (int x = 0; x < Wq; x++) {
+                                    const size_t e = ((size_t)(q + 1) * G.pitch + x + 1) * 16 + oc % 16;
+                                    out[((size_t)k * c.hp + 4 * q + 2 * (ty - 1) + g) * c.wp + 4 * x + 2 * (tx - 1) + j] = (float)hi[e] + (float)lo[e];
+                                }
+                        }
+                }
+        return 0;
+    }
+    if (what == 3 && !pending) return fail(RIFE_HIP_EINVAL, "the flow update before this block is not fused into its stem");
+    if (what == 2) {
+        float4* outf = nullptr;
+        if ((rc = dalloc(c, outf, (size_t)c.wp * c.hp))) return rc;
+        hipLaunchKernelGGL(k_final_float, grid2d(c.wp, c.hp), dim3(256), 0, st, c.img0, c.img1, c.F, c.M, c.flow[3], outf, c.wp, c.hp);
+        hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(c.wp, c.hp), dim3(256), 0, st, reinterpret_cast<const float*>(outf), tmp, 3, c.hp, c.wp, 4);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, tmp, (size_t)c.wp * c.hp * 3 * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
+    const rife_hip::Block& B = E->blk[b];
+    const int s = B.scale, Hb = c.hp / s, Wb = c.wp / s;
+    if (what == 0) {
+        if ((rc = run_assemble(*E, c, b, timestep))) return rc;
+        hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(Wb, Hb), dim3(256), 0, st, c.X, tmp, 12, Hb, Wb, 16);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, tmp, (size_t)Hb * Wb * 12 * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
+    // what == 1: the fused stem kernel of the product with one-hot weights
+    const int NT = s == 1 ? 32 : 64, cout = B.c / 2, per = std::min(4, cout / 12), nlaunch = (4 + per - 1) / per;
+    const int Ho = Hb / 2, Wo = Wb / 2;
+    std::vector<float> hbias(64, 0.f), hslope(64, 1.f), host((size_t)Ho * Wo * cout);
+    float *dbias = nullptr, *dslope = nullptr; uint16_t* dw = nullptr;
+    if ((rc = dalloc(c, dbias, 64)) || (rc = dalloc(c, dslope, 64)) || (rc = dalloc(c, dw, (size_t)9 * 2 * NT * 8))) return rc;
+    HIPCHK(hipMemcpyAsync(dbias, hbias.data(), 256, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dslope, hslope.data(), 256, hipMemcpyHostToDevice, st));
+    for (int l = 0; l < nlaunch; l++) {
+        std::vector<uint16_t> hw((size_t)9 * 2 * NT * 8, 0);
+        for (int q = 0; q < per && l * per + q < 4; q++) {
+            const int p = l * per + q, t = (1 + p / 2) * 3 + 1 + p % 2;
+            for (int k = 0; k < 12; k++) hw[(((size_t)t * 2 + k / 8) * NT + 12 * q + k) * 8 + k % 8] = f2h(1.f);
+        }
+        HIPCHK(hipMemcpyAsync(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice, st));
+        StemFusedArgs fa;
+        fa.img0 = c.img0; fa.img1 = c.img1; fa.F = c.F; fa.M = c.M; fa.wpk = dw; fa.bias = dbias; fa.slope = dslope;
+        fa.out = c.S1; fa.timestep = timestep; fa.tsp = nullptr; fa.wp = c.wp; fa.hp = c.hp; fa.Ho = Ho; fa.Wo = Wo; fa.out_ld = cout; fa.Cout = cout;
+        fa.tiles_x = (Wo + 31) / 32;
+        const int nb = fa.tiles_x * ((Ho + 3) / 4);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem0_fused_kernel<2, 2, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, stemf_lds_bytes<2>()));
+        if (pending) {                                                   // every launch reads the old F, M and writes the same new ones
+            fa.pend.flow = pending; fa.pend.Fw = c.F2; fa.pend.Mw = c.M2;
+            if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2, 0, true>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+            else hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256, true>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);
+            if (what == 3) { HIPCHK(hipGetLastError()); return copy_fm(c.F2, c.M2); }
+        } else if (s == 4) hipLaunchKernelGGL((stem0_fused_kernel<4, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+        else if (s == 2) hipLaunchKernelGGL((stem0_fused_kernel<2, 2>), dim3(nb), dim3(512), stemf_lds_bytes<2>(), st, fa);
+        else hipLaunchKernelGGL((stem0_fused_kernel<1, 1, 256>), dim3(nb), dim3(512), (stemf_lds_bytes<1, 256>()), st, fa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(host.data(), c.S1, host.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int q = 0; q < per && l * per + q < 4; q++) {
+            const int p = l * per + q, py = p / 2, px = p % 2;
+            for (int k = 0; k < 12; k++)
+                for (int y = 0; y < Ho; y++)
+                    for (int x = 0; x < Wo; x++)
+                        out[((size_t)k * Hb + 2 * y + py) * Wb + 2 * x + px] = host[((size_t)y * Wo + x) * cout + 12 * q + k];
+        }
+    }
+    return 0;
+}
+int rife_hip_v4_tap(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, int what, int b,
+                    const float* const* inject, int n_inject, float* out) {      // nothing may throw across the C boundary
+    if (!in0 || !in1 || !out) return fail(RIFE_HIP_EINVAL, "null frame / output pointer");
+    if (n_inject > 0 && !inject) return fail(RIFE_HIP_EINVAL, "n_inject > 0 without blobs");
+    for (int k = 0; k < n_inject && k < 4; k++) if (!inject[k]) return fail(RIFE_HIP_EINVAL, "null injected blob");
+    try { return rife_hip_v4_tap_impl(E, in0, in1, w, h, timestep, what, b, inject, n_inject, out); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EINVAL, std::string("v4_tap: ") + e.what()); }
+}
+
+// The plain v4 pass with the first n_inject (0..3) blobs flow{k} injected instead of computed: the remaining blocks and the tail run on the
+// product's own schedule (fused stems, fused tail of head_h2_kernel<EPI_FINAL>), so that flows which leave the frame by hundreds of pixels
+// reach exactly the gather code a real pass runs.  out: w x h u8 RGB.
+static int rife_hip_v4_process_injected_impl(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep,
+                                             const float* const* inject, int n_inject, uint8_t* out) {
+    int rc;
+    if ((rc = process_common(E, w, h, timestep))) return rc;
+    if (!E->v4 || E->v40) return fail(RIFE_HIP_EINVAL, "flow injection into the plain pass exists for the rife-v4.6 graph only");
+    if (n_inject < 0 || n_inject > 3) return fail(RIFE_HIP_EINVAL, "bad injection count");
+    if ((rc = check_device(E->gpuid))) return rc;
+    Ctx c; float* tmp = nullptr;
+    const float* pending = nullptr;
+    if ((rc = tap_prologue(E, c, in0, in1, w, h, inject, n_inject, tmp, &pending))) return rc;
+    const bool fuse_tail = trunk_h2() && g_head_h2 && g_fuse_tail && E->blk[3].head.d_wh != nullptr;
+    FinalArgs fin{c.img0, c.img1, c.F, c.M, c.d_out, c.w, c.h, c.wp, c.hp};
+    for (int b = n_inject; b < 4; b++) {
+        if ((rc = run_block_convs(*E, c, b, timestep, (b == 3 && fuse_tail) ? &fin : nullptr, nullptr, PH_ALL, pending))) return rc;
+        pending = nullptr;
+        if (b < 3 && flow_update_fused_into(*E, c, b + 1)) pending = c.flow[b];
+        else if (b < 3 && (rc = run_flow_update(*E, c, b))) return rc;
+    }
+    if (!fuse_tail) hipLaunchKernelGGL(k_final, grid2d(c.w, c.h), dim3(256), 0, c.stream, c.img0, c.img1, c.F, c.M, c.flow[3], c.d_out, c.w, c.h, c.wp, c.hp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c.d_out, (size_t)w * h * 3, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return 0;
+}
+int rife_hip_v4_process_injected(const rife_hip_t* E, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep,
+                                 const float* const* inject, int n_inject, uint8_t* out) {      // nothing may throw across the C boundary
+    if (!in0 || !in1 || !out) return fail(RIFE_HIP_EINVAL, "null frame / output pointer");
+    if (n_inject > 0 && !inject) return fail(RIFE_HIP_EINVAL, "n_inject > 0 without blobs");
+    for (int k = 0; k < n_inject && k < 4; k++) if (!inject[k]) return fail(RIFE_HIP_EINVAL, "null injected blob");
+    try { return rife_hip_v4_process_injected_impl(E, in0, in1, w, h, timestep, inject, n_inject, out); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EINVAL, std::string("v4_process_injected: ") + e.what()); }
+}
+
+#endif  // RIFE_HIP_TEST_BUILD
+
+static int rife_hip_graph_check_impl(const char* base) {
+    if (!base) return fail(RIFE_HIP_EINVAL, "null argument");
+    GraphNet n;
+    return graph_load(n, base, true);
+}
+int rife_hip_graph_check(const char* base) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_graph_check_impl(base); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_graph_check: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_graph_check: unknown exception"); }
+}
+
+#ifdef RIFE_HIP_TEST_BUILD      // ======== include/rife_hip_test.h (continued) ========
+int rife_hip_v4_flow_dims(const rife_hip_t* E, int w, int h, int fi, int* channels, int* fh, int* fw) {
+    if (!E || !E->loaded || !E->v4) return fail(RIFE_HIP_EINVAL, "flow blobs exist for a loaded rife-v4 family engine only");
+    if (fi < 0 || fi > 3 || w <= 0 || h <= 0 || !channels || !fh || !fw) return fail(RIFE_HIP_EINVAL, "bad argument");
+    const int wp = (w + 31) / 32 * 32, hp = (h + 31) / 32 * 32;
+    *channels = E->v40 ? 5 : 6; *fh = hp / E->flow_div(fi); *fw = wp / E->flow_div(fi);
+    return 0;
+}
+
+// ---- single-kernel entry points ------------------------------------------------------------------------------
+static int op_conv_common(int gpuid, const float* x, int c, int h, int w, const float* weight, const float* bias, int outc, int stride,
+                          bool deconv, int epi, const float* residual, const float* slope, float* out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    ConvLayer L;
+    L.cin = c; L.cout = outc; L.stride = deconv ? 1 : stride; L.deconv = deconv; L.epi = epi;
+    if ((rc = upload_layer(L, weight, bias, slope, 1.0f))) { free_layer(L); return rc; }
+    const int ho = deconv ? 2 * h : (h + 2 - 3) / stride + 1, wo = deconv ? 2 * w : (w + 2 - 3) / stride + 1;
+    const int ldi = L.cin_p;
+    float *d_chw = nullptr, *d_x = nullptr, *d_y = nullptr, *d_r = nullptr, *d_o = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_chw); (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_r); (void)hipFree(d_o); free_layer(L); };
+    const size_t nin = (size_t)c * h * w, nout = (size_t)outc * ho * wo;
+    hipError_t e = hipMalloc(&d_chw, std::max(nin, nout) * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_x, (size_t)h * w * ldi * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_y, (size_t)ho * wo * outc * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_o, nout * 4);
+    if (e == hipSuccess && residual) e = hipMalloc(&d_r, (size_t)ho * wo * outc * 4);
+    if (e != hipSuccess) { cleanup(); return fail(RIFE_HIP_EHIP, "hipMalloc failed"); }
+    (void)hipMemcpy(d_chw, x, nin * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(w, h), dim3(256), 0, 0, d_chw, d_x, c, h, w, ldi);
+    TensorView rv{d_r, outc, 0};
+    if (residual) {
+        (void)hipMemcpy(d_chw, residual, nout * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_chw_to_nhwc, grid2d(wo, ho), dim3(256), 0, 0, d_chw, d_r, outc, ho, wo, outc);
+    }
+    rc = launch_conv(L, {d_x, ldi, 0}, h, w, {d_y, outc, 0}, residual ? &rv : nullptr, 0);
+    if (!rc) {
+        hipLaunchKernelGGL(k_nhwc_to_chw, grid2d(wo, ho), dim3(256), 0, 0, d_y, d_o, outc, ho, wo, outc);
+        e = hipMemcpy(out, d_o, nout * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RIFE_HIP_EHIP, std::string("op: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    return rc;
+}
+
+int rife_hip_op_conv3x3(int gpuid, const float* x, int c, int h, int w, const float* weight, const float* bias, int outc, int stride,
+                        const float* residual, const float* slope, float* out) {
+    if (stride != 1 && stride != 2) return fail(RIFE_HIP_EINVAL, "stride must be 1 or 2");
+    return op_conv_common(gpuid, x, c, h, w, weight, bias, outc, stride, false, EPI_STORE, residual, slope, out);
+}
+
+int rife_hip_op_deconv4x4(int gpuid, const float* x, int c, int h, int w, const float* weight, const float* bias, int outc, const float* slope, float* out) {
+    return op_conv_common(gpuid, x, c, h, w, weight, bias, outc, 2, true, EPI_DECONV, nullptr, slope, out);
+}
+
+int rife_hip_op_warp(int gpuid, const float* image, const float* flow, int c, int h, int w, float* out) {
+    int rc;
+    if ((rc = check_device(gpuid))) return rc;
+    float *d_i = nullptr, *d_f = nullptr, *d_o = nullptr;
+    const size_t n = (size_t)c * h * w;
+    hipError_t e = hipMalloc(&d_i, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_f, (size_t)2 * h * w * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_o, n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_i, image, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_f, flow, (size_t)2 * h * w * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_warp_chw, grid2d(w, h), dim3(256), 0, 0, d_i, d_f, d_o, c, h, w);
+        e = hipMemcpy(out, d_o, n * 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_i); (void)hipFree(d_f); (void)hipFree(d_o);
+    if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("op_warp: ") + hipGetErrorString(e));
+    return 0;
+}
+
+#endif  // RIFE_HIP_TEST_BUILD
+
+#ifdef RIFE_HIP_BENCH_BUILD
+#include "bench_hooks.h"      // bench-only / probe entry points and ablation instantiations: librife_hip_bench.so (tools/*.py), never the product
+#endif
+
+// tooling: structural hash of a named blob of a .param file (used to derive / test the compiled-in constants)
+static int rife_hip_param_hash_impl(const char* param_path, const char* blob, uint64_t* out) {
+    NcnnModel m;
+    if (!m.load_param(param_path)) return fail(RIFE_HIP_EIO, m.error);
+    *out = m.structural_hash(blob);
+    return *out ? 0 : fail(RIFE_HIP_EMODEL, "no such blob");
+}
+int rife_hip_param_hash(const char* param_path, const char* blob, uint64_t* out) {      // nothing may throw across the C boundary (malformed model files, std::bad_alloc)
+    try { return rife_hip_param_hash_impl(param_path, blob, out); }
+    catch (const std::exception& e) { return fail(RIFE_HIP_EIO, std::string("rife_hip_param_hash: ") + e.what()); }
+    catch (...) { return fail(RIFE_HIP_EIO, "rife_hip_param_hash: unknown exception"); }
+}
+
+}  // extern "C"

@@ -5,11 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tools import gen_models, gen_frames
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
-g = amd.RIFE(0, rife_v4=True); g.load(gen_models.ensure(None, "rife-v4.6"))
+# --test-build: the test build (reads RIFE_HIP_POOL_PARTS: 0 = whole-chip pool streams at every caller count, the round-5 behaviour); default: the product
+mod = amd.test_build() if "--test-build" in sys.argv else amd
+print("library: %s, RIFE_HIP_POOL_PARTS=%s" % ("test build" if mod is not amd else "product", os.environ.get("RIFE_HIP_POOL_PARTS", "(unset)")), flush=True)
+g = mod.RIFE(0, rife_v4=True); g.load(gen_models.ensure(None, "rife-v4.6"))
 for (w, h) in ((3840, 2160), (1920, 1080)):
     base = gen_frames.smooth_pair(w // 4, h // 4, 3)
     fr = [np.ascontiguousarray(np.kron(np.roll(base[i % 2], 5 * i, axis=1), np.ones((4, 4, 1), np.uint8))) for i in range(9)]
-    n = 48
+    n = 96
     for kind in ("pageable", "page-locked"):
         if kind == "page-locked":
             pf = [amd.pinned_empty(f.shape) for f in fr]
@@ -23,6 +26,7 @@ for (w, h) in ((3840, 2160), (1920, 1080)):
         for nt in (1, 2, 3, 4):
             def worker(k):
                 for i in range(k, n, nt): g.process(*pairs[i], outimage=outs[i])
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(nt)]; [x.start() for x in th]; [x.join() for x in th]      # untimed: the pool settles on this caller count
             t0 = time.perf_counter(); th = [threading.Thread(target=worker, args=(k,)) for k in range(nt)]; [x.start() for x in th]; [x.join() for x in th]
             res.append("%d thr %.1f" % (nt, n / (time.perf_counter() - t0)))
         g.process_batch([p[0] for p in pairs], [p[1] for p in pairs], [p[2] for p in pairs], outs)

@@ -52,4 +52,8 @@ for h, w in sizes:
         for g in (128, 64):
             rc, us, _ = rs2(h, w, (g << 24) | 0x10000, 40)
             print("%dx%d conv_rs2 planned for %3d CUs                   rc=%d %.1f us" % (h, w, g, rc, us), flush=True)
+rc, us, _ = rs2(544, 960, 0x1000, 20)
+print("544x960 conv_rs2 barrier trace (stderr) rc=%d %.1f us" % (rc, us), flush=True)
+rc, us, _ = rs2(544, 960, 0x1000 | NODMA | NOSTORE, 20)
+print("544x960 conv_rs2 barrier trace, math only (stderr) rc=%d %.1f us" % (rc, us), flush=True)
 sys.exit(1 if bad else 0)
