@@ -44,6 +44,10 @@ int rife_hip_op_deconv4x4(int gpuid, const float* x_chw, int c, int h, int w, co
 /* rife.Warp (src/warp.cpp:96-168): image c x h x w, flow 2 x h x w. */
 int rife_hip_op_warp(int gpuid, const float* image_chw, const float* flow_chw, int c, int h, int w, float* out_chw);
 
+/* ---- workspace pool of the host-buffer entry points (csrc/engine_abi.h: lease_ctx / release_ctx): pooled = idle workspaces the engine holds,
+ * leased = workspaces in use by callers right now, high_water = the most callers in flight at any of the last 32 leases (the pool is trimmed to it). */
+int rife_hip_pool_state(const rife_hip_t* r, int* pooled, int* leased, int* high_water);
+
 #ifdef __cplusplus
 }
 #endif

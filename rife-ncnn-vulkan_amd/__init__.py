@@ -33,7 +33,7 @@ C_ABI_SYMBOLS = [
     "rife_hip_graph_check", "rife_hip_param_hash",
 ]
 # include/rife_hip_test.h: exported by librife_hip_test.so (and the bench build) only
-TEST_ABI_SYMBOLS = ["rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_v4_tap", "rife_hip_v4_process_injected", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp"]
+TEST_ABI_SYMBOLS = ["rife_hip_v4_extract_flow", "rife_hip_v4_flow_dims", "rife_hip_v4_tap", "rife_hip_v4_process_injected", "rife_hip_op_conv3x3", "rife_hip_op_deconv4x4", "rife_hip_op_warp", "rife_hip_pool_state"]
 
 
 def build(force=False):
@@ -89,6 +89,7 @@ def _load(path, with_test_surface):
         L.rife_hip_op_conv3x3.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, ci, vp, vp, vp]
         L.rife_hip_op_deconv4x4.argtypes = [ci, vp, ci, ci, ci, vp, vp, ci, vp, vp]
         L.rife_hip_op_warp.argtypes = [ci, vp, vp, ci, ci, ci, vp]
+        L.rife_hip_pool_state.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     return L
 
 
@@ -308,6 +309,13 @@ class RIFE:
     def _need_taps(self):
         if not self._taps:
             raise RifeError("the parity taps (include/rife_hip_test.h) live in the test build: create the engine with amd.test_build().RIFE(...)")
+
+    def pool_state(self):
+        """(pooled, leased, high_water) of the workspace pool of the host-buffer entry points (test build; include/rife_hip_test.h)."""
+        self._need_taps()
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(self._L.rife_hip_pool_state(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "pool_state", self._L)
+        return a.value, b.value, c.value
 
     def v4_extract_flow(self, in0image, in1image, timestep, fi, inject=()):
         self._need_taps()

@@ -150,20 +150,22 @@ static int process_common(const rife_hip* E, int w, int h, float timestep) {
 }
 
 // Workspace pool of the host-buffer entry points (rife_hip_process from the reference's proc threads, process_frames, the workers of process_batch).
-// Round 6: the pool lays its streams out over the chip the way bench.py's resident-frame legs do, from the number of callers in flight: fewer than four
-// -> ordinary streams (the whole chip each: 1 in flight is fastest there, 2 - 3 gain nothing from a partition, profiles/r4/cumask_probe.txt); four and more ->
-// frames of 4 Mpixel and more two per half of the compute units, smaller ones one per quarter (CU index mod parts, like rife_hip_stream_create).  The bytes do
-// not depend on the layout (kernel selection never looks at a partition).  RIFE_HIP_POOL_PARTS (A/B, test build): 0 = never partition, n = always n parts.
-// "Callers in flight" is the MOST that were in flight at any of the last 32 leases, not the count of the moment: four threads that call back to back are
-// seen as 3 or 4 at a lease, and a layout that followed the moment rebuilt a 1.6 GB workspace at every flip (measured: 4 threads 229 frames/s against 469 from
-// 3, profiles/r6/host_path_before_hysteresis.txt).
-// Trimming: a released workspace is destroyed when the pool holds more than that same high-water mark (a burst of N concurrent 4K callers no longer pins
-// N x 1.6 GB for the engine's life); workspaces of the layout that is no longer in use go first, then the oldest.
+// Pool streams are ordinary streams: every workspace sees the whole chip.  Round 6 built and measured the layout VERDICT r5 (item 6) asked for - CU-partitioned
+// pool streams from the number of callers in flight (four and more: frames of 4 Mpixel and more two per half of the compute units, smaller ones one per
+// quarter, like bench.py's resident-frame legs; "in flight" = the most at any of the last 32 leases, because a layout that follows the count of the moment
+// rebuilds a 1.6 GB workspace at every flip) - and it LOSES on this path (profiles/r6/ab_pool_partitions.txt, same call, 96 pairs, two rounds): 4K process()
+// from 4 threads 243 - 321 frames/s partitioned against 424 - 450 whole-chip, process_batch() 322 - 372 against 454 - 485; 1080p 559 - 647 against 1,364 - 1,472.
+// The H2D / D2H copies of a caller ride on its workspace's stream, and on a CU-masked stream they are no longer SDMA transfers that overlap the other callers'
+// kernels.  With whole-chip streams the reference's own surface already reaches the resident-frame headline of the same box within 1 - 3 % (3 caller threads
+// 475 - 490, process_batch 483 - 485 frames/s at 4K).  The layout stays reachable for A/B: RIFE_HIP_POOL_PARTS=2 / 4 (test build) forces it, =3 selects the
+// from-the-callers rule.
+// Trimming: a released workspace is destroyed when the pool holds more than the most callers that were in flight at any of the last 32 leases (a burst of N
+// concurrent 4K callers no longer pins N x 1.6 GB for the engine's life); workspaces of a layout that is no longer in use go first, then the
+// oldest.
 static int pool_layout(int callers, int w, int h) {
     const int forced = process_switches().pool_parts;
-    if (forced == 0 || forced == 1) return 1;
     if (forced == 2 || forced == 4) return forced;
-    if (callers < 4) return 1;
+    if (forced != 3 || callers < 4) return 1;
     return (long long)w * h >= 4000000ll ? 2 : 4;
 }
 // force_parts = 1: a whole-chip stream whatever the callers in flight (the lockstep groups of process_batch: a group's batched coarse-block launches ride on ONE
@@ -1066,6 +1068,17 @@ int rife_hip_op_conv3x3(int gpuid, const float* x, int c, int h, int w, const fl
 
 int rife_hip_op_deconv4x4(int gpuid, const float* x, int c, int h, int w, const float* weight, const float* bias, int outc, const float* slope, float* out) {
     return op_conv_common(gpuid, x, c, h, w, weight, bias, outc, 2, true, EPI_DECONV, nullptr, slope, out);
+}
+
+int rife_hip_pool_state(const rife_hip_t* E, int* pooled, int* leased, int* high_water) {
+    if (!E) return fail(RIFE_HIP_EINVAL, "null engine");
+    std::lock_guard<std::mutex> g(E->mu);
+    int hw = 1;
+    for (int v : E->lease_hist) hw = std::max(hw, v);
+    if (pooled) *pooled = (int)E->free_ctx.size();
+    if (leased) *leased = E->leased;
+    if (high_water) *high_water = hw;
+    return 0;
 }
 
 int rife_hip_op_warp(int gpuid, const float* image, const float* flow, int c, int h, int w, float* out) {

@@ -38,7 +38,7 @@ struct Switches {
     bool v2_fused_stem;        // RIFE_HIP_V2_FUSED_STEM=0: k2_assemble + conv_h2s2 instead of stem2_fused_kernel
     bool v2_stem_r64;          // RIFE_HIP_V2_STEM_R64=0: scale-1 fused stem with two workgroups per CU
     bool v2_skip_copy;         // RIFE_HIP_V2_SKIP_COPY=1: U-Net skips copied (k2_copy_view) instead of stored twice
-    int pool_parts;            // RIFE_HIP_POOL_PARTS=0..4: -1 = from the callers in flight (pool_layout), 0 / 1 = never partition, 2 / 4 = always
+    int pool_parts;            // RIFE_HIP_POOL_PARTS: 2 / 4 = pool streams own 1 / 2, 1 / 4 of the compute units; 3 = that layout from four callers in flight on; else whole-chip streams (default: measured faster, pool_layout)
     // ---- engine scope
     bool t64, rs, rs2, stem_rs, tta_consensus, tail_rs, tail_rs_always, fuse_flow;      // RIFE_HIP_T64 / RS / RS2 / STEM_RS / TTA_CONSENSUS / TAIL_RS (0, 2) / FUSE_FLOW=1
     int ks_mask;               // RIFE_HIP_KS=<bit mask of blocks on conv_ks>; -1 = not set

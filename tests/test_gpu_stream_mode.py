@@ -158,3 +158,31 @@ def test_partition_streams_give_the_same_bytes(modeldirs):
     g.process_device(d0[0].data_ptr(), d1[0].data_ptr(), w, h, 0.5, outs[0].data_ptr(), one)
     torch.cuda.synchronize()
     assert np.array_equal(outs[0].cpu().numpy(), want[0])
+
+
+def test_workspace_pool_is_trimmed_to_the_callers_in_flight(modeldirs):
+    """The pool of the host-buffer entry points (csrc/engine_abi.h lease_ctx / release_ctx): a burst of four concurrent callers leaves at most
+    four workspaces pooled, and once 32 leases have gone by with one caller in flight the pool is back to ONE workspace - the burst's memory is returned.  The
+    frames are the same bytes before, during and after."""
+    t = amd.test_build()
+    g = t.RIFE(0, rife_v4=True); g.load(modeldirs["rife-v4.6"])
+    w, h = 640, 360
+    prs = [gen_frames.smooth_pair(w, h, 80 + i) for i in range(4)]
+    want = [g.process(p[0], p[1], 0.5) for p in prs]
+    assert g.pool_state() == (1, 0, 1)
+    got = [[None] * 6 for _ in range(4)]
+    start = threading.Barrier(4)
+    def worker(i):
+        start.wait()
+        for k in range(6):
+            got[i][k] = g.process(prs[i][0], prs[i][1], 0.5)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [x.start() for x in th]; [x.join() for x in th]
+    for i in range(4):
+        for k in range(6):
+            assert np.array_equal(got[i][k], want[i])
+    pooled, leased, hw = g.pool_state()
+    assert leased == 0 and 2 <= hw <= 4 and 1 <= pooled <= hw, (pooled, leased, hw)
+    for k in range(33):                                             # 32 leases with one caller in flight flush the history
+        assert np.array_equal(g.process(prs[k % 4][0], prs[k % 4][1], 0.5), want[k % 4])
+    assert g.pool_state() == (1, 0, 1)
