@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="TEST MODE for a 1-GPU box: all ranks use device 0 and rendezvous over gloo (RCCL refuses two ranks on one device); "
                     "exercises the N-rank code paths (sharding, barriers, the all-ranks host-buffer leg) on real HIP work.  The line is labelled and is not a scaling measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configs (extra.configs: 1080p, v23-1080p, 4k-tta) that the default call appends")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the ~ 4 s sustained leg with socket power / shader clock sampling (extra.sustained)")
     ap.add_argument("--dry-run", action="store_true", help="CPU plumbing check (gloo): launcher, sharding, barrier, MAX over ranks, JSON; no HIP work")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -285,6 +286,12 @@ def main():
         el = sh.timed_steps(lambda i: run_steps(i, args.steps), 1, first_index=args.warmup, dist=dist, device_sync=torch.cuda.synchronize,
                             make_tensor=lambda v, dtype: torch.tensor(v, dtype=dtype, device=coll_dev))
         region_fps.append(world * args.steps / el)
+    # sustained leg (rank 0 of a 1-GPU run): the same steps for ~ 4 s while a thread reads the socket power and the shader clock (rocm-smi).  Every BASELINE
+    # workload runs at the board's power cap (profiles/r6/power_workloads.txt: 1,337 - 1,400 W of 1,400, 1.8 - 2.05 GHz): the clock the matrix pipe really gets is
+    # part of the roofline story, and the sustained rate is a few per cent below the first K steps of a cool chip.  Never `value`.
+    sustained = None
+    if world == 1 and not args.no_sustained:
+        sustained = sustained_leg(lambda n: run_steps(args.warmup, n), region_fps[0], torch.cuda.synchronize)
     # PCIe-inclusive legs: the boundary call the reference CLI makes (RIFE::process on host frames: H2D x2 + pass + D2H inside the
     # call, src/rife.cpp:2522-2530, 3176-3186) from pageable host memory, 1 and 2 caller threads (the reference's default -j 1:2:2)
     host = None
@@ -450,6 +457,7 @@ def main():
                       "frames_per_s_host_buffers": None if host is None else dict(host, note="rife_hip_process on host frames: 2 x H2D + pass + D2H inside the call (PCIe-inclusive; never `value`); page_locked = frames from rife_hip_host_alloc; process_batch_one_thread = ONE caller, rife_hip_process_batch over the region's K pairs"),
                       "frames_per_s_host_buffers_all_ranks": None if host_all is None else dict(host_all, note="every rank at once: one caller per rank, rife_hip_process_batch over its K host-frame pairs, one barrier-bracketed region; whole-job rate = pairs of all ranks / MAX elapsed (PCIe-inclusive; never `value`)"),
                       "numa": numa,
+                      "sustained": sustained,
                       "frames_per_s_same_region_with_per_launch_events": round(world * args.steps / elapsed_instr, 3),
                       "frames_per_s_with_1_pair_in_flight": None if fps1 is None else round(fps1, 3), "kernel_ms_per_pair": round(all_ms / args.steps, 4), "conv_ms_per_pair": round(conv_ms / args.steps, 4),
                       "conv_tflops_overall": round(gflop_pair / max(conv_ms / args.steps, 1e-9), 2),
@@ -615,6 +623,47 @@ def cpu_baseline_small_frames():
         except Exception as e:
             sys.stderr.write("bench.py: oracle frame for %s unavailable (%s)\n" % (name, e))
     return out
+
+
+def sustained_leg(run_n, fps_guess, device_sync, seconds=4.0):
+    """~ `seconds` of the timed region's steps while a thread samples `rocm-smi --showpower --showclocks` (Current Socket Graphics Package Power, sclk):
+    {frames_per_s, seconds, power_w / sclk_mhz medians over the second half of the leg, power_cap_w}.  Figures are None where rocm-smi is not usable."""
+    import subprocess
+    import threading
+    n = max(8, int(fps_guess * seconds))
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            try:
+                t = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                pw = [float(l.split(":")[-1]) for l in t.splitlines() if "Socket Graphics Package Power" in l]
+                fq = [float(l.split("(")[-1].split("Mhz")[0]) for l in t.splitlines() if "sclk clock level" in l]
+                if pw and fq:
+                    samples.append((time.perf_counter(), pw[0], fq[0]))
+            except Exception:
+                time.sleep(0.2)
+    cap = None
+    try:
+        t = subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
+        capv = [float(l.split(":")[-1]) for l in t.splitlines() if "Max Graphics Package Power" in l]
+        cap = capv[0] if capv else None
+    except Exception:
+        pass
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    device_sync()
+    t0 = time.perf_counter()
+    run_n(n)
+    device_sync()
+    t1 = time.perf_counter()
+    stop[0] = True
+    th.join(timeout=15)
+    tail = [(p, f) for (t, p, f) in samples if t0 + 0.5 * (t1 - t0) <= t <= t1]
+    med = lambda v: sorted(v)[len(v) // 2] if v else None
+    return {"frames_per_s": round(n / (t1 - t0), 3), "seconds": round(t1 - t0, 2), "steps": n, "power_w": med([p for p, _ in tail]), "sclk_mhz": med([f for _, f in tail]),
+            "power_cap_w": cap, "samples": len(tail), "f16_mfma_peak_at_that_clock_tflops": None if not tail else round(F16_MFMA_PEAK_TFLOPS * med([f for _, f in tail]) / 2400.0, 1),
+            "note": "the timed region's steps for ~ %.0f s, rocm-smi sampled by a second thread (second half of the leg); dense f16 matrix peak scaled from 2,400 MHz; never `value`" % seconds}
 
 
 def cpu_model():

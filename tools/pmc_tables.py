@@ -14,9 +14,11 @@ import shutil
 import sys
 
 PASSES = {"mfma_lds": "SQ_VALU_MFMA_BUSY_CYCLES", "wait": "SQ_WAIT_ANY", "fetch": "FETCH_SIZE", "write": "WRITE_SIZE"}
-DOMINANT = "conv_rs_kernel"       # round 3: the row-streaming kernel serves the block-3 trunk (round 2: "conv_t64_kernel<3, 2>")
-DOMINANT_OF = {"4k": "conv_rs_kernel", "1080p": "conv_rs_kernel", "4k_tta": "conv_rs_kernel", "v23_1080p": "conv_h2_kernel<3, 9, 0>"}
-TRUNKS = ("conv_rs_kernel", "conv_t64_kernel", "conv_row_kernel", "conv_ks_kernel", "conv_h2_kernel", "conv_h2b_kernel")
+# the dominant kernel per workload: the first of these symbols that has dispatches (round 6: conv_rs2_kernel, two block-3 trunk layers per launch; round 3 - 5:
+# conv_rs_kernel, which still serves segments too short for conv_rs2 and the summaries committed by earlier rounds; round 2: "conv_t64_kernel<3, 2>")
+DOMINANT = ("conv_rs2_kernel", "conv_rs_kernel")
+DOMINANT_OF = {"4k": DOMINANT, "1080p": DOMINANT, "4k_tta": DOMINANT, "v23_1080p": ("conv_h2_kernel<3, 9, 0>",)}
+TRUNKS = ("conv_rs2_kernel", "conv_rs_kernel", "conv_t64_kernel", "conv_row_kernel", "conv_ks_kernel", "conv_h2_kernel", "conv_h2b_kernel")
 
 
 def parse(path):
@@ -37,16 +39,17 @@ def main(src, dst, pairs=3, wl="4k"):
     os.makedirs(dst, exist_ok=True)
     tabs = {}
     sfx = "" if wl == "4k" else "_" + wl
-    dominant = DOMINANT_OF.get(wl, DOMINANT)
+    dominant_names = DOMINANT_OF.get(wl, DOMINANT)
     for short, first in PASSES.items():
         s = os.path.join(src, "pmc_%s%s_all.txt" % (first, sfx))
         shutil.copy(s, os.path.join(dst, "pmc_all_kernels_%s_%s.txt" % (wl, short)))
         tabs[short] = parse(s)
     f, w, m = tabs["fetch"], tabs["write"], tabs["mfma_lds"]
+    dominant = next((d for d in dominant_names if any(d in k for k in f)), dominant_names[0])
     # ---- trunk kernels
     with open(os.path.join(dst, "pmc_trunk_kernels_%s.txt" % wl), "w") as o:
         o.write("# bash tools/profile_round.sh: rocprofv3 --kernel-trace --pmc <pass> -- python tools/prof_run.py --workload %s --pairs %d   (MI355X)\n" % (wl.replace("_", "-"), pairs))
-        o.write("# per-dispatch means for the trunk kernels (rife-v4.6: trunk_b3 = conv_rs_kernel<0>, 64 channels; trunk_b2 = conv_t64_kernel<2, 3> / conv_row_kernel<96>, 96 channels; coarse blocks conv_row / conv_h2b), 4 separate PMC passes\n")
+        o.write("# per-dispatch means for the trunk kernels (rife-v4.6: trunk_b3 = conv_rs2_kernel<0> (two layers per launch; conv_rs_kernel<0> before round 6), 64 channels; trunk_b2 = conv_t64_kernel<2, 3> / conv_row_kernel<96>, 96 channels; coarse blocks conv_row / conv_h2b), 4 separate PMC passes\n")
         for short in PASSES:
             for k, c in tabs[short].items():
                 if any(t in k for t in TRUNKS):

@@ -10,7 +10,7 @@ set -u
 TAG=${1:-r4}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profile_$TAG
-DOM=${DOM:-conv_rs_kernel}
+DOM=${DOM:-conv_rs2_kernel}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $ROOT/tools/prof_run.py --workload 4k --pairs 8 > $OUT/kt.log 2>&1
@@ -39,6 +39,8 @@ done
 rm -rf $OUT/kt $OUT/kt1080
 cd $ROOT
 timeout 400 python tools/rs_bench.py > $OUT/rs_bench.txt 2>&1
+timeout 400 python tools/rs2_bench.py > $OUT/rs2_bench.txt 2>&1
+timeout 600 python tools/power_workloads.py 8 > $OUT/power_workloads.txt 2>&1
 timeout 300 python tools/ks_bench.py > $OUT/ks_bench.txt 2>&1
 timeout 300 python tools/stem_rs_bench.py > $OUT/stem_rs_bench.txt 2>&1
 timeout 300 python tools/tail_rs_bench.py > $OUT/tail_rs_bench.txt 2>&1

@@ -40,17 +40,20 @@ for h, w, g in cases:
     print("%4dx%-4d planned for %-3s CUs (%d segments per strip, %d workgroups) vs conv_rs x 2: bytes differing down %d, up %d of %d %s%s" % (h, w, g or "all", st[6], st[7], st[0], st[1], st[2],
           "OK" if ok else "MISMATCH", "" if ok else " first at plane %d padded row %d col %d" % (st[3], st[4], st[5])), flush=True)
 print("parity: %s" % ("byte-identical everywhere" if not bad else "%d cases differ" % bad), flush=True)
+# bursts of IT launches (~ 0.15 - 0.3 s per variant): 40 launches (7 ms) ran at the clock of an idle chip ramping up (177 us per conv_rs2 launch against 108 in a
+# 0.8 s burst, profiles/r6/rs2_power.txt); inside a pass the chip sits at the 1,400 W cap (1.8 GHz) and a launch takes 147 us (bench.py, roofline.avg_launch_ms)
+IT = 1500
 sizes = ((544, 960),) if quick else ((544, 960), (272, 480))
 for h, w in sizes:
     for rep in range(2 if quick else 3):
-        rc, us = rs(h, w, 0x10000, 40)
+        rc, us = rs(h, w, 0x10000, IT)
         print("%dx%d conv_rs  x 2, layers alternate direction   rc=%d %.1f us" % (h, w, rc, 2 * us), flush=True)
         for name, v in (("full (down)", 0), ("full, launches alternate direction", 0x10000), ("full (up)", 0x20000), ("no stores", NOSTORE), ("no DMA", NODMA),
                         ("no DMA, no stores (math only)", NODMA | NOSTORE), ("no math", NOMATH), ("no math, no stores (loads only)", NOMATH | NOSTORE), ("no math, no DMA (stores only)", NOMATH | NODMA)):
-            rc, us, _ = rs2(h, w, v, 40)
+            rc, us, _ = rs2(h, w, v, IT)
             print("%dx%d conv_rs2 %-36s rc=%d %.1f us" % (h, w, name, rc, us), flush=True)
         for g in (128, 64):
-            rc, us, _ = rs2(h, w, (g << 24) | 0x10000, 40)
+            rc, us, _ = rs2(h, w, (g << 24) | 0x10000, IT)
             print("%dx%d conv_rs2 planned for %3d CUs                   rc=%d %.1f us" % (h, w, g, rc, us), flush=True)
 rc, us, _ = rs2(544, 960, 0x1000, 20)
 print("544x960 conv_rs2 barrier trace (stderr) rc=%d %.1f us" % (rc, us), flush=True)
