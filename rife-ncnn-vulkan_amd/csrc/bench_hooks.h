@@ -720,7 +720,17 @@ int rife_hip_bench_rs2(int gpuid, int h, int w, int variant, int iters, float* m
     a.kparts = kparts; a.nseg = nstrips * kparts; a.descend = 0; a.limit = (int)(nb - 16);
     const int nwg = std::min(plan_cus, a.nseg);
     const bool alternate = (variant & 0x10000) != 0, up = (variant & 0x20000) != 0;
+    // 0x80000: "cold" mode - the input is one of four fixed random tensors, the output one of four others, in rotation (1.07 GB at 4K, four times the 256 MB
+    // MALL): every launch reads from HBM like a launch inside a pass does, and the data stays what it is (the default mode feeds every launch its predecessor's
+    // output, in and out 267 MB together: after a few thousand launches the tensor is whatever x <- layerB(layerA(x)) converges to, and half of it sits in the MALL)
+    const bool cold = (variant & 0x80000) != 0;
+    const bool fixed = (variant & 0x100000) != 0;      // 0x100000: every launch reads the SAME random tensor x and writes y (267 MB like the ping-pong mode, but the data never changes)
     variant &= 0xffff | RS_CLK;
+    unsigned char *xs[4] = {x, nullptr, nullptr, nullptr}, *ys[4] = {y, nullptr, nullptr, nullptr};
+    if (cold) for (int k = 1; k < 4; k++) {
+        HIPCHK(hipMalloc(&xs[k], nb)); HIPCHK(hipMalloc(&ys[k], nb));
+        HIPCHK(hipMemcpy(xs[k], x, nb, hipMemcpyDeviceToDevice)); HIPCHK(hipMemset(ys[k], 0, nb));
+    }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rs2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, RS2_LDS));
     if (stats) {
         for (int i = 0; i < 8; i++) stats[i] = -1;
@@ -762,7 +772,9 @@ int rife_hip_bench_rs2(int gpuid, int h, int w, int variant, int iters, float* m
         for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kfn, dim3(nwg), dim3(RS2_NTHR), RS2_LDS, 0, a);
         HIPCHK(hipEventRecord(e0, 0));
         for (int i = 0; i < iters; i++) {
-            a.in = (i & 1) ? y : x; a.out = (i & 1) ? x : y;
+            if (cold) { a.in = xs[i & 3]; a.out = ys[i & 3]; }
+            else if (fixed) { a.in = x; a.out = y; }
+            else { a.in = (i & 1) ? y : x; a.out = (i & 1) ? x : y; }
             a.descend = up ? 1 : (alternate ? (i & 1) : 0);
             hipLaunchKernelGGL(kfn, dim3(nwg), dim3(RS2_NTHR), RS2_LDS, 0, a);
         }
@@ -772,7 +784,30 @@ int rife_hip_bench_rs2(int gpuid, int h, int w, int variant, int iters, float* m
         *ms_out = t / iters;
         return 0;
     };
-    if (iters > 0) switch (variant) {
+    if (iters > 0 && (variant & RS_CLK)) {
+        // per-workgroup life of the LAST launch: shader cycles and 100 MHz real-time ticks at start / end (conv_rs2.h, TAG & RS_CLK)
+        long long* dst = nullptr;
+        HIPCHK(hipMalloc(&dst, (size_t)nwg * 32)); HIPCHK(hipMemset(dst, 0, (size_t)nwg * 32));
+        a.stamps = dst;
+        rc = run(conv_rs2_kernel<RS_CLK>);
+        std::vector<long long> hs((size_t)nwg * 4);
+        HIPCHK(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(dst);
+        long long s0 = LLONG_MAX, e1c = 0;
+        std::vector<double> life(nwg), ghz(nwg), start(nwg);
+        for (int i = 0; i < nwg; i++) { s0 = std::min(s0, hs[4 * i + 1]); e1c = std::max(e1c, hs[4 * i + 2]); }
+        for (int i = 0; i < nwg; i++) {
+            life[i] = (hs[4 * i + 2] - hs[4 * i + 1]) * 0.01; start[i] = (hs[4 * i + 1] - s0) * 0.01;
+            ghz[i] = (double)hs[4 * i] / std::max(1.0, (double)(hs[4 * i + 2] - hs[4 * i + 1])) * 0.1;
+        }
+        auto pct = [](std::vector<double> v, double p) { std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
+        fprintf(stderr, "rs2 clk (%s), last launch, %d workgroups: first start -> last end %.1f us | workgroup life us min %.1f p10 %.1f median %.1f p90 %.1f max %.1f | start spread us median %.1f max %.1f | GHz median %.3f min %.3f max %.3f\n",
+                cold ? "cold" : fixed ? "fixed input" : "ping-pong", nwg, (e1c - s0) * 0.01, pct(life, 0), pct(life, 0.1), pct(life, 0.5), pct(life, 0.9), pct(life, 1), pct(start, 0.5), pct(start, 1), pct(ghz, 0.5), pct(ghz, 0), pct(ghz, 1));
+        for (int x = 0; x < 8; x++) {                                    // workgroup b runs on XCD b % 8
+            std::vector<double> v; for (int i = x; i < nwg; i += 8) v.push_back(life[i]);
+            if (!v.empty()) fprintf(stderr, "   XCD %d: life median %.1f max %.1f us\n", x, pct(v, 0.5), pct(v, 1));
+        }
+    } else if (iters > 0) switch (variant) {
         case 0: rc = run(conv_rs2_kernel<0>); break;
         case RS_NOSTORE: rc = run(conv_rs2_kernel<RS_NOSTORE>); break;
         case RS_NODMA: rc = run(conv_rs2_kernel<RS_NODMA>); break;
@@ -811,6 +846,7 @@ int rife_hip_bench_rs2(int gpuid, int h, int w, int variant, int iters, float* m
         }
         default: rc = fail(RIFE_HIP_EINVAL, "unknown variant");
     }
+    for (int k = 1; k < 4; k++) { if (xs[k]) (void)hipFree(xs[k]); if (ys[k]) (void)hipFree(ys[k]); }
     (void)hipFree(x); (void)hipFree(y); (void)hipFree(yr); (void)hipFree(tm); (void)hipFree(dimg[0]); (void)hipFree(dimg[1]); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;
 }

@@ -52,11 +52,23 @@ for h, w in sizes:
                         ("no DMA, no stores (math only)", NODMA | NOSTORE), ("no math", NOMATH), ("no math, no stores (loads only)", NOMATH | NOSTORE), ("no math, no DMA (stores only)", NOMATH | NODMA)):
             rc, us, _ = rs2(h, w, v, IT)
             print("%dx%d conv_rs2 %-36s rc=%d %.1f us" % (h, w, name, rc, us), flush=True)
+        COLD = 0x80000
+        for name, v in (("full, cold, alternate", COLD | 0x10000), ("no stores, cold", COLD | NOSTORE), ("no DMA, cold", COLD | NODMA), ("no math, cold", COLD | NOMATH),
+                        ("no math, no stores, cold (loads only)", COLD | NOMATH | NOSTORE), ("no math, no DMA, cold (stores only)", COLD | NOMATH | NODMA)):
+            rc, us, _ = rs2(h, w, v, IT)
+            print("%dx%d conv_rs2 %-36s rc=%d %.1f us" % (h, w, name, rc, us), flush=True)
+        rc, us, _ = rs2(h, w, 0x100000, IT)
+        print("%dx%d conv_rs2 %-36s rc=%d %.1f us" % (h, w, "full, fixed input x -> y", rc, us), flush=True)
         for g in (128, 64):
             rc, us, _ = rs2(h, w, (g << 24) | 0x10000, IT)
             print("%dx%d conv_rs2 planned for %3d CUs                   rc=%d %.1f us" % (h, w, g, rc, us), flush=True)
-rc, us, _ = rs2(544, 960, 0x1000, 20)
+for v, nm in ((0x40000, "ping-pong"), (0x40000 | 0x100000, "fixed input x -> y (267 MB like ping-pong, data never changes)"), (0x40000 | 0x80000, "cold: four rotating fixed inputs (1.07 GB)")):
+    rc, us, _ = rs2(544, 960, v, 600)
+    print("544x960 conv_rs2 per-workgroup clocks, %s (stderr) rc=%d %.1f us" % (nm, rc, us), flush=True)
+rc, us, _ = rs2(544, 960, 0x1000, 600)
 print("544x960 conv_rs2 barrier trace (stderr) rc=%d %.1f us" % (rc, us), flush=True)
-rc, us, _ = rs2(544, 960, 0x1000 | NODMA | NOSTORE, 20)
+rc, us, _ = rs2(544, 960, 0x1000 | 0x80000, 600)
+print("544x960 conv_rs2 barrier trace, cold mode (stderr) rc=%d %.1f us" % (rc, us), flush=True)
+rc, us, _ = rs2(544, 960, 0x1000 | NODMA | NOSTORE, 600)
 print("544x960 conv_rs2 barrier trace, math only (stderr) rc=%d %.1f us" % (rc, us), flush=True)
 sys.exit(1 if bad else 0)

@@ -9,24 +9,23 @@ L = benchlib.lib()
 L.rife_hip_bench_rs.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_longlong)]
 L.rife_hip_bench_rs2.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_longlong)]
 NOSTORE, NODMA, NOMATH, NOFRAG, NOLO = 0x100, 0x200, 0x400, 0x10, 0x20
-secs = float(sys.argv[1]) if len(sys.argv) > 1 else 1.2
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 2.5
 
-def find(pattern):
-    g = glob.glob(pattern)
-    return g[0] if g else None
-PW = find("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input") or find("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")
-FQ = find("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")
+import subprocess
 samples, stop = [], [False]
-def sampler():
+def sampler():      # rocm-smi's "Current Socket Graphics Package Power" follows the load within ~ 50 ms (the hwmon power1_input file is a slow average: useless for 1 s bursts)
     while not stop[0]:
         try:
-            p = int(open(PW).read()) / 1e6 if PW else -1
-            f = int(open(FQ).read()) / 1e6 if FQ else -1
+            t = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+            pw = [float(l.split(":")[-1]) for l in t.splitlines() if "Socket Graphics Package Power" in l]
+            fq = [float(l.split("(")[-1].split("Mhz")[0]) for l in t.splitlines() if "sclk clock level" in l]
+            if pw and fq:
+                samples.append((time.perf_counter(), pw[0], fq[0]))
         except Exception:
-            p = f = -1
-        samples.append((time.perf_counter(), p, f))
-        time.sleep(0.05)
+            time.sleep(0.1)
 th = threading.Thread(target=sampler, daemon=True); th.start()
+time.sleep(1.5)
+IDLE = sum(p for _, p, _ in samples) / max(1, len(samples))
 
 def run(fn, h, w, variant, us_guess):
     iters = max(50, int(secs * 1e6 / us_guess))
@@ -41,7 +40,7 @@ def run(fn, h, w, variant, us_guess):
     pw = sum(p for p, _ in sel) / max(1, len(sel)); fq = sum(f for _, f in sel) / max(1, len(sel))
     return rc, ms.value * 1e3, pw, fq, len(sel)
 
-print("power file %s, clock file %s" % (PW, FQ), flush=True)
+print("idle socket power %.0f W (%d samples before the first burst)" % (IDLE, len(samples)), flush=True)
 H, W = 544, 960
 for rep in range(2):
     for name, fn, v, g in (("conv_rs  full (x 2 layers)", L.rife_hip_bench_rs, 0x10000, 90), ("conv_rs  math only", L.rife_hip_bench_rs, NODMA | NOSTORE, 50), ("conv_rs  no math", L.rife_hip_bench_rs, NOMATH, 50),
@@ -51,5 +50,5 @@ for rep in range(2):
                            ("conv_rs2 no math", L.rife_hip_bench_rs2, NOMATH, 70), ("conv_rs2 no stores", L.rife_hip_bench_rs2, NOSTORE, 140), ("conv_rs2 no DMA", L.rife_hip_bench_rs2, NODMA, 140)):
         rc, us, pw, fq, n = run(fn, H, W, v, g)
         per_layer = us / 2 if fn is L.rife_hip_bench_rs2 else us
-        print("%-40s rc=%d %7.1f us per launch (%.1f per layer)  %6.0f W  %5.0f MHz  (%d samples)  -> %.3f J per layer" % (name, rc, us, per_layer, pw, fq, n, pw * per_layer * 1e-6), flush=True)
+        print("%-40s rc=%d %7.1f us per launch (%.1f per layer)  %6.0f W  %5.0f MHz  (%d samples)  -> %.4f J per layer, %.4f above idle" % (name, rc, us, per_layer, pw, fq, n, pw * per_layer * 1e-6, (pw - IDLE) * per_layer * 1e-6), flush=True)
 stop[0] = True
