@@ -200,9 +200,15 @@ static int lease_ctx(const rife_hip* E, std::unique_ptr<Ctx>& c, int w, int h, i
             std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
             int mine = 0;
             for (int cu = 0; cu < ncu; cu++) if (cu % parts == part) { mask[cu / 32] |= 1u << (cu % 32); mine++; }
-            if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipExtStreamCreateWithCUMask failed");
+            if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) c->stream = nullptr;
             c->cu_budget = mine;
-        } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(RIFE_HIP_EHIP, "hipStreamCreate failed");
+        } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) c->stream = nullptr;
+        if (!c->stream) {                                                // no stream: the lease never happened (a workspace without one must not reach the pool through the caller's release)
+            std::lock_guard<std::mutex> g(E->mu);
+            E->leased--; E->part_live[parts][part]--;
+            c.reset();
+            return fail(RIFE_HIP_EHIP, parts > 1 ? "hipExtStreamCreateWithCUMask failed" : "hipStreamCreate failed");
+        }
         c->own_stream = true;
     }
     tl_cu_budget = c->cu_budget;                                         // the caller enqueues on this workspace's stream next
@@ -588,7 +594,7 @@ static int rife_hip_process_device_batch_impl(const rife_hip_t* E, int n, const 
     std::unique_ptr<Ctx> copy_ctx;                       // timestep 0 / 1 with no caller stream: one internal stream for the D2D copies
     size_t next_slot = 0;
     auto lease_new = [&](std::unique_ptr<Ctx>& c) -> bool {
-        if (lease_ctx(E, c, w, h, 1)) return false;
+        if (lease_ctx(E, c, w, h, 1)) { if (c) release_ctx(E, c); return false; }      // a workspace whose tensors could not be allocated still returns its lease
         if (!c->ev_group && hipEventCreateWithFlags(&c->ev_group, hipEventDisableTiming) != hipSuccess) { release_ctx(E, c); return false; }
         if (user && hipStreamWaitEvent(c->stream, fork, 0) != hipSuccess) { release_ctx(E, c); return false; }
         return true;
