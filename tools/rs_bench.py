@@ -4,6 +4,9 @@
 1. agreement with conv_t64 (same products, another summation order: |difference| ~1e-6) on random S16 tensors at aligned, ragged and tiny sizes, walking down and up, with 1 .. #CU workgroups;
 2. per-launch time of both kernels (interleaved rounds in one process), ablations of conv_rs (no stores / no LDS-DMA / no matrix work /
    raised priority / non-temporal loads and stores), the clock probe."""
+# NOTE (round 6): the timing loops of this tool feed every launch its predecessor's output (ping-pong); after a few hundred launches the tensor has converged to
+# constants and the matrix pipe rewards that with a higher clock (conv_rs2: 110 us at 2.26 GHz in this mode, 144 - 154 us at 1.63 GHz on data that stays random:
+# tools/rs2_bench.py, profiles/r6/rs2_bench_real_data.txt).  Read these figures as A/B ratios, not as what a launch costs inside a pass.
 import ctypes, os, sys
 sys.path.insert(0, os.getcwd())
 from tools import benchlib

@@ -6,6 +6,9 @@ no matrix work / no vmcnt wait, and combinations.  Then the clock probe (200 bac
 median workgroup life, first start -> last end, the gap to the previous launch and the shader clock = cycles / 100 MHz ticks, and writes the last
 launch's per-workgroup records to gpurun_out/t64_clk_<variant>.bin).  Then one stamped launch: per workgroup, wave and step the shader clock at
 (3) DMA issued + epilogue done = start of the step's matrix work, (0) end of it, (1) this wave's DMA pieces landed, (2) barrier passed."""
+# NOTE (round 6): the timing loops of this tool feed every launch its predecessor's output (ping-pong); after a few hundred launches the tensor has converged to
+# constants and the matrix pipe rewards that with a higher clock (conv_rs2: 110 us at 2.26 GHz in this mode, 144 - 154 us at 1.63 GHz on data that stays random:
+# tools/rs2_bench.py, profiles/r6/rs2_bench_real_data.txt).  Read these figures as A/B ratios, not as what a launch costs inside a pass.
 import ctypes, importlib, os, struct, sys, statistics
 sys.path.insert(0, os.getcwd())
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
