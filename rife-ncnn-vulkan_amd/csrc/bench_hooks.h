@@ -226,6 +226,7 @@ int rife_hip_bench_mfma_mix(int gpuid, int mix, int tiles, int iters, float* ms_
         }
         v = (int)w;
     }
+    if (mix & 0x100) { for (auto& v : h) v = 0; mix &= 0xff; }      // 0x100: all-zero operands - the same instruction stream without the data's toggling (tools/mfma_power_peak.py)
     int* d = nullptr; float* o = nullptr;
     HIPCHK(hipMalloc(&d, h.size() * 4)); HIPCHK(hipMalloc(&o, 4));
     HIPCHK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));

@@ -28,7 +28,8 @@ threading.Thread(target=sampler, daemon=True).start()
 time.sleep(1.0)
 TILES = 256
 for rep in range(2):
-    for mix, name, nmfma in ((0, "160 x v_mfma_f32_32x32x16_f16 per tile (the hi + lo mix)", 160), (2, "80 x v_mfma_f32_32x32x16_f16 per tile (hi only)", 80)):
+    for mix, name, nmfma in ((0, "160 x v_mfma_f32_32x32x16_f16 per tile (the hi + lo mix)", 160), (2, "80 x v_mfma_f32_32x32x16_f16 per tile (hi only)", 80),
+                             (0x100, "160 per tile, ALL-ZERO operands (same instruction stream, no toggling)", 160)):
         flop = 512 * 8 * TILES * nmfma * 32 * 32 * 16 * 2.0
         ms = ctypes.c_float()
         assert L.rife_hip_bench_mfma_mix(0, mix, TILES, 3, ctypes.byref(ms)) == 0, L.rife_hip_last_error()
