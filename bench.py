@@ -38,10 +38,12 @@ F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense v_mfma_f32_32x32x
 F16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 HBM_PEAK_TBPS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak
 # What the f16 matrix pipe SUSTAINS on random operands on this pool's MI355X boxes (tools/mfma_power_peak.py, profiles/r6/mfma_power_peak.txt: nothing but
-# v_mfma_f32_32x32x16_f16 on register operands, 2.5 s bursts): 1,364 TFLOP/s at 1,086 W and 1.86 GHz - 0.55 of the 2,500 TFLOP/s figure.  Real data clocks the
-# matrix pipe down (conv_rs2 on random tensors: 1.63 GHz, 144 - 154 us per launch; on a tensor that has converged to constants: 2.26 GHz, 110 us;
-# profiles/r6/rs2_bench_real_data.txt).  `roofline.peak` stays the guide's figure; the fields *_of_sustained price the same rates against this measured one.
-F16_MFMA_SUSTAINED_TFLOPS = 1364.0
+# v_mfma_f32_32x32x16_f16 on register operands, bursts of seconds): 1,743 - 1,756 TFLOP/s at 1,320 W and 1.80 GHz with the pipe 94 % busy (one wave per SIMD, two
+# or four accumulation chains; four waves per SIMD x four chains: 1,710 - 1,744) - 0.70 of the 2,500 TFLOP/s figure, which the same loop reaches on all-zero
+# operands (2,461 - 2,477 at 2.40 GHz, 860 - 890 W).  Real data clocks the matrix pipe down (conv_rs2 on random tensors: 1.63 GHz, 144 - 154 us per launch; on a
+# tensor that has converged to constants: 2.26 GHz, 110 us; profiles/r6/rs2_bench_real_data.txt).  `roofline.peak` stays the guide's figure; the fields
+# *_of_sustained price the same rates against this measured one.
+F16_MFMA_SUSTAINED_TFLOPS = 1750.0
 # dominant kernel per family: (profile class, kernel symbol, channels C of the C->C 3x3 trunk conv, MFMA instructions issued per
 # algorithmic product: 2 for the split-f16 scheme (hi and lo) x the identity tap of the folded skip connection)
 DOMINANT = {"rife-v4.6": ("trunk_b3", "conv_rs2_kernel (IFNet block-3 trunk: TWO 3x3 convs 64->64 + skip + LeakyReLU per launch, the first layer's rows LDS-resident; row-streaming, specialised waves; split-f16 MFMA, S16 {hi, lo} tensors)", 64, 2.0 * 38 / 36),
@@ -87,7 +89,7 @@ def roofline_of(dom, family, w, h, f32_mode):
             "algorithmic_tflops": round(tflops, 1), "mfma_frac_survey_basis": round(tflops / F16_MFMA_PEAK_TFLOPS, 4),
             "mfma_frac_issued": round(tflops * mfma_factor / F16_MFMA_PEAK_TFLOPS, 4),
             "mfma_sustained_tflops": F16_MFMA_SUSTAINED_TFLOPS, "mfma_frac_issued_of_sustained": round(tflops * mfma_factor / F16_MFMA_SUSTAINED_TFLOPS, 4),
-            "mfma_sustained_basis": "dense f16 matrix rate sustained on random operands by a bare v_mfma_f32_32x32x16_f16 loop on this pool's MI355X (tools/mfma_power_peak.py, profiles/r6/mfma_power_peak.txt): 1,364 of the nominal 2,500 TFLOP/s"}
+            "mfma_sustained_basis": "dense f16 matrix rate sustained on random operands by a bare v_mfma_f32_32x32x16_f16 loop on this pool's MI355X (tools/mfma_power_peak.py, profiles/r6/mfma_power_peak.txt): 1,750 of the nominal 2,500 TFLOP/s, at 1,320 W and 1.80 GHz"}
 
 
 DOMINANT_SYMBOL = {"rife-v4.6": ("conv_rs2_kernel", "conv_rs_kernel"), "rife-v2.3": ("conv_h2_kernel<3, 9, 0>",)}      # first symbol with dispatches in the trace
@@ -441,7 +443,7 @@ def main():
         # that compares across rounds
         if roof is not None and roofline_ms is not None:
             roof["e2e_frac"] = round(roofline_ms / (elapsed / args.steps * 1e3), 5)
-            # the same pair against the matrix work it cannot avoid at the rate the chip sustains: 2 products (hi, lo) x the algorithmic flops / 1,364 TFLOP/s
+            # the same pair against the matrix work it cannot avoid at the rate the chip sustains: 2 products (hi, lo) x the algorithmic flops / 1,750 TFLOP/s
             roof["e2e_frac_of_sustained_mfma"] = round(2.0 * gflop_pair / F16_MFMA_SUSTAINED_TFLOPS / (elapsed / args.steps * 1e3), 5)
             roof["e2e_basis"] = ("%s per pair (%.3f ms, SURVEY 8(d)) / ms_per_step"
                                  % ("matrix-roofline time (597.5 GFLOP / 2.5 PFLOP/s)" if family == "rife-v2.3" else "fused-minimum HBM time", roofline_ms))

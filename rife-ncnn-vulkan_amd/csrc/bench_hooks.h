@@ -142,6 +142,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int n = 0; n < 2; n++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+    if (MIX == 4) {      // round 6: FOUR independent accumulation chains per wave (160 instructions per tile like MIX 0): no wave ever waits for its own previous result
+        f32x16 acc4[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc4[n][r] = 0.f;
+        for (int t = 0; t < tiles; t++) {
+#pragma unroll
+            for (int k = 0; k < 40; k++)
+#pragma unroll
+                for (int n = 0; n < 4; n++) acc4[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[(k + n) & 3], xb[(k + (n >> 1)) & 3], acc4[n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[0][r] = acc4[0][r] + acc4[2][r]; acc[1][r] = acc4[1][r] + acc4[3][r]; }
+    } else
     for (int t = 0; t < tiles; t++) {
 #pragma unroll
         for (int k = 0; k < 40; k++) {
@@ -226,15 +241,23 @@ int rife_hip_bench_mfma_mix(int gpuid, int mix, int tiles, int iters, float* ms_
         }
         v = (int)w;
     }
-    if (mix & 0x100) { for (auto& v : h) v = 0; mix &= 0xff; }      // 0x100: all-zero operands - the same instruction stream without the data's toggling (tools/mfma_power_peak.py)
+    const bool one_wave = (mix & 0x200) != 0;      // 0x200: 256 workgroups of 4 waves = ONE wave per SIMD (the matrix waves of conv_rs / conv_rs2 run like this)
+    if (mix & 0x100) for (auto& v : h) v = 0;
+    mix &= 0xff;      // 0x100: all-zero operands - the same instruction stream without the data's toggling (tools/mfma_power_peak.py)
     int* d = nullptr; float* o = nullptr;
     HIPCHK(hipMalloc(&d, h.size() * 4)); HIPCHK(hipMalloc(&o, 4));
     HIPCHK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     auto launch = [&]() {
+        if (one_wave) {
+            if (mix == 4) hipLaunchKernelGGL(k_bench_mfma_mix<4>, dim3(256), dim3(256), 0, 0, d, o, tiles);
+            else hipLaunchKernelGGL(k_bench_mfma_mix<0>, dim3(256), dim3(256), 0, 0, d, o, tiles);
+            return;
+        }
         if (mix == 0) hipLaunchKernelGGL(k_bench_mfma_mix<0>, dim3(512), dim3(512), 0, 0, d, o, tiles);
         else if (mix == 1) hipLaunchKernelGGL(k_bench_mfma_mix<1>, dim3(512), dim3(512), 0, 0, d, o, tiles);
         else if (mix == 3) hipLaunchKernelGGL(k_bench_mfma_mix<3>, dim3(512), dim3(512), 0, 0, d, o, tiles);
+        else if (mix == 4) hipLaunchKernelGGL(k_bench_mfma_mix<4>, dim3(512), dim3(512), 0, 0, d, o, tiles);
         else hipLaunchKernelGGL(k_bench_mfma_mix<2>, dim3(512), dim3(512), 0, 0, d, o, tiles);
     };
     for (int i = 0; i < 3; i++) launch();
