@@ -321,22 +321,25 @@ def test_malformed_param_files_are_refused_not_fatal(modeldirs, tmp_path):
 
 
 def test_pmc_tables_reads_the_committed_summaries(tmp_path):
-    """tools/pmc_tables.py on the per-kernel PMC summaries kept in profiles/r4, for every bench workload: the derived files are complete and the
+    """tools/pmc_tables.py on the per-kernel PMC summaries kept in profiles/r4 and profiles/r6, for every bench workload: the derived files are complete and the
     dominant kernel's traffic is what bench.py falls back to for roofline.traffic when it cannot measure it live."""
     import json, shutil
     from tools import pmc_tables
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for wl, dom, floor in (("4k", "conv_rs_kernel", 2.6e8), ("1080p", "conv_rs_kernel", 6.6e7), ("v23_1080p", "conv_h2_kernel<3, 9, 0>", 5e7), ("4k_tta", "conv_rs_kernel", 2.6e8)):
-        src = tmp_path / ("src_" + wl); src.mkdir()
+    # round 4: conv_rs_kernel, one trunk layer per launch; round 6: conv_rs2_kernel, two layers per launch (one input + one output tensor: the same stored bytes)
+    for rnd, wl, dom, floor in (("r4", "4k", "conv_rs_kernel", 2.6e8), ("r4", "1080p", "conv_rs_kernel", 6.6e7), ("r4", "v23_1080p", "conv_h2_kernel<3, 9, 0>", 5e7),
+                                ("r4", "4k_tta", "conv_rs_kernel", 2.6e8), ("r6", "4k", "conv_rs2_kernel", 2.6e8), ("r6", "1080p", "conv_rs2_kernel", 6.6e7),
+                                ("r6", "v23_1080p", "conv_h2_kernel<3, 9, 0>", 5e7), ("r6", "4k_tta", "conv_rs2_kernel", 2.6e8)):
+        src = tmp_path / ("src_%s_%s" % (rnd, wl)); src.mkdir()
         sfx = "" if wl == "4k" else "_" + wl
         for short, first in pmc_tables.PASSES.items():
-            shutil.copy(os.path.join(root, "profiles", "r4", "pmc_all_kernels_%s_%s.txt" % (wl, short)), src / ("pmc_%s%s_all.txt" % (first, sfx)))
-        dst = tmp_path / ("dst_" + wl)
+            shutil.copy(os.path.join(root, "profiles", rnd, "pmc_all_kernels_%s_%s.txt" % (wl, short)), src / ("pmc_%s%s_all.txt" % (first, sfx)))
+        dst = tmp_path / ("dst_%s_%s" % (rnd, wl))
         pmc_tables.main(str(src), str(dst), 1 if wl == "4k_tta" else 3, wl)
         j = json.load(open(dst / ("pmc_%s.json" % wl)))
-        committed = json.load(open(os.path.join(root, "profiles", "r4", "pmc_%s.json" % wl)))
+        committed = json.load(open(os.path.join(root, "profiles", rnd, "pmc_%s.json" % wl)))
         assert j["hbm_bytes_per_launch"] == committed["hbm_bytes_per_launch"] > floor and dom in j["kernel"]      # at least what the layer stores
-        assert committed["source"].startswith("profiles/r4/")
+        assert committed["source"].startswith("profiles/%s/" % rnd)
         table = open(dst / ("bandwidth_kernels_%s.txt" % wl)).read()
         assert dom.split("<")[0] in table
         derived = [l for l in open(dst / ("pmc_trunk_kernels_%s.txt" % wl)) if "matrix pipe busy" in l]
