@@ -34,6 +34,7 @@ WORKLOADS = {
     "v23-1080p": ("rife-v2.3", 1920, 1080, 597.5, 0.239, False, False),   # BASELINE config 2; the survey gives FLOPs only: 597.5 G / 2.5 PFLOP/s = 0.239 ms (matrix roofline, 4,180 frames/s)
     "4k-tta": ("rife-v4.6", 3840, 2160, 16 * 701.0, 16 * 0.701, True, True),   # BASELINE config 5 (-x -z) on one GPU
 }
+DEFAULT_PARTS = {"4k": 2, "1080p": 2, "v23-1080p": 4, "4k-tta": 0}      # CU partitions of the streams in the timed region (0 = ordinary streams), see main()
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense v_mfma_f32_32x32x2_f32 peak
 F16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 HBM_PEAK_TBPS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak
@@ -243,7 +244,9 @@ def main():
         f = np.roll(base[i % 2], (2 * (i // 2), 5 * (i // 2)), axis=(0, 1))
         frames.append(torch.from_numpy(np.ascontiguousarray(f)).cuda())
     timesteps = [0.5, 0.125, 0.25, 0.7, 0.9]
-    cu_parts = args.cu_parts if args.cu_parts >= 0 else (4 if args.workload in ("1080p", "v23-1080p") else 2 if args.workload == "4k" else 0)
+    # default layouts (same-call sweeps: profiles/r4/cumask_probe.txt, profiles/r5/stream_layouts.txt, profiles/r6/layout_sweep.txt): rife-v4.6 at 4K and (since round 6)
+    # at 1080p four pairs in flight, two per half of the compute units (1080p: 1,807-1,838 against 1,796-1,807 frames/s from one per quarter); rife-v2.3 one per quarter
+    cu_parts = args.cu_parts if args.cu_parts >= 0 else DEFAULT_PARTS.get(args.workload, 0)
     nstreams = args.streams if args.streams > 0 else (4 if cu_parts > 1 else 2)
 
     class PartStream:                                        # a stream of rife_hip_stream_create, with torch.cuda.Stream's attribute
@@ -556,7 +559,7 @@ def other_configs(amd, torch, sh, local, eng46, base4k, oracle_small):
             for i in range(4):
                 f = np.roll(pair[i % 2], (2 * (i // 2), 5 * (i // 2)), axis=(0, 1))
                 frames.append(torch.from_numpy(np.ascontiguousarray(f)).cuda())
-            cu_parts = 0 if tta else 4
+            cu_parts = DEFAULT_PARTS.get(name, 0)
             nstreams = 2 if tta else 4
             fps, _ = leg_fps(torch, sh, eng, frames, w, h, nstreams, cu_parts, steps, warmup, local)
             # dominant kernel of the leg: HIP events per launch, ONE pair in flight on the whole chip
