@@ -212,6 +212,7 @@ struct rife_hip {
     mutable std::unique_ptr<Ctx> tta_ctx[2][8];                          // [direction][orientation]
     static constexpr int NLANE = 4;                                      // spatial TTA: orientations run on 4 worker streams
     mutable hipStream_t tta_lane[NLANE] = {nullptr, nullptr, nullptr, nullptr};
+    mutable int tta_lane_cus = 0;                                        // > 0: the lanes are CU-masked streams that own this many compute units each (run_v4_tta)
     mutable hipEvent_t tta_fork[6] = {}, tta_join[6][NLANE] = {};
 
     ~rife_hip() {

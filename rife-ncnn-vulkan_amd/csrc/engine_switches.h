@@ -38,6 +38,7 @@ struct Switches {
     bool v2_fused_stem;        // RIFE_HIP_V2_FUSED_STEM=0: k2_assemble + conv_h2s2 instead of stem2_fused_kernel
     bool v2_stem_r64;          // RIFE_HIP_V2_STEM_R64=0: scale-1 fused stem with two workgroups per CU
     bool v2_skip_copy;         // RIFE_HIP_V2_SKIP_COPY=1: U-Net skips copied (k2_copy_view) instead of stored twice
+    int tta_lane_parts;        // RIFE_HIP_TTA_LANE_PARTS=2 / 4: the four orientation lanes of -x on CU-masked streams, two per half / one per quarter (default 0: ordinary streams - measured faster)
     int pool_parts;            // RIFE_HIP_POOL_PARTS: 2 / 4 = pool streams own 1 / 2, 1 / 4 of the compute units; 3 = that layout from four callers in flight on; else whole-chip streams (default: measured faster, pool_layout)
     // ---- engine scope
     bool t64, rs, rs2, stem_rs, tta_consensus, tail_rs, tail_rs_always, fuse_flow;      // RIFE_HIP_T64 / RS / RS2 / STEM_RS / TTA_CONSENSUS / TAIL_RS (0, 2) / FUSE_FLOW=1
@@ -76,6 +77,7 @@ static Switches read_switches() {
     s.v2_stem_r64 = not_off(ab("RIFE_HIP_V2_STEM_R64"));
     s.v2_skip_copy = on(ab("RIFE_HIP_V2_SKIP_COPY"));
     s.pool_parts = num(ab("RIFE_HIP_POOL_PARTS"), -1, 0, 4);
+    s.tta_lane_parts = num(ab("RIFE_HIP_TTA_LANE_PARTS"), 0, 0, 4);
     s.t64 = not_off(ab("RIFE_HIP_T64"));
     s.rs = not_off(ab("RIFE_HIP_RS"));
     s.rs2 = not_off(ab("RIFE_HIP_RS2"));

@@ -533,14 +533,30 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
     constexpr int NL = rife_hip::NLANE;
     const bool lanes = nori == 8;          // the 8 orientations are independent between consensus points: 4 worker streams
     int rc;
+    // The four lanes are ordinary streams.  Round 6 measured them as CU-masked streams (RIFE_HIP_TTA_LANE_PARTS=2 / 4, test build: two per half / one per quarter
+    // of the compute units - the layout that gives plain 4K pairs + 5 %, profiles/r6/layout_sweep.txt): SLOWER here, 22.4 - 22.7 / 22.0 - 22.4 against 25.3 - 25.4
+    // frames/s at 4K and 59 - 60 against 80 at 1080p, identical bytes (profiles/r6/ab_tta_lane_parts.txt): the lanes meet at a consensus after every block, and a
+    // lane that is done early leaves its part of the chip idle where an ordinary stream's neighbours would take it over.
+    const int lane_parts = lanes ? process_switches().tta_lane_parts : 0;
     if (lanes && !E.tta_lane[0]) {
-        for (int l = 0; l < NL; l++) HIPCHK(hipStreamCreateWithFlags(&E.tta_lane[l], hipStreamNonBlocking));
+        const int ncu = device_cus(true);
+        for (int l = 0; l < NL; l++) {
+            if (lane_parts > 1) {
+                std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+                int mine = 0;
+                for (int cu = 0; cu < ncu; cu++) if (cu % lane_parts == l % lane_parts) { mask[cu / 32] |= 1u << (cu % 32); mine++; }
+                HIPCHK(hipExtStreamCreateWithCUMask(&E.tta_lane[l], (uint32_t)mask.size(), mask.data()));
+                E.tta_lane_cus = mine;
+            } else HIPCHK(hipStreamCreateWithFlags(&E.tta_lane[l], hipStreamNonBlocking));
+        }
         for (int i = 0; i < 6; i++) {
             HIPCHK(hipEventCreateWithFlags(&E.tta_fork[i], hipEventDisableTiming));
             for (int l = 0; l < NL; l++) HIPCHK(hipEventCreateWithFlags(&E.tta_join[i][l], hipEventDisableTiming));
         }
     }
     auto lane_of = [&](int ti) { return lanes ? E.tta_lane[ti % NL] : st; };
+    const int caller_budget = tl_cu_budget, lane_budget = lanes && lane_parts > 1 ? E.tta_lane_cus : tl_cu_budget;      // persistent kernels size their grids for the stream they are enqueued on
+    struct BudgetGuard { int keep; ~BudgetGuard() { tl_cu_budget = keep; } } budget_guard{caller_budget};
     for (int dir = 0; dir < ntemp; dir++)
         for (int ti = 0; ti < nori; ti++) {
             auto& up = E.tta_ctx[dir][ti];
@@ -587,6 +603,7 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
     for (int fi = 0; fi < 4; fi++) {
         const int Wf = wp / E.flow_div(fi), Hf = hp / E.flow_div(fi);
         if ((rc = fork())) return rc;
+        tl_cu_budget = lane_budget;
         for (int ti = 0; ti < nori; ti++) {
             hipStream_t ls = lane_of(ti);
             for (int dir = 0; dir < ntemp; dir++) {
@@ -602,6 +619,7 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
             }
         }
         if ((rc = join())) return rc;
+        tl_cu_budget = caller_budget;
         if (fused_consensus) {       // -x -z: temporal and spatial consensus of the sixteen flow tensors in one pass (k_v4_consensus)
             Timed t(E.prof, "tta_merge", 0, st);
             Ptr8x2 f;
@@ -622,9 +640,11 @@ static int run_v4_tta(const rife_hip& E, hipStream_t st, const uint8_t* d_in0, c
                 HIPCHK(hipEventRecord(E.tta_fork[5], st));
                 for (int l = 0; l < NL; l++) HIPCHK(hipStreamWaitEvent(E.tta_lane[l], E.tta_fork[5], 0));
             }
+            tl_cu_budget = lane_budget;
             for (int ti = 0; ti < nori; ti++)
                 for (int dir = 0; dir < ntemp; dir++)
                     if ((rc = run_flow_update(E, *E.tta_ctx[dir][ti], fi))) return rc;
+            tl_cu_budget = caller_budget;
         }
     }
     Ptr16 outs;
