@@ -237,8 +237,18 @@ static void release_ctx(const rife_hip* E, std::unique_ptr<Ctx>& c) {
 // H2D of both frames, the whole pass and the D2H of the result, all enqueued on the workspace's stream (no host wait)
 static int enqueue_host_pair(const rife_hip* E, Ctx& c, const uint8_t* in0, const uint8_t* in1, int w, int h, float timestep, uint8_t* out) {
     const size_t nbytes = (size_t)w * h * 3;
-    hipError_t e = hipMemcpyAsync(c.d_in0, in0, nbytes, hipMemcpyHostToDevice, c.stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(c.d_in1, in1, nbytes, hipMemcpyHostToDevice, c.stream);
+    hipError_t e;
+    {
+        // Upload token (round 6, RIFE_HIP_H2D_TOKEN=0 in the test build: off): one caller uploads at a time and holds the token until its two frames have landed.
+        // Callers that run in lockstep - all copying over the one PCIe link at once, then all computing - fall out of phase by construction: B's upload rides
+        // under A's pass (tools/host_path_bench2.py: 2 caller threads read anything between 272 and 446 frames/s at 4K without it, profiles/r6/ab_h2d_token.txt).
+        const bool token = process_switches().h2d_token;
+        std::unique_lock<std::mutex> g(E->h2d_mu, std::defer_lock);
+        if (token) g.lock();
+        e = hipMemcpyAsync(c.d_in0, in0, nbytes, hipMemcpyHostToDevice, c.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c.d_in1, in1, nbytes, hipMemcpyHostToDevice, c.stream);
+        if (e == hipSuccess && token) e = hipStreamSynchronize(c.stream);      // page-locked frames: the copies above only enqueue
+    }
     if (e != hipSuccess) return fail(RIFE_HIP_EHIP, std::string("H2D: ") + hipGetErrorString(e));
     int rc;
     if (E->v1) rc = run_v1(*E, c, c.d_in0, c.d_in1, c.d_out);
@@ -299,7 +309,11 @@ int rife_hip_process_batch(const rife_hip_t* E, int n, const uint8_t* const* in0
     // three workers = three pairs in flight: tools/host_path_bench2.py, 4K, 48 pairs: process() from 1 / 2 / 3 / 4 caller threads
     // 192 / 341 / 389 / 365 frames/s from pageable frames (resident frames: 395), 244 / 307 / 349 / 344 from page-locked ones
     const int batch_workers = process_switches().batch_workers;
-    const int K = std::min(n, batch_workers ? batch_workers : 4);      // round 4: four workers (measured against 3 / 5 / 6 / 8: 4K 439 vs 426 / 426 / 431 / 446, 1080p 1,334 vs 1,251 / 1,367 / 1,443 / 1,398 pageable; page-locked best at 4)
+    // round 4: four workers (measured against 3 / 5 / 6 / 8: 4K 439 vs 426 / 426 / 431 / 446, 1080p 1,334 vs 1,251 / 1,367 / 1,443 / 1,398 pageable; page-locked best at 4).
+    // Round 6, with conv_rs2 and the trimmed pool (profiles/r6/ab_batch_workers.txt, same call, two rounds): frames of 4 Mpixel and more are better served by SIX -
+    // 4K 492 - 495 pageable / 482 - 488 page-locked against 481 - 482 / 450 - 456 from four (3: 468 / 431, 8: 466 - 468 / 436 - 438): at the resident-frame rate;
+    // 1080p stays at four (6: + 1 ... 7 % pageable, - 3 ... 5 % page-locked)
+    const int K = std::min(n, batch_workers ? batch_workers : ((long long)w * h >= 4000000ll ? 6 : 4));
     // A host frame that serves several pairs of the batch (consecutive pairs of a sequence share one) crosses PCIe once: it becomes a
     // resident frame on first use and is released after its last (stream mode, below).  Batches without shared frames run as before.
     struct Shared { std::mutex mu; rife_hip_frame_t* f = nullptr; int left = 0; };

@@ -201,6 +201,7 @@ struct rife_hip {
     mutable int leased = 0;                                              // pool workspaces in use = callers in flight
     mutable int lease_hist[32] = {};                                     // callers in flight at each of the last 32 leases: the pool is trimmed to their maximum
     mutable unsigned lease_n = 0;
+    mutable std::mutex h2d_mu;                                            // upload token of the host-frame entry points (enqueue_host_pair)
     mutable int pool_parts_now = 1;                                      // the layout of the latest lease (pool_layout)
     mutable int part_live[5][4] = {};                                    // [parts][part]: leased workspaces per partition of the chip
     mutable std::vector<hipEvent_t> batch_fork;                          // rife_hip_process_device_batch: recycled fork events

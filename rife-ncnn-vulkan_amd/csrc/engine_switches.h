@@ -39,6 +39,7 @@ struct Switches {
     bool v2_stem_r64;          // RIFE_HIP_V2_STEM_R64=0: scale-1 fused stem with two workgroups per CU
     bool v2_skip_copy;         // RIFE_HIP_V2_SKIP_COPY=1: U-Net skips copied (k2_copy_view) instead of stored twice
     int tta_lane_parts;        // RIFE_HIP_TTA_LANE_PARTS=2 / 4: the four orientation lanes of -x on CU-masked streams, two per half / one per quarter (default 0: ordinary streams - measured faster)
+    bool h2d_token;            // RIFE_HIP_H2D_TOKEN=0: host-frame callers upload concurrently (A/B; default: one upload at a time, enqueue_host_pair)
     int pool_parts;            // RIFE_HIP_POOL_PARTS: 2 / 4 = pool streams own 1 / 2, 1 / 4 of the compute units; 3 = that layout from four callers in flight on; else whole-chip streams (default: measured faster, pool_layout)
     // ---- engine scope
     bool t64, rs, rs2, stem_rs, tta_consensus, tail_rs, tail_rs_always, fuse_flow;      // RIFE_HIP_T64 / RS / RS2 / STEM_RS / TTA_CONSENSUS / TAIL_RS (0, 2) / FUSE_FLOW=1
@@ -77,6 +78,7 @@ static Switches read_switches() {
     s.v2_stem_r64 = not_off(ab("RIFE_HIP_V2_STEM_R64"));
     s.v2_skip_copy = on(ab("RIFE_HIP_V2_SKIP_COPY"));
     s.pool_parts = num(ab("RIFE_HIP_POOL_PARTS"), -1, 0, 4);
+    s.h2d_token = not_off(ab("RIFE_HIP_H2D_TOKEN"));
     s.tta_lane_parts = num(ab("RIFE_HIP_TTA_LANE_PARTS"), 0, 0, 4);
     s.t64 = not_off(ab("RIFE_HIP_T64"));
     s.rs = not_off(ab("RIFE_HIP_RS"));
