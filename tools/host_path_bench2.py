@@ -7,11 +7,17 @@ from tools import gen_models, gen_frames
 amd = importlib.import_module("rife-ncnn-vulkan_amd")
 # --test-build: the test build (reads RIFE_HIP_POOL_PARTS: 0 = whole-chip pool streams at every caller count, the round-5 behaviour); default: the product
 mod = amd.test_build() if "--test-build" in sys.argv else amd
-print("library: %s, RIFE_HIP_POOL_PARTS=%s" % ("test build" if mod is not amd else "product", os.environ.get("RIFE_HIP_POOL_PARTS", "(unset)")), flush=True)
+print("frames: %s; library: %s, RIFE_HIP_POOL_PARTS=%s" % ("smooth blocky pair" if "--smooth" in sys.argv else "F1 (real pair tiled)", "test build" if mod is not amd else "product", os.environ.get("RIFE_HIP_POOL_PARTS", "(unset)")), flush=True)
 g = mod.RIFE(0, rife_v4=True); g.load(gen_models.ensure(None, "rife-v4.6"))
 for (w, h) in ((3840, 2160), (1920, 1080)):
-    base = gen_frames.smooth_pair(w // 4, h // 4, 3)
-    fr = [np.ascontiguousarray(np.kron(np.roll(base[i % 2], 5 * i, axis=1), np.ones((4, 4, 1), np.uint8))) for i in range(9)]
+    # frames: F1 like bench.py (the reference's real pair tiled to size, rolled per index) - the matrix pipe's clock depends on the data (profiles/r6/README.md), so
+    # the resident-frame `value` of bench.py and these PCIe-inclusive rates are only comparable on the same frames; --smooth: the blocky smooth pair of rounds 2 - 5
+    if "--smooth" in sys.argv:
+        base = gen_frames.smooth_pair(w // 4, h // 4, 3)
+        fr = [np.ascontiguousarray(np.kron(np.roll(base[i % 2], 5 * i, axis=1), np.ones((4, 4, 1), np.uint8))) for i in range(9)]
+    else:
+        base = gen_frames.tiled_real_pair(w // 640)
+        fr = [np.ascontiguousarray(np.roll(base[i % 2], (2 * (i // 2), 5 * (i // 2)), axis=(0, 1))) for i in range(9)]
     n = 96
     for kind in ("pageable", "page-locked"):
         if kind == "page-locked":
